@@ -1,0 +1,47 @@
+# Builds the product library (libhrt.so: HIP kernels for gfx950 + host C ABI) and the CPU oracle.
+#   make            -> nvidia-optix-ray-tracer_amd/lib/libhrt.so, oracle/liboracle.so, tools
+#   make lib        -> the product library only
+#   make oracle     -> the test oracle only
+HIPCC   ?= /opt/rocm/bin/hipcc
+CXX     ?= g++
+PKG     := nvidia-optix-ray-tracer_amd
+CSRC    := $(PKG)/csrc
+LIBDIR  := $(PKG)/lib
+ARCH    := gfx950
+
+# -ffp-contract=off: arithmetic that feeds control flow must round exactly like the oracle.
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) -Wall -pthread
+
+all: lib oracle tools
+
+lib: $(LIBDIR)/libhrt.so
+
+$(LIBDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/device_types.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/hrt_api.o: $(CSRC)/hrt_api.cpp $(CSRC)/device_types.h $(CSRC)/bvh8.h include/hrt.h include/hrt_params.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/bvh8_build.o: $(CSRC)/bvh8_build.cpp $(CSRC)/bvh8.h
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -c $< -o $@
+
+$(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/hrt_api.o $(LIBDIR)/bvh8_build.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -pthread
+
+oracle:
+	$(MAKE) -C oracle
+
+tools: $(LIBDIR)/hrt_render
+
+$(LIBDIR)/hrt_render: $(CSRC)/host/hrt_render.cpp $(CSRC)/host/renderer_host.hpp $(LIBDIR)/libhrt.so
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Iinclude -I$(CSRC) -o $@ $< -L$(LIBDIR) -lhrt -Wl,-rpath,'$$ORIGIN'
+
+clean:
+	rm -rf $(LIBDIR)
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib oracle tools clean

@@ -1,0 +1,159 @@
+/*
+ * hrt.h -- C ABI of the MI355X wavefront path tracer (libhrt.so).
+ *
+ * Drop-in boundary for ONE path of the reference: the per-frame ray-tracing
+ * launch and the acceleration-structure calls that feed it.  Every entry point
+ * names the reference call site it replaces (paths relative to the reference
+ * tree).  Plain pointers and sizes only; "stream" is a hipStream_t passed as
+ * void* (NULL = the null stream, which is what the reference uses).
+ *
+ * Conventions
+ *   - every function returns HRT_OK (0) or a negative HrtStatus; the message of
+ *     the last failure on a context is hrt_last_error(ctx).  (The reference
+ *     logs and exit()s through its check macros, include/Global/HostFunctions.cuh:147-166;
+ *     a library cannot, so the caller re-wraps.)
+ *   - d_* parameters are DEVICE pointers owned by the caller, h_* are host pointers.
+ *   - acceleration-structure memory is owned by the handle (reference:
+ *     cleanupAccelerationStructure, src/Global/RendererImpl.cu:244-266).
+ *   - *_build calls are thread-safe per context (reference builds from several
+ *     loader threads, src/Global/RendererMesh.cu:93-100); hrt_render_launch is
+ *     called from one thread at a time per context.
+ *   - there is NO CPU fallback: without a gfx950 device every compute entry
+ *     point fails with HRT_ERR_NO_DEVICE.
+ */
+#ifndef HRT_H
+#define HRT_H
+
+#include <stdint.h>
+#include "hrt_params.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum HrtStatus {
+    HRT_OK               =  0,
+    HRT_ERR_INVALID      = -1,   /* bad argument                                 */
+    HRT_ERR_NO_DEVICE    = -2,   /* no HIP device / wrong architecture           */
+    HRT_ERR_HIP          = -3,   /* a HIP runtime call failed                    */
+    HRT_ERR_OOM          = -4,
+    HRT_ERR_STATE        = -5    /* call order (e.g. launch before materials_set)*/
+} HrtStatus;
+
+typedef struct HrtContext HrtContext;
+
+/* context flags */
+#define HRT_CTX_TIMING   0x1u    /* bracket every kernel with HIP events (hrt_get_stats) */
+#define HRT_CTX_COUNT    0x2u    /* traverse kernel counts node visits / primitive tests */
+
+/* replaces createContext / destroyContext, src/Global/RendererImpl.cu:6-27 */
+int  hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx);
+int  hrt_ctx_destroy(HrtContext *ctx);
+int  hrt_ctx_set_flags(HrtContext *ctx, uint32_t flags);   /* switch HRT_CTX_TIMING / HRT_CTX_COUNT at run time */
+const char *hrt_last_error(const HrtContext *ctx);        /* ctx may be NULL: creation errors */
+const char *hrt_version(void);
+
+/* replaces buildGASForTriangles / buildGASForParticle, src/Global/RendererImpl.cu:89-111,139-172.
+ * d_vertices: float3, stride 12, every 3 consecutive vertices are one triangle (no index
+ * buffer, as the reference).  n_vertices must be a multiple of 3.  The caller may free
+ * d_vertices after the call returns (Mesh mode does, src/Global/RendererMesh.cu:116). */
+int  hrt_blas_build_triangles(HrtContext *ctx, const HrtFloat3 *d_vertices, uint32_t n_vertices,
+                              void *stream, HrtTraversable *out_blas);
+/* replaces buildGASForSpheres, src/Global/RendererImpl.cu:113-138 */
+int  hrt_blas_build_spheres(HrtContext *ctx, const HrtFloat3 *d_centers, const float *d_radii,
+                            uint32_t n_spheres, void *stream, HrtTraversable *out_blas);
+int  hrt_blas_destroy(HrtContext *ctx, HrtTraversable blas);
+
+/* replaces buildIAS / updateIAS, src/Global/RendererImpl.cu:174-242.  d_instances lives in
+ * device memory (reference: cudaMemcpy H2D then build, src/Global/RendererMesh.cu:151-160). */
+int  hrt_tlas_build(HrtContext *ctx, const HrtInstance *d_instances, uint32_t n_instances,
+                    void *stream, HrtTraversable *out_tlas);
+int  hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_instances,
+                     uint32_t n_instances, void *stream);
+int  hrt_tlas_destroy(HrtContext *ctx, HrtTraversable tlas);
+
+/* replaces optixSbtRecordPackHeader as used at src/Global/RendererImpl.cu:514-560 */
+int  hrt_sbt_record_pack_header(HrtProgram program, void *record_header);
+/* replaces the hit-group SBT upload, src/Global/RendererMesh.cu:283-305: record i belongs
+ * to the instance whose sbtOffset is i.  h_records is host memory; it is copied. */
+int  hrt_materials_set(HrtContext *ctx, const HrtSbtRecord *h_records, uint32_t n_records);
+/* replaces the miss record of createRaygenMissSBTRecord, src/Global/RendererImpl.cu:472-492 */
+int  hrt_miss_set(HrtContext *ctx, const HrtMissParams *h_miss);
+
+/* replaces RandomGenerator::initDeviceRandomGenerators / freeDeviceRandomGenerators,
+ * src/Global/HostFunctions.cu:122-140: allocates W*H states and initialises state i with
+ * curand_init(seed = i ^ seed_salt, subsequence = i, offset = 0).  seed_salt pins the
+ * reference's clock64() term (quirk Q8); the kernel is bounds-checked and indexes by the
+ * frame width (fixes quirk Q9). */
+int  hrt_rng_init(HrtContext *ctx, uint32_t width, uint32_t height, uint64_t seed_salt,
+                  void *stream, HrtRngState **out_d_states);
+int  hrt_rng_free(HrtContext *ctx, HrtRngState *d_states, void *stream);
+
+/* replaces optixLaunch(pipeline, stream, dev_params, sizeof(GlobalParams), &sbt, W, H, 1)
+ * + cudaDeviceSynchronize, src/Global/RendererMesh.cu:416-419 / RendererTime.cu:497-500.
+ * h_params / h_raygen are HOST copies of the two blocks the reference uploads each frame
+ * (RendererMesh.cu:403-413).  spp successive samples are taken on the persistent per-pixel
+ * RNG streams; the colour written is colorToFloat4(mean of the samples), which for spp = 1
+ * is exactly the reference's frame.  tile == NULL renders the whole frame; rows outside the
+ * tile are left untouched.  The call returns after the work has been ENQUEUED on stream;
+ * hrt_sync (or any stream sync) completes it. */
+int  hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params,
+                       const HrtRayGenParams *h_raygen, uint32_t spp,
+                       const HrtTile *tile, void *stream);
+int  hrt_sync(HrtContext *ctx, void *stream);
+
+/* replaces convertFloat4ToUchar4Kernel, src/Global/RendererImpl.cu:672-678 (second sRGB
+ * encode: quirk Q7) */
+int  hrt_to_rgba8(HrtContext *ctx, const HrtFloat4 *d_src, HrtUchar4 *d_dst,
+                  uint32_t width, uint32_t height, void *stream);
+
+/* ---- measurement (no reference counterpart: the reference has no timers) ------------- */
+enum { HRT_K_GENERATE = 0, HRT_K_TRAVERSE, HRT_K_TRAVERSE_ANY, HRT_K_BIN, HRT_K_SHADE,
+       HRT_K_ACCUMULATE, HRT_K_FINALIZE, HRT_K_COUNT };
+
+typedef struct HrtStats {
+    uint64_t rays;                         /* trace calls since the last reset (1..5 per pixel-sample) */
+    uint64_t rays_closest, rays_any;       /* split by traverse kernel                                 */
+    uint64_t paths;                        /* pixel-samples                                            */
+    uint64_t node_visits, prim_tests;      /* HRT_CTX_COUNT only, closest+any                          */
+    uint64_t node_visits_closest, prim_tests_closest;   /* the closest-hit kernel's share            */
+    double   kernel_ms[HRT_K_COUNT];       /* HRT_CTX_TIMING only: summed HIP-event time per kernel    */
+    uint64_t kernel_launches[HRT_K_COUNT];
+    uint64_t bvh_nodes, bvh_triangles, bvh_spheres;   /* of the TLAS last launched               */
+    uint64_t bvh_bytes;
+} HrtStats;
+
+int  hrt_stats_reset(HrtContext *ctx);
+int  hrt_stats_get(HrtContext *ctx, HrtStats *out);       /* synchronises the device */
+
+/* ---- introspection used by the parity tests ------------------------------------------ */
+/* Trace n rays (origin/direction float3 arrays on the device, tmin/tmax as in the shader)
+ * through a TLAS with the closest-hit kernel and write t,u,v (float) and prim,inst (u32;
+ * 0xffffffff on miss) per ray.  This is the traverse kernel of hrt_render_launch run on a
+ * caller-supplied queue. */
+int  hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_origins,
+                    const HrtFloat3 *d_directions, uint32_t n_rays, float tmin, float tmax,
+                    int any_hit, float *d_t, float *d_u, float *d_v,
+                    uint32_t *d_prim, uint32_t *d_inst, void *stream);
+
+/* When set (non-NULL), every following launch also writes the linear mean radiance (the value
+ * colorToFloat4 is applied to, shader/Shader.cu:270) as W*H float4, so that tests can compare
+ * it bit-for-bit with the oracle.  Pass NULL to switch it off. */
+int  hrt_debug_set_linear_output(HrtContext *ctx, HrtFloat4 *d_linear);
+
+/* Host-only BVH8 build over triangles given as 9 floats each (no GPU needed): returns the
+ * packed node and primitive blobs the device kernels traverse.  Free with hrt_host_free. */
+typedef struct HrtBvhBlob {
+    void    *nodes;      uint64_t n_nodes;      /* 80-byte packed BVH8 nodes             */
+    void    *triangles;  uint64_t n_triangles;  /* 48-byte triangle records, leaf order  */
+    float    bounds[6];
+} HrtBvhBlob;
+int  hrt_host_build_bvh8(const float *h_triangles, uint32_t n_triangles, HrtBvhBlob *out);
+/* Copy the flattened world-space BVH of a TLAS back to the host (same blob format). */
+int  hrt_tlas_download(HrtContext *ctx, HrtTraversable tlas, HrtBvhBlob *out);
+void hrt_host_free(HrtBvhBlob *blob);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRT_H */

@@ -1,0 +1,70 @@
+// bvh8.h -- packed BVH8 layout shared by the host builder and the HIP traversal kernels.
+//
+// Replaces what optixAccelBuild produces for the reference (src/Global/RendererImpl.cu:30-88,
+// 174-208): an opaque RT-core BVH.  Here the structure is explicit:
+//
+//   Bvh8Node (80 B, five 16-byte loads per visit), after Ylitie/Karras/Laine 2017
+//   ("Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs"):
+//     word 0-2  origin p (float3)            child boxes are p + q * 2^e per axis
+//     word 3    ex | ey<<8 | ez<<16 | imask<<24     (e biased by 127, imask: bit s = slot s is an inner node)
+//     word 4    child_base   (index of the first inner child; inner children are contiguous, slot order)
+//     word 5    prim_base    (index of the first primitive record of this node's leaves)
+//     word 6-7  meta[8]      inner: 0b001_11000 | slot; leaf: unary count (1,3,7)<<5 | prim offset; empty: 0
+//     word 8-9  qlo_x[8]   word 10-11 qlo_y[8]   word 12-13 qlo_z[8]
+//     word 14-15 qhi_x[8]  word 16-17 qhi_y[8]   word 18-19 qhi_z[8]
+//
+//   PrimRecord (48 B, three 16-byte loads per test), world space, leaf order:
+//     triangle: {v0.xyz, prim} {e1.xyz, inst} {e2.xyz, 0}        e1 = v1 - v0, e2 = v2 - v0 (float)
+//     sphere:   {c.xyz,  prim} {r, 0, 0, inst} {0, 0, 0, 1}      object-space centre/radius
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace hrt {
+
+struct alignas(16) Bvh8Node {
+    float    p[3];
+    uint8_t  e[3];
+    uint8_t  imask;
+    uint32_t child_base;
+    uint32_t prim_base;
+    uint8_t  meta[8];
+    uint8_t  qlo[3][8];
+    uint8_t  qhi[3][8];
+};
+static_assert(sizeof(Bvh8Node) == 80, "packed BVH8 node is 80 bytes");
+
+struct alignas(16) PrimRecord {
+    float    a[3]; uint32_t prim;
+    float    b[3]; uint32_t inst;
+    float    c[3]; uint32_t kind;      // 0 triangle, 1 sphere
+};
+static_assert(sizeof(PrimRecord) == 48, "primitive record is 48 bytes");
+
+constexpr uint32_t kMaxLeafPrims = 3;      // unary count in 3 bits
+constexpr uint32_t kPrimKindTriangle = 0, kPrimKindSphere = 1;
+
+// Input primitive for the builder: a record plus its (unpadded) world-space bounds.
+struct BuildPrim {
+    PrimRecord rec;
+    float lo[3], hi[3];
+};
+
+struct Bvh8 {
+    std::vector<Bvh8Node>   nodes;
+    std::vector<PrimRecord> prims;
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    uint32_t n_triangles = 0, n_spheres = 0;
+    uint32_t max_depth = 0;
+    std::vector<float>      prim_bounds;   // 6 floats per primitive, leaf order (host-side checks only)
+};
+
+// Deterministic host build (binned SAH BVH2 -> greedy collapse to 8-wide -> octant slot
+// assignment -> outward-rounded 8-bit quantisation).  threads <= 0: hardware concurrency.
+void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads = 0);
+
+// Structural self-check used by the CPU tests: every primitive's bounds lie inside the
+// dequantised box of every ancestor slot.  Returns an empty string when consistent.
+const char *validate_bvh8(const Bvh8 &bvh);
+
+}  // namespace hrt

@@ -1,0 +1,360 @@
+// bvh8_build.cpp -- deterministic host builder for the packed BVH8 the HIP kernels traverse.
+//
+// Stands in for optixAccelBuild (reference: src/Global/RendererImpl.cu:30-88 buildASImpl,
+// :174-208 buildIAS).  OptiX's builder is closed; this one is:
+//   1. binned-SAH BVH2 over padded primitive bounds (16 bins x 3 axes, leaves <= 3 prims),
+//      big subtrees built on worker threads (topology does not depend on thread timing);
+//   2. greedy collapse to 8-wide nodes (always open the inner child with the largest area);
+//   3. octant-ordered slot assignment so that (slot ^ (7 - ray_octant)) approximates
+//      front-to-back order during traversal;
+//   4. outward-rounded 8-bit quantisation of the child boxes against the node origin/exponent.
+#include "bvh8.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <thread>
+
+namespace hrt {
+namespace {
+
+struct B2 {
+    float lo[3], hi[3];
+    uint32_t left, right;     // inner
+    uint32_t first, count;    // leaf when count > 0
+};
+
+inline float half_area(const float *lo, const float *hi) {
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+struct Builder {
+    const std::vector<BuildPrim> &in;
+    std::vector<float> plo, phi, cen;   // padded bounds + centroid, 3 per prim
+    std::vector<uint32_t> idx;
+    std::vector<B2> nodes;
+    std::atomic<uint32_t> n_nodes{0};
+    int max_par_depth = 0;
+
+    explicit Builder(const std::vector<BuildPrim> &p) : in(p) {}
+
+    uint32_t alloc2() { return n_nodes.fetch_add(2); }
+
+    void bounds_of(uint32_t b, uint32_t e, float *lo, float *hi, float *clo, float *chi) const {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = clo[a] = std::numeric_limits<float>::infinity();
+            hi[a] = chi[a] = -std::numeric_limits<float>::infinity();
+        }
+        for (uint32_t i = b; i < e; ++i) {
+            const uint32_t p = idx[i];
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::min(lo[a], plo[3 * p + a]);
+                hi[a] = std::max(hi[a], phi[3 * p + a]);
+                clo[a] = std::min(clo[a], cen[3 * p + a]);
+                chi[a] = std::max(chi[a], cen[3 * p + a]);
+            }
+        }
+    }
+
+    void build(uint32_t node, uint32_t b, uint32_t e, int depth) {
+        B2 &n = nodes[node];
+        float clo[3], chi[3];
+        bounds_of(b, e, n.lo, n.hi, clo, chi);
+        const uint32_t cnt = e - b;
+        n.left = n.right = 0; n.first = b; n.count = 0;
+        if (cnt == 1) { n.count = 1; return; }
+
+        constexpr int NB = 16;
+        float best_cost = std::numeric_limits<float>::infinity();
+        int best_axis = -1, best_bin = -1;
+        for (int a = 0; a < 3; ++a) {
+            const float ext = chi[a] - clo[a];
+            if (!(ext > 0.0f)) continue;
+            const float scale = (float)NB / ext;
+            uint32_t bc[NB] = {0};
+            float blo[NB][3], bhi[NB][3];
+            for (int k = 0; k < NB; ++k)
+                for (int c = 0; c < 3; ++c) { blo[k][c] = std::numeric_limits<float>::infinity(); bhi[k][c] = -blo[k][c]; }
+            for (uint32_t i = b; i < e; ++i) {
+                const uint32_t p = idx[i];
+                int k = (int)((cen[3 * p + a] - clo[a]) * scale);
+                k = std::min(std::max(k, 0), NB - 1);
+                bc[k]++;
+                for (int c = 0; c < 3; ++c) { blo[k][c] = std::min(blo[k][c], plo[3 * p + c]); bhi[k][c] = std::max(bhi[k][c], phi[3 * p + c]); }
+            }
+            float racc_lo[3], racc_hi[3], rarea[NB]; uint32_t rcnt[NB];
+            for (int c = 0; c < 3; ++c) { racc_lo[c] = std::numeric_limits<float>::infinity(); racc_hi[c] = -racc_lo[c]; }
+            uint32_t rc = 0;
+            for (int k = NB - 1; k > 0; --k) {
+                rc += bc[k];
+                for (int c = 0; c < 3; ++c) { racc_lo[c] = std::min(racc_lo[c], blo[k][c]); racc_hi[c] = std::max(racc_hi[c], bhi[k][c]); }
+                rcnt[k] = rc; rarea[k] = rc ? half_area(racc_lo, racc_hi) : 0.0f;
+            }
+            float lacc_lo[3], lacc_hi[3];
+            for (int c = 0; c < 3; ++c) { lacc_lo[c] = std::numeric_limits<float>::infinity(); lacc_hi[c] = -lacc_lo[c]; }
+            uint32_t lc = 0;
+            for (int k = 0; k < NB - 1; ++k) {
+                lc += bc[k];
+                for (int c = 0; c < 3; ++c) { lacc_lo[c] = std::min(lacc_lo[c], blo[k][c]); lacc_hi[c] = std::max(lacc_hi[c], bhi[k][c]); }
+                if (lc == 0 || rcnt[k + 1] == 0) continue;
+                const float cost = half_area(lacc_lo, lacc_hi) * (float)lc + rarea[k + 1] * (float)rcnt[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
+            }
+        }
+
+        if (cnt <= kMaxLeafPrims) {
+            // leaf unless splitting is clearly cheaper (c_prim = 0.3, c_inner = 0.5)
+            const float area = half_area(n.lo, n.hi);
+            const float split_cost = best_axis >= 0 && area > 0.0f ? 0.3f * best_cost / area + 0.5f
+                                                                    : std::numeric_limits<float>::infinity();
+            if (!(split_cost < 0.3f * (float)cnt)) { n.count = cnt; return; }
+        }
+
+        uint32_t mid;
+        if (best_axis >= 0) {
+            const float ext = chi[best_axis] - clo[best_axis];
+            const float scale = (float)NB / ext;
+            const float c0 = clo[best_axis];
+            const int a = best_axis, bb = best_bin;
+            auto it = std::partition(idx.begin() + b, idx.begin() + e, [&](uint32_t p) {
+                int k = (int)((cen[3 * p + a] - c0) * scale);
+                k = std::min(std::max(k, 0), NB - 1);
+                return k <= bb;
+            });
+            mid = (uint32_t)(it - idx.begin());
+        } else {
+            mid = b + cnt / 2;      // all centroids coincide: split by index
+        }
+        if (mid == b || mid == e) mid = b + cnt / 2;
+
+        const uint32_t l = alloc2();
+        nodes[node].left = l; nodes[node].right = l + 1;
+        if (depth < max_par_depth && cnt > 65536) {
+            std::thread t([&, l, b, mid, depth] { build(l, b, mid, depth + 1); });
+            build(l + 1, mid, e, depth + 1);
+            t.join();
+        } else {
+            build(l, b, mid, depth + 1);
+            build(l + 1, mid, e, depth + 1);
+        }
+    }
+};
+
+inline uint8_t unary_count(uint32_t n) { return (uint8_t)((1u << n) - 1u); }
+
+}  // namespace
+
+void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads) {
+    out = Bvh8();
+    const uint32_t n = (uint32_t)prims.size();
+    for (const auto &p : prims) { if (p.rec.kind == kPrimKindSphere) out.n_spheres++; else out.n_triangles++; }
+    if (n == 0) {
+        // a single empty node: every ray misses
+        Bvh8Node root; std::memset(&root, 0, sizeof root);
+        root.e[0] = root.e[1] = root.e[2] = 127;
+        for (int a = 0; a < 3; ++a) for (int s = 0; s < 8; ++s) { root.qlo[a][s] = 255; root.qhi[a][s] = 0; }
+        out.nodes.push_back(root);
+        return;
+    }
+
+    Builder B(prims);
+    B.plo.resize(3 * (size_t)n); B.phi.resize(3 * (size_t)n); B.cen.resize(3 * (size_t)n); B.idx.resize(n);
+    float smax = 1.0f;
+    for (uint32_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) smax = std::max(smax, std::max(std::fabs(prims[i].lo[a]), std::fabs(prims[i].hi[a])));
+    // Padding keeps the quantised slab test conservative w.r.t. the canonical intersector's
+    // own rounding (DESIGN.md "conservative boxes"): ~2e-6 of the scene scale.
+    const float pad = 2e-6f * smax;
+    for (uint32_t i = 0; i < n; ++i) {
+        B.idx[i] = i;
+        for (int a = 0; a < 3; ++a) {
+            B.plo[3 * i + a] = prims[i].lo[a] - pad;
+            B.phi[3 * i + a] = prims[i].hi[a] + pad;
+            B.cen[3 * i + a] = 0.5f * (prims[i].lo[a] + prims[i].hi[a]);
+        }
+    }
+    B.nodes.resize(2 * (size_t)n + 2);
+    B.n_nodes = 1;
+    int hw = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    if (hw < 1) hw = 1;
+    B.max_par_depth = 0;
+    while ((1 << B.max_par_depth) < hw && B.max_par_depth < 6) B.max_par_depth++;
+    B.build(0, 0, n, 0);
+
+    for (int a = 0; a < 3; ++a) { out.lo[a] = B.nodes[0].lo[a]; out.hi[a] = B.nodes[0].hi[a]; }
+
+    // ---- collapse to 8-wide, breadth first so that inner children are contiguous ----
+    struct Item { uint32_t b2; uint32_t depth; };
+    std::vector<Item> queue;
+    queue.reserve(n);
+    out.nodes.reserve(n / 2 + 8);
+    out.prims.reserve(n);
+    out.prim_bounds.reserve(6 * (size_t)n);
+
+    // root: if the BVH2 root is itself a leaf, wrap it into a node with one leaf child
+    queue.push_back({0u, 0u});
+    out.nodes.emplace_back();
+    size_t head = 0;
+    while (head < queue.size()) {
+        const Item it = queue[head];
+        const uint32_t self = (uint32_t)head;
+        ++head;
+        const B2 &bn = B.nodes[it.b2];
+        out.max_depth = std::max(out.max_depth, it.depth);
+
+        uint32_t ch[8]; int nch = 0;
+        if (bn.count > 0) { ch[nch++] = it.b2; }
+        else {
+            ch[nch++] = bn.left; ch[nch++] = bn.right;
+            while (nch < 8) {
+                int pick = -1; float pa = -1.0f;
+                for (int k = 0; k < nch; ++k) {
+                    const B2 &c = B.nodes[ch[k]];
+                    if (c.count > 0) continue;
+                    const float ar = half_area(c.lo, c.hi);
+                    if (ar > pa) { pa = ar; pick = k; }
+                }
+                if (pick < 0) break;
+                const B2 &c = B.nodes[ch[pick]];
+                ch[pick] = c.left; ch[nch++] = c.right;
+            }
+        }
+
+        // slot assignment: slot s is visited first by rays of octant s (bit2 = -x, bit1 = -y, bit0 = -z)
+        float ncx[3];
+        for (int a = 0; a < 3; ++a) ncx[a] = 0.5f * (bn.lo[a] + bn.hi[a]);
+        float cost[8][8];
+        for (int k = 0; k < nch; ++k) {
+            const B2 &c = B.nodes[ch[k]];
+            const float d[3] = {0.5f * (c.lo[0] + c.hi[0]) - ncx[0], 0.5f * (c.lo[1] + c.hi[1]) - ncx[1], 0.5f * (c.lo[2] + c.hi[2]) - ncx[2]};
+            for (int s = 0; s < 8; ++s) {
+                const float sx = (s & 4) ? -1.0f : 1.0f, sy = (s & 2) ? -1.0f : 1.0f, sz = (s & 1) ? -1.0f : 1.0f;
+                cost[k][s] = d[0] * sx + d[1] * sy + d[2] * sz;
+            }
+        }
+        int slot_child[8]; for (int s = 0; s < 8; ++s) slot_child[s] = -1;
+        bool child_done[8] = {false, false, false, false, false, false, false, false};
+        for (int round = 0; round < nch; ++round) {
+            int bk = -1, bs = -1; float bc = std::numeric_limits<float>::infinity();
+            for (int k = 0; k < nch; ++k) {
+                if (child_done[k]) continue;
+                for (int s = 0; s < 8; ++s) {
+                    if (slot_child[s] >= 0) continue;
+                    if (cost[k][s] < bc) { bc = cost[k][s]; bk = k; bs = s; }
+                }
+            }
+            if (bk < 0) {   // NaN costs (degenerate boxes): first free pair
+                for (int k = 0; k < nch && bk < 0; ++k) if (!child_done[k]) bk = k;
+                for (int s = 0; s < 8 && bs < 0; ++s) if (slot_child[s] < 0) bs = s;
+            }
+            slot_child[bs] = bk; child_done[bk] = true;
+        }
+
+        Bvh8Node nd; std::memset(&nd, 0, sizeof nd);
+        for (int a = 0; a < 3; ++a) {
+            nd.p[a] = bn.lo[a];
+            const float ext = bn.hi[a] - bn.lo[a];
+            int e = ext > 0.0f ? (int)std::ceil(std::log2((double)ext / 255.0)) : -126;
+            e = std::min(std::max(e, -126), 127);
+            while (e < 127 && std::ldexp(255.0, e) < (double)ext) ++e;
+            nd.e[a] = (uint8_t)(e + 127);
+        }
+        nd.child_base = (uint32_t)queue.size();
+        nd.prim_base = (uint32_t)out.prims.size();
+        uint32_t prim_off = 0;
+        for (int s = 0; s < 8; ++s) {
+            const int k = slot_child[s];
+            if (k < 0) {
+                nd.meta[s] = 0;
+                for (int a = 0; a < 3; ++a) { nd.qlo[a][s] = 255; nd.qhi[a][s] = 0; }
+                continue;
+            }
+            const B2 &c = B.nodes[ch[k]];
+            for (int a = 0; a < 3; ++a) {
+                const double sc = std::ldexp(1.0, (int)nd.e[a] - 127);
+                int ql = (int)std::floor(((double)c.lo[a] - (double)nd.p[a]) / sc);
+                int qh = (int)std::ceil(((double)c.hi[a] - (double)nd.p[a]) / sc);
+                ql = std::min(std::max(ql, 0), 255); qh = std::min(std::max(qh, 0), 255);
+                const float fs = (float)sc;
+                while (ql > 0 && nd.p[a] + (float)ql * fs > c.lo[a]) --ql;       // float decode must stay outside
+                while (qh < 255 && nd.p[a] + (float)qh * fs < c.hi[a]) ++qh;
+                nd.qlo[a][s] = (uint8_t)ql; nd.qhi[a][s] = (uint8_t)qh;
+            }
+            if (c.count > 0) {
+                nd.meta[s] = (uint8_t)((unary_count(c.count) << 5) | prim_off);
+                for (uint32_t i = 0; i < c.count; ++i) {
+                    const uint32_t p = B.idx[c.first + i];
+                    out.prims.push_back(prims[p].rec);
+                    for (int a = 0; a < 3; ++a) out.prim_bounds.push_back(prims[p].lo[a]);
+                    for (int a = 0; a < 3; ++a) out.prim_bounds.push_back(prims[p].hi[a]);
+                }
+                prim_off += c.count;
+            } else {
+                nd.meta[s] = (uint8_t)(0x20u | (24u + (uint32_t)s));
+                nd.imask |= (uint8_t)(1u << s);
+                queue.push_back({ch[k], it.depth + 1});
+                out.nodes.emplace_back();
+            }
+        }
+        out.nodes[self] = nd;
+    }
+}
+
+// Walk the packed tree and check containment of every primitive in every ancestor slot box.
+const char *validate_bvh8(const Bvh8 &bvh) {
+    if (bvh.nodes.empty()) return "no nodes";
+    struct E { uint32_t node; };
+    std::vector<uint32_t> stack{0u};
+    std::vector<uint8_t> seen(bvh.prims.size(), 0);
+    // per node: each leaf slot's prims must be inside the slot box; the true bounds of all
+    // primitives below an inner slot must be inside that slot's box (nlo/nhi = true bounds).
+    std::vector<float> nlo(3 * bvh.nodes.size()), nhi(3 * bvh.nodes.size());
+    // bottom-up boxes: nodes are in BFS order, so children have larger indices
+    for (size_t i = bvh.nodes.size(); i-- > 0;) {
+        const Bvh8Node &nd = bvh.nodes[i];
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t inner_rank = 0;
+        for (int s = 0; s < 8; ++s) {
+            const uint8_t m = nd.meta[s];
+            if (m == 0) continue;
+            float blo[3], bhi[3];
+            for (int a = 0; a < 3; ++a) {
+                const float sc = std::ldexp(1.0f, (int)nd.e[a] - 127);
+                blo[a] = nd.p[a] + (float)nd.qlo[a][s] * sc;
+                bhi[a] = nd.p[a] + (float)nd.qhi[a][s] * sc;
+            }
+            const bool inner = (nd.imask >> s) & 1u;
+            if (inner) {
+                if ((m & 0xe0u) != 0x20u || (m & 0x1fu) != 24u + (uint32_t)s) return "inner meta mismatch";
+                const uint32_t c = nd.child_base + inner_rank++;
+                if (c >= bvh.nodes.size() || c <= i) return "child index out of order";
+                for (int a = 0; a < 3; ++a) {
+                    if (nlo[3 * c + a] < blo[a] || nhi[3 * c + a] > bhi[a]) return "subtree primitives escape slot box";
+                    lo[a] = std::min(lo[a], nlo[3 * c + a]); hi[a] = std::max(hi[a], nhi[3 * c + a]);
+                }
+            } else {
+                const uint32_t cntbits = m >> 5, off = m & 0x1fu;
+                const uint32_t cnt = cntbits == 1 ? 1 : cntbits == 3 ? 2 : cntbits == 7 ? 3 : 0;
+                if (cnt == 0 || off + cnt > 24) return "leaf meta malformed";
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const uint32_t p = nd.prim_base + off + k;
+                    if (p >= bvh.prims.size()) return "prim index out of range";
+                    if (seen[p]) return "primitive referenced twice";
+                    seen[p] = 1;
+                    for (int a = 0; a < 3; ++a) {
+                        if (bvh.prim_bounds[6 * p + a] < blo[a] || bvh.prim_bounds[6 * p + 3 + a] > bhi[a]) return "primitive escapes leaf box";
+                        lo[a] = std::min(lo[a], bvh.prim_bounds[6 * p + a]); hi[a] = std::max(hi[a], bvh.prim_bounds[6 * p + 3 + a]);
+                    }
+                }
+            }
+        }
+        for (int a = 0; a < 3; ++a) { nlo[3 * i + a] = lo[a]; nhi[3 * i + a] = hi[a]; }
+    }
+    for (size_t p = 0; p < seen.size(); ++p) if (!seen[p]) return "primitive not referenced";
+    return "";
+}
+
+}  // namespace hrt

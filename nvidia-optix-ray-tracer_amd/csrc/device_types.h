@@ -1,0 +1,113 @@
+// device_types.h -- records and kernel argument blocks shared by kernels.hip and the host API.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hrt {
+
+constexpr float    kFloatZero     = 1e-6f;    // FLOAT_ZERO_VALUE, include/Global/DeviceFunctions.cuh:18
+constexpr float    kFloatInfinity = 1e16f;    // FLOAT_INFINITY_VALUE, :19
+constexpr uint32_t kRayTraceDepth = 5u;       // rayTraceDepth, include/Global/Shader.cuh:8
+constexpr uint32_t kMissPrim      = 0xffffffffu;
+
+constexpr int kProgramSphereRough = 0, kProgramSphereMetal = 1, kProgramTriangleRough = 2, kProgramTriangleMetal = 3;
+constexpr uint32_t kNumPrograms = 4;
+constexpr uint32_t kNumBins = 1 + kNumPrograms;      // bin 0: path ends; bin 1+P: closest-hit program P
+
+// curandStateXORWOW_t layout (48 B); only d and v[] are live for curand_uniform.
+struct RngState {
+    uint32_t d, v[5];
+    int32_t  boxmuller_flag, boxmuller_flag_double;
+    float    boxmuller_extra, _pad;
+    double   boxmuller_extra_double;
+};
+static_assert(sizeof(RngState) == 48, "curandState is 48 bytes");
+
+// One queued ray (32 B, two 16-byte accesses).  o.w = tile-local pixel index (bits),
+// d.w = global pixel index y*W+x (bits) = RNG stream index (shader/Shader.cu:97).
+struct alignas(16) RayRec { float4 o, d; };
+
+// HitGroupParams as the shader reads it (include/Global/Shader.cuh:43-70), 32 B.
+struct alignas(8) HitGroup {
+    const void *ptr0;      // sphere.centers | triangles.vertexNormals
+    const void *ptr1;      // sphere.radii
+    float albedo[3];
+    float fuzz;
+};
+static_assert(sizeof(HitGroup) == 32, "HitGroupParams is 32 bytes");
+
+struct GenerateArgs {
+    RayRec *rays;
+    const uint32_t *rows;          // tile rows -> frame rows
+    uint32_t n_tile_pixels, width, height;
+    float center[3], U[3], V[3], W[3];
+};
+
+struct TraverseArgs {
+    const void *nodes;             // Bvh8Node[]
+    const void *prims;             // PrimRecord[]
+    const RayRec *rays;
+    const uint32_t *n_rays_ptr;    // 4 device counters whose sum is the queue length, or NULL
+    uint32_t n_rays;               // used when n_rays_ptr == NULL
+    uint32_t *fetch_counter;       // zeroed before the launch
+    float4 *hit_tuvp;              // t, u, v, primitive index (bits); t = tmax on miss
+    uint32_t *hit_inst;            // instance index, kMissPrim on miss
+    const float *inst_inv;         // 12 floats per instance: world->object (spheres)
+    const uint32_t *inst_identity;
+    float tmin, tmax;
+    int refill_threshold;          // refill when at least this many lanes are idle
+    uint64_t *count_nodes, *count_prims;
+};
+
+struct BinArgs {
+    const uint32_t *n_rays_ptr; uint32_t n_rays;
+    const uint32_t *hit_inst;
+    const uint32_t *inst_program;
+    uint32_t depth;
+    uint32_t *bin_count;           // kNumBins counters of this stage (zeroed)
+    uint32_t *bin_items;           // kNumBins arrays of bin_stride ray indices
+    uint32_t bin_stride;
+    uint64_t *total_rays;
+};
+
+struct ShadeArgs {
+    const uint32_t *bin_count; const uint32_t *bin_items; uint32_t bin_stride;
+    const RayRec *rays_in; RayRec *rays_out;
+    const float4 *hit_tuvp; const uint32_t *hit_inst;
+    const HitGroup *hitgroups;
+    RngState *states;
+    uint32_t *chain;               // 4 instance indices per tile pixel
+    uint32_t depth;
+};
+
+struct AccumArgs {
+    const uint32_t *bin_count; const uint32_t *bin_items;
+    const RayRec *rays_in; const uint32_t *hit_inst;
+    const HitGroup *hitgroups;
+    const uint32_t *chain;
+    float4 *accum;
+    float bg[3];
+    uint32_t depth;
+    uint32_t first_sample;
+};
+
+struct FinalizeArgs {
+    const float4 *accum; const uint32_t *rows;
+    uint32_t n_tile_pixels, width, spp;
+    float4 *color, *albedo, *normal, *linear;
+};
+
+// host-callable launchers (defined in kernels.hip)
+void launch_rng_init(RngState *states, uint32_t n, uint64_t salt, const uint32_t *d_jump, hipStream_t s);
+void launch_generate(const GenerateArgs &a, hipStream_t s);
+void launch_traverse(const TraverseArgs &a, bool any_hit, bool count, bool has_spheres, uint32_t grid_blocks, hipStream_t s);
+void launch_bin(const BinArgs &a, uint32_t grid_blocks, hipStream_t s);
+void launch_shade(const ShadeArgs &a, int program, uint32_t grid_blocks, hipStream_t s);
+void launch_accumulate(const AccumArgs &a, uint32_t grid_blocks, hipStream_t s);
+void launch_finalize(const FinalizeArgs &a, hipStream_t s);
+void launch_to_rgba8(const float4 *src, uchar4 *dst, uint32_t n, hipStream_t s);
+void launch_pack_rays(const float *o, const float *d, uint32_t n, RayRec *rays, hipStream_t s);
+void launch_unpack_hits(const float4 *tuvp, const uint32_t *inst, uint32_t n, float *t, float *u, float *v,
+                        uint32_t *prim, uint32_t *oinst, hipStream_t s);
+
+}  // namespace hrt

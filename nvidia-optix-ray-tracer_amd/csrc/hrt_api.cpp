@@ -1,0 +1,785 @@
+// hrt_api.cpp -- C ABI of libhrt.so: context, acceleration structures, materials, RNG, launch.
+// Entry points and the reference call sites they replace are documented in include/hrt.h.
+// There is deliberately no CPU fallback anywhere in this file: every compute path ends in a
+// HIP kernel launch, and context creation fails when no gfx950 device is present.
+#include "../../include/hrt.h"
+#include "bvh8.h"
+#include "device_types.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace hrt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Blas {
+    uint32_t kind = kPrimKindTriangle;
+    uint32_t n_prims = 0;
+    std::vector<float> verts;        // triangles: 9 floats each (object space)
+    std::vector<float> centers;      // spheres: 3 floats each
+    std::vector<float> radii;
+};
+
+struct Tlas {
+    uint32_t n_instances = 0;
+    std::vector<uint32_t> sbt_offset;      // per instance
+    std::vector<uint32_t> kind;            // per instance: triangle / sphere BLAS
+    Bvh8 bvh;                               // host copy (download / stats)
+    void *d_nodes = nullptr, *d_prims = nullptr;
+    float *d_inst_inv = nullptr;
+    uint32_t *d_inst_identity = nullptr;
+    bool has_spheres = false;
+    uint64_t generation = 0;
+};
+
+struct StageCounters { uint32_t bin_count[8]; uint32_t fetch; uint32_t pad[7]; };   // 64 B
+static_assert(sizeof(StageCounters) == 64, "stage counters are one 64-byte line");
+
+struct DeviceStats { uint64_t rays_closest, rays_any, nodes_closest, prims_closest, nodes_any, prims_any; };
+
+struct Workspace {
+    uint32_t capacity = 0, rows_capacity = 0;
+    RayRec *rays[2] = {nullptr, nullptr};
+    float4 *hit_tuvp = nullptr; uint32_t *hit_inst = nullptr;
+    uint32_t *bin_items = nullptr;
+    uint32_t *chain = nullptr;
+    float4 *accum = nullptr;
+    uint32_t *rows = nullptr;
+    StageCounters *stages = nullptr;       // [kRayTraceDepth + 1]
+};
+
+struct TimedSpan { int kind; hipEvent_t a, b; };
+
+}  // namespace
+
+struct HrtContext {
+    int device = 0;
+    uint32_t flags = 0;
+    int n_cu = 256;
+    std::string error;
+    std::mutex mu;
+    std::unordered_map<uint64_t, std::unique_ptr<Blas>> blas;
+    std::unordered_map<uint64_t, std::unique_ptr<Tlas>> tlas;
+    uint64_t next_handle = 0x1000;
+    // materials
+    std::vector<HrtSbtRecord> records;
+    HrtMissParams miss{{0.7f, 0.8f, 0.9f}};      // reference default, src/Global/RendererMesh.cu:262
+    bool have_records = false;
+    uint64_t materials_generation = 0;
+    // per-launch device tables derived from (tlas, records)
+    HitGroup *d_hitgroups = nullptr; uint32_t *d_inst_program = nullptr; uint32_t table_capacity = 0;
+    uint64_t table_tlas = 0, table_tlas_gen = 0, table_mat_gen = ~0ull;
+    bool program_present[kNumPrograms] = {false, false, false, false};
+    // rng
+    uint32_t *d_jump = nullptr;
+    // workspace + stats
+    Workspace ws;
+    std::vector<uint32_t> h_rows; HrtTile rows_tile{0, 0, 0, 0, 0}; uint32_t rows_w = 0, rows_h = 0;
+    DeviceStats *d_stats = nullptr;
+    uint64_t paths = 0;
+    uint64_t last_tlas = 0;
+    std::vector<TimedSpan> spans; std::vector<hipEvent_t> event_pool; size_t events_used = 0;
+    double kernel_ms[HRT_K_COUNT] = {0}; uint64_t kernel_launches[HRT_K_COUNT] = {0};
+    float4 *d_linear = nullptr;
+    int refill_threshold = 24;
+    int traverse_blocks_per_cu = 6;
+};
+
+namespace {
+
+int fail(HrtContext *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (ctx) ctx->error = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return fail(ctx, _e == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP,          \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// ---- XORWOW sub-sequence jump matrices: T^(2^(67+k)), k = 0..31, 160 columns x 5 words ----
+struct Gf2m { uint32_t col[160][5]; };
+void gf2_apply(const Gf2m &m, const uint32_t in[5], uint32_t out[5]) {
+    uint32_t r[5] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < 5; ++w)
+        for (int b = 0; b < 32; ++b)
+            if ((in[w] >> b) & 1u)
+                for (int k = 0; k < 5; ++k) r[k] ^= m.col[w * 32 + b][k];
+    std::memcpy(out, r, sizeof r);
+}
+void gf2_square(Gf2m &m) {
+    Gf2m t;
+    for (int i = 0; i < 160; ++i) gf2_apply(m, m.col[i], t.col[i]);
+    m = t;
+}
+std::vector<uint32_t> make_jump_tables() {
+    Gf2m t;
+    for (int i = 0; i < 160; ++i) {
+        uint32_t v[5] = {0, 0, 0, 0, 0};
+        v[i / 32] = 1u << (i % 32);
+        const uint32_t x = v[0] ^ (v[0] >> 2);           // one xorshift step of XORWOW
+        const uint32_t n4 = (v[4] ^ (v[4] << 4)) ^ (x ^ (x << 1));
+        t.col[i][0] = v[1]; t.col[i][1] = v[2]; t.col[i][2] = v[3]; t.col[i][3] = v[4]; t.col[i][4] = n4;
+    }
+    for (int k = 0; k < 67; ++k) gf2_square(t);
+    std::vector<uint32_t> out(32 * 800);
+    for (int k = 0; k < 32; ++k) {
+        std::memcpy(&out[(size_t)k * 800], t.col, sizeof t.col);
+        gf2_square(t);
+    }
+    return out;
+}
+
+// ---- transforms (fixed operation order; DESIGN.md "instances") ----
+bool is_identity(const float *m) {
+    static const float id[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    return std::memcmp(m, id, sizeof id) == 0;
+}
+inline void xf_point(const float *m, const float *p, float *o) {
+    o[0] = ((m[0] * p[0] + m[1] * p[1]) + m[2] * p[2]) + m[3];
+    o[1] = ((m[4] * p[0] + m[5] * p[1]) + m[6] * p[2]) + m[7];
+    o[2] = ((m[8] * p[0] + m[9] * p[1]) + m[10] * p[2]) + m[11];
+}
+void invert_affine(const float *m, float *o) {
+    const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+    const double det = a * A + b * B + c * C;
+    const double r = 1.0 / det;
+    const double n00 = A * r, n01 = -(b * i - c * h) * r, n02 = (b * f - c * e) * r;
+    const double n10 = B * r, n11 = (a * i - c * g) * r, n12 = -(a * f - c * d) * r;
+    const double n20 = C * r, n21 = -(a * h - b * g) * r, n22 = (a * e - b * d) * r;
+    const double tx = m[3], ty = m[7], tz = m[11];
+    o[0] = (float)n00; o[1] = (float)n01; o[2] = (float)n02; o[3] = (float)(-(n00 * tx + n01 * ty + n02 * tz));
+    o[4] = (float)n10; o[5] = (float)n11; o[6] = (float)n12; o[7] = (float)(-(n10 * tx + n11 * ty + n12 * tz));
+    o[8] = (float)n20; o[9] = (float)n21; o[10] = (float)n22; o[11] = (float)(-(n20 * tx + n21 * ty + n22 * tz));
+}
+
+void free_tlas_device(Tlas &t) {
+    if (t.d_nodes) (void)hipFree(t.d_nodes);
+    if (t.d_prims) (void)hipFree(t.d_prims);
+    if (t.d_inst_inv) (void)hipFree(t.d_inst_inv);
+    if (t.d_inst_identity) (void)hipFree(t.d_inst_identity);
+    t.d_nodes = t.d_prims = nullptr; t.d_inst_inv = nullptr; t.d_inst_identity = nullptr;
+}
+
+// Flatten the instances into world space, build the BVH8 on the host, upload it.
+int build_tlas_into(HrtContext *ctx, Tlas &t, const HrtInstance *d_instances, uint32_t n, hipStream_t s) {
+    std::vector<HrtInstance> inst(n);
+    if (n) {
+        HIP_TRY(ctx, hipMemcpyAsync(inst.data(), d_instances, sizeof(HrtInstance) * (size_t)n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+    }
+    std::vector<BuildPrim> prims;
+    std::vector<float> inv(12 * (size_t)std::max(n, 1u));
+    std::vector<uint32_t> ident(std::max(n, 1u), 1u);
+    t.sbt_offset.assign(n, 0); t.kind.assign(n, 0); t.has_spheres = false;
+    size_t total = 0;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        for (uint32_t i = 0; i < n; ++i) {
+            auto it = ctx->blas.find(inst[i].traversableHandle);
+            if (it == ctx->blas.end()) return fail(ctx, HRT_ERR_INVALID, "instance %u: unknown BLAS handle 0x%llx", i, (unsigned long long)inst[i].traversableHandle);
+            total += it->second->n_prims;
+        }
+    }
+    prims.reserve(total);
+    for (uint32_t i = 0; i < n; ++i) {
+        const Blas *b;
+        { std::lock_guard<std::mutex> lk(ctx->mu); b = ctx->blas.find(inst[i].traversableHandle)->second.get(); }
+        const float *m = inst[i].transform;
+        const bool id = is_identity(m);
+        ident[i] = id ? 1u : 0u;
+        invert_affine(m, &inv[12 * (size_t)i]);
+        t.sbt_offset[i] = inst[i].sbtOffset;
+        t.kind[i] = b->kind;
+        if ((inst[i].visibilityMask & 1u) == 0) continue;       // the reference traces with mask 1 (Shader.cu:71)
+        for (uint32_t p = 0; p < b->n_prims; ++p) {
+            BuildPrim bp; std::memset(&bp, 0, sizeof bp);
+            if (b->kind == kPrimKindTriangle) {
+                float v[3][3];
+                for (int k = 0; k < 3; ++k) {
+                    const float *src = &b->verts[9 * (size_t)p + 3 * k];
+                    if (id) { v[k][0] = src[0]; v[k][1] = src[1]; v[k][2] = src[2]; } else xf_point(m, src, v[k]);
+                }
+                for (int a = 0; a < 3; ++a) {
+                    bp.rec.a[a] = v[0][a]; bp.rec.b[a] = v[1][a] - v[0][a]; bp.rec.c[a] = v[2][a] - v[0][a];
+                    bp.lo[a] = std::fmin(v[0][a], std::fmin(v[1][a], v[2][a]));
+                    bp.hi[a] = std::fmax(v[0][a], std::fmax(v[1][a], v[2][a]));
+                }
+                bp.rec.prim = p; bp.rec.inst = i; bp.rec.kind = kPrimKindTriangle;
+                // NaN / Inf geometry never hits anything; keep it out of the tree
+                bool ok = true;
+                for (int a = 0; a < 3; ++a) ok = ok && std::isfinite(bp.lo[a]) && std::isfinite(bp.hi[a]);
+                if (!ok) continue;
+            } else {
+                t.has_spheres = true;
+                const float *c = &b->centers[3 * (size_t)p];
+                const float r = b->radii[p], rr = std::fabs(r);
+                bp.rec.a[0] = c[0]; bp.rec.a[1] = c[1]; bp.rec.a[2] = c[2]; bp.rec.prim = p;
+                bp.rec.b[0] = r; bp.rec.inst = i; bp.rec.kind = kPrimKindSphere;
+                for (int a = 0; a < 3; ++a) { bp.lo[a] = INFINITY; bp.hi[a] = -INFINITY; }
+                for (int cidx = 0; cidx < 8; ++cidx) {
+                    float q[3] = {c[0] + ((cidx & 1) ? rr : -rr), c[1] + ((cidx & 2) ? rr : -rr), c[2] + ((cidx & 4) ? rr : -rr)}, w[3];
+                    if (id) { w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; } else xf_point(m, q, w);
+                    for (int a = 0; a < 3; ++a) { bp.lo[a] = std::fmin(bp.lo[a], w[a]); bp.hi[a] = std::fmax(bp.hi[a], w[a]); }
+                }
+                bool ok = true;
+                for (int a = 0; a < 3; ++a) ok = ok && std::isfinite(bp.lo[a]) && std::isfinite(bp.hi[a]);
+                if (!ok) continue;
+            }
+            prims.push_back(bp);
+        }
+    }
+    build_bvh8(prims, t.bvh, 0);
+    if (t.bvh.max_depth + 2 > (uint32_t)(8 + 40))
+        return fail(ctx, HRT_ERR_INVALID, "BVH depth %u exceeds the traversal stack", t.bvh.max_depth);
+
+    free_tlas_device(t);
+    t.n_instances = n;
+    const size_t nb = sizeof(Bvh8Node) * t.bvh.nodes.size();
+    const size_t pb = sizeof(PrimRecord) * std::max<size_t>(t.bvh.prims.size(), 1);
+    HIP_TRY(ctx, hipMalloc(&t.d_nodes, nb));
+    HIP_TRY(ctx, hipMalloc(&t.d_prims, pb));
+    HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_inv, sizeof(float) * inv.size()));
+    HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_identity, sizeof(uint32_t) * ident.size()));
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, t.bvh.nodes.data(), nb, hipMemcpyHostToDevice, s));
+    if (!t.bvh.prims.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_prims, t.bvh.prims.data(), sizeof(PrimRecord) * t.bvh.prims.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_inv, inv.data(), sizeof(float) * inv.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_identity, ident.data(), sizeof(uint32_t) * ident.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    t.generation++;
+    return HRT_OK;
+}
+
+int ensure_workspace(HrtContext *ctx, uint32_t n, uint32_t height) {
+    Workspace &w = ctx->ws;
+    if (n > w.capacity) {
+        if (w.rays[0]) { (void)hipFree(w.rays[0]); (void)hipFree(w.rays[1]); (void)hipFree(w.hit_tuvp); (void)hipFree(w.hit_inst);
+                         (void)hipFree(w.bin_items); (void)hipFree(w.chain); (void)hipFree(w.accum); }
+        w.capacity = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&w.rays[0], sizeof(RayRec) * (size_t)n));
+        HIP_TRY(ctx, hipMalloc((void **)&w.rays[1], sizeof(RayRec) * (size_t)n));
+        HIP_TRY(ctx, hipMalloc((void **)&w.hit_tuvp, sizeof(float4) * (size_t)n));
+        HIP_TRY(ctx, hipMalloc((void **)&w.hit_inst, sizeof(uint32_t) * (size_t)n));
+        HIP_TRY(ctx, hipMalloc((void **)&w.bin_items, sizeof(uint32_t) * (size_t)n * kNumBins));
+        HIP_TRY(ctx, hipMalloc((void **)&w.chain, sizeof(uint32_t) * 4 * (size_t)n));
+        HIP_TRY(ctx, hipMalloc((void **)&w.accum, sizeof(float4) * (size_t)n));
+        w.capacity = n;
+    }
+    if (height > w.rows_capacity) {
+        if (w.rows) (void)hipFree(w.rows);
+        w.rows_capacity = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&w.rows, sizeof(uint32_t) * (size_t)height));
+        w.rows_capacity = height;
+    }
+    if (!w.stages) HIP_TRY(ctx, hipMalloc((void **)&w.stages, sizeof(StageCounters) * (kRayTraceDepth + 1)));
+    return HRT_OK;
+}
+
+struct Timer {
+    HrtContext *ctx; hipStream_t s; bool on; TimedSpan span{};
+    Timer(HrtContext *c, hipStream_t st, int kind) : ctx(c), s(st), on((c->flags & HRT_CTX_TIMING) != 0) {
+        if (!on) { ctx->kernel_launches[kind]++; return; }
+        span.kind = kind; span.a = next(); span.b = next();
+        (void)hipEventRecord(span.a, s);
+    }
+    ~Timer() { if (on) { (void)hipEventRecord(span.b, s); ctx->spans.push_back(span); } }
+    hipEvent_t next() {
+        if (ctx->events_used == ctx->event_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ctx->event_pool.push_back(e); }
+        return ctx->event_pool[ctx->events_used++];
+    }
+};
+
+void drain_spans(HrtContext *ctx) {
+    for (const TimedSpan &sp : ctx->spans) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { ctx->kernel_ms[sp.kind] += ms; ctx->kernel_launches[sp.kind]++; }
+    }
+    ctx->spans.clear();
+    ctx->events_used = 0;
+}
+
+}  // namespace
+
+// ======================================================================================
+extern "C" {
+
+const char *hrt_version(void) { return "hrt 0.1 (gfx950 wavefront path tracer)"; }
+
+const char *hrt_last_error(const HrtContext *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
+    if (!out_ctx) return fail(nullptr, HRT_ERR_INVALID, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(nullptr, HRT_ERR_NO_DEVICE, "no HIP device visible: libhrt has no CPU path");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, HRT_ERR_INVALID, "device %d out of range (%d devices)", device_id, n);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return fail(nullptr, HRT_ERR_HIP, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, HRT_ERR_NO_DEVICE, "device %d is %s; libhrt carries gfx950 code only", device_id, prop.gcnArchName);
+    if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, HRT_ERR_HIP, "hipSetDevice(%d) failed", device_id);
+    std::unique_ptr<HrtContext> ctx(new HrtContext());
+    ctx->device = device_id; ctx->flags = flags; ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const std::vector<uint32_t> jump = make_jump_tables();
+    if (hipMalloc((void **)&ctx->d_jump, jump.size() * sizeof(uint32_t)) != hipSuccess ||
+        hipMemcpy(ctx->d_jump, jump.data(), jump.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_stats, sizeof(DeviceStats)) != hipSuccess ||
+        hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)) != hipSuccess)
+        return fail(nullptr, HRT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(hipGetLastError()));
+    if (const char *e = std::getenv("HRT_TRAVERSE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 16) ctx->traverse_blocks_per_cu = v; }
+    if (const char *e = std::getenv("HRT_REFILL_THRESHOLD")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->refill_threshold = v; }
+    *out_ctx = ctx.release();
+    return HRT_OK;
+}
+
+int hrt_ctx_set_flags(HrtContext *ctx, uint32_t flags) {
+    if (!ctx) return HRT_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    drain_spans(ctx);
+    ctx->flags = flags;
+    return HRT_OK;
+}
+
+int hrt_ctx_destroy(HrtContext *ctx) {
+    if (!ctx) return HRT_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : ctx->tlas) free_tlas_device(*kv.second);
+    Workspace &w = ctx->ws;
+    void *ptrs[] = {w.rays[0], w.rays[1], w.hit_tuvp, w.hit_inst, w.bin_items, w.chain, w.accum, w.rows, w.stages,
+                    ctx->d_jump, ctx->d_stats, ctx->d_hitgroups, ctx->d_inst_program};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    delete ctx;
+    return HRT_OK;
+}
+
+// ---- acceleration structures ---------------------------------------------------------
+int hrt_blas_build_triangles(HrtContext *ctx, const HrtFloat3 *d_vertices, uint32_t n_vertices, void *stream, HrtTraversable *out_blas) {
+    if (!ctx || !out_blas) return HRT_ERR_INVALID;
+    if (n_vertices % 3 != 0) return fail(ctx, HRT_ERR_INVALID, "n_vertices (%u) is not a multiple of 3", n_vertices);
+    if (n_vertices && !d_vertices) return fail(ctx, HRT_ERR_INVALID, "d_vertices is NULL");
+    (void)hipSetDevice(ctx->device);
+    std::unique_ptr<Blas> b(new Blas());
+    b->kind = kPrimKindTriangle; b->n_prims = n_vertices / 3;
+    b->verts.resize(3 * (size_t)n_vertices);
+    if (n_vertices) {
+        HIP_TRY(ctx, hipMemcpyAsync(b->verts.data(), d_vertices, sizeof(float) * 3 * (size_t)n_vertices, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const uint64_t h = ctx->next_handle++;
+    ctx->blas[h] = std::move(b);
+    *out_blas = h;
+    return HRT_OK;
+}
+
+int hrt_blas_build_spheres(HrtContext *ctx, const HrtFloat3 *d_centers, const float *d_radii, uint32_t n, void *stream, HrtTraversable *out_blas) {
+    if (!ctx || !out_blas) return HRT_ERR_INVALID;
+    if (n && (!d_centers || !d_radii)) return fail(ctx, HRT_ERR_INVALID, "sphere arrays are NULL");
+    (void)hipSetDevice(ctx->device);
+    std::unique_ptr<Blas> b(new Blas());
+    b->kind = kPrimKindSphere; b->n_prims = n;
+    b->centers.resize(3 * (size_t)n); b->radii.resize(n);
+    if (n) {
+        HIP_TRY(ctx, hipMemcpyAsync(b->centers.data(), d_centers, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        HIP_TRY(ctx, hipMemcpyAsync(b->radii.data(), d_radii, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const uint64_t h = ctx->next_handle++;
+    ctx->blas[h] = std::move(b);
+    *out_blas = h;
+    return HRT_OK;
+}
+
+int hrt_blas_destroy(HrtContext *ctx, HrtTraversable blas) {
+    if (!ctx) return HRT_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return ctx->blas.erase(blas) ? HRT_OK : fail(ctx, HRT_ERR_INVALID, "unknown BLAS handle");
+}
+
+int hrt_tlas_build(HrtContext *ctx, const HrtInstance *d_instances, uint32_t n, void *stream, HrtTraversable *out_tlas) {
+    if (!ctx || !out_tlas) return HRT_ERR_INVALID;
+    if (n && !d_instances) return fail(ctx, HRT_ERR_INVALID, "d_instances is NULL");
+    (void)hipSetDevice(ctx->device);
+    std::unique_ptr<Tlas> t(new Tlas());
+    const int rc = build_tlas_into(ctx, *t, d_instances, n, (hipStream_t)stream);
+    if (rc != HRT_OK) { free_tlas_device(*t); return rc; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const uint64_t h = ctx->next_handle++;
+    ctx->tlas[h] = std::move(t);
+    *out_tlas = h;
+    return HRT_OK;
+}
+
+int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_instances, uint32_t n, void *stream) {
+    if (!ctx) return HRT_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    Tlas *t;
+    { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->tlas.find(tlas); if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle"); t = it->second.get(); }
+    if (n != t->n_instances) return fail(ctx, HRT_ERR_INVALID, "update must keep the instance count (%u != %u)", n, t->n_instances);
+    // The flattened world-space tree is rebuilt (a refit of a two-level structure is a later row).
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    return build_tlas_into(ctx, *t, d_instances, n, (hipStream_t)stream);
+}
+
+int hrt_tlas_destroy(HrtContext *ctx, HrtTraversable tlas) {
+    if (!ctx) return HRT_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->tlas.find(tlas);
+    if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle");
+    (void)hipDeviceSynchronize();
+    free_tlas_device(*it->second);
+    ctx->tlas.erase(it);
+    return HRT_OK;
+}
+
+// ---- SBT ------------------------------------------------------------------------------
+int hrt_sbt_record_pack_header(HrtProgram program, void *record_header) {
+    if (!record_header || (int)program < 0 || (int)program >= (int)HRT_PROGRAM_COUNT) return HRT_ERR_INVALID;
+    unsigned char *h = (unsigned char *)record_header;
+    std::memset(h, 0, HRT_SBT_RECORD_HEADER_SIZE);
+    h[0] = 'H'; h[1] = 'R'; h[2] = 'T'; h[3] = (unsigned char)program;
+    return HRT_OK;
+}
+
+int hrt_materials_set(HrtContext *ctx, const HrtSbtRecord *h_records, uint32_t n_records) {
+    if (!ctx || (n_records && !h_records)) return HRT_ERR_INVALID;
+    for (uint32_t i = 0; i < n_records; ++i) {
+        const unsigned char *h = h_records[i].header;
+        if (h[0] != 'H' || h[1] != 'R' || h[2] != 'T' || h[3] >= HRT_PROGRAM_COUNT)
+            return fail(ctx, HRT_ERR_INVALID, "SBT record %u: header not packed by hrt_sbt_record_pack_header", i);
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->records.assign(h_records, h_records + n_records);
+    ctx->have_records = true;
+    ctx->materials_generation++;
+    return HRT_OK;
+}
+
+int hrt_miss_set(HrtContext *ctx, const HrtMissParams *h_miss) {
+    if (!ctx || !h_miss) return HRT_ERR_INVALID;
+    ctx->miss = *h_miss;
+    return HRT_OK;
+}
+
+// ---- RNG ------------------------------------------------------------------------------
+int hrt_rng_init(HrtContext *ctx, uint32_t width, uint32_t height, uint64_t seed_salt, void *stream, HrtRngState **out_d_states) {
+    if (!ctx || !out_d_states) return HRT_ERR_INVALID;
+    const uint64_t n64 = (uint64_t)width * height;
+    if (n64 == 0 || n64 > 0xffffffffull) return fail(ctx, HRT_ERR_INVALID, "frame %ux%u is empty or exceeds 2^32 pixels", width, height);
+    (void)hipSetDevice(ctx->device);
+    RngState *d = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&d, sizeof(RngState) * n64));
+    launch_rng_init(d, (uint32_t)n64, seed_salt, ctx->d_jump, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));      // reference: cudaStreamSynchronize, HostFunctions.cu:135
+    *out_d_states = reinterpret_cast<HrtRngState *>(d);
+    return HRT_OK;
+}
+
+int hrt_rng_free(HrtContext *ctx, HrtRngState *d_states, void *stream) {
+    if (!ctx) return HRT_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(ctx, hipFree(d_states));
+    return HRT_OK;
+}
+
+// ---- the launch -----------------------------------------------------------------------
+static int refresh_tables(HrtContext *ctx, uint64_t handle, Tlas *t, hipStream_t s) {
+    if (ctx->table_tlas == handle && ctx->table_tlas_gen == t->generation && ctx->table_mat_gen == ctx->materials_generation) return HRT_OK;
+    const uint32_t n = std::max(t->n_instances, 1u);
+    std::vector<HitGroup> hg(n); std::vector<uint32_t> prog(n, 0);
+    for (auto &p : ctx->program_present) p = false;
+    for (uint32_t i = 0; i < t->n_instances; ++i) {
+        const uint32_t off = t->sbt_offset[i];
+        if (off >= ctx->records.size()) return fail(ctx, HRT_ERR_STATE, "instance %u: sbtOffset %u has no SBT record (%zu set)", i, off, ctx->records.size());
+        const HrtSbtRecord &r = ctx->records[off];
+        const uint32_t program = r.header[3];
+        const bool sphere_prog = program == HRT_PROGRAM_SPHERE_ROUGH || program == HRT_PROGRAM_SPHERE_METAL;
+        if (sphere_prog != (t->kind[i] == kPrimKindSphere))
+            return fail(ctx, HRT_ERR_STATE, "instance %u: program %u does not match its geometry", i, program);
+        std::memcpy(&hg[i], &r.data, sizeof(HitGroup));
+        prog[i] = program;
+        ctx->program_present[program] = true;
+    }
+    if (n > ctx->table_capacity) {
+        if (ctx->d_hitgroups) { (void)hipFree(ctx->d_hitgroups); (void)hipFree(ctx->d_inst_program); }
+        ctx->table_capacity = 0;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_hitgroups, sizeof(HitGroup) * n));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_inst_program, sizeof(uint32_t) * n));
+        ctx->table_capacity = n;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_hitgroups, hg.data(), sizeof(HitGroup) * n, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_inst_program, prog.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    ctx->table_tlas = handle; ctx->table_tlas_gen = t->generation; ctx->table_mat_gen = ctx->materials_generation;
+    return HRT_OK;
+}
+
+int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const HrtRayGenParams *rg, uint32_t spp,
+                      const HrtTile *tile, void *stream) {
+    if (!ctx || !h_params || !rg) return HRT_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipSetDevice(ctx->device);
+    if (spp == 0) return fail(ctx, HRT_ERR_INVALID, "spp must be >= 1");
+    if (rg->width == 0 || rg->height == 0 || (uint64_t)rg->width * rg->height > 0xffffffffull) return fail(ctx, HRT_ERR_INVALID, "bad frame size %ux%u", rg->width, rg->height);
+    if (!rg->colorBuffer) return fail(ctx, HRT_ERR_INVALID, "RayGenParams.colorBuffer is NULL");
+    if (!h_params->stateArray) return fail(ctx, HRT_ERR_INVALID, "GlobalParams.stateArray is NULL");
+    if (!ctx->have_records) return fail(ctx, HRT_ERR_STATE, "hrt_materials_set has not been called");
+    Tlas *t;
+    { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->tlas.find(h_params->handle);
+      if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "GlobalParams.handle 0x%llx is not a TLAS", (unsigned long long)h_params->handle);
+      t = it->second.get(); }
+    int rc = refresh_tables(ctx, h_params->handle, t, s);
+    if (rc != HRT_OK) return rc;
+
+    // ---- tile rows ----
+    HrtTile tl = tile ? *tile : HrtTile{0, rg->height, 1, 1, 0};
+    if (tl.stripe_rows == 0 || tl.stripe_period == 0 || tl.stripe_phase >= tl.stripe_period || tl.y_begin > tl.y_end || tl.y_end > rg->height)
+        return fail(ctx, HRT_ERR_INVALID, "bad tile");
+    const bool same_rows = ctx->rows_w == rg->width && ctx->rows_h == rg->height && std::memcmp(&ctx->rows_tile, &tl, sizeof tl) == 0 && ctx->ws.rows;
+    if (!same_rows) {
+        ctx->h_rows.clear();
+        for (uint32_t y = tl.y_begin; y < tl.y_end; ++y)
+            if ((y / tl.stripe_rows) % tl.stripe_period == tl.stripe_phase) ctx->h_rows.push_back(y);
+    }
+    const uint32_t n_rows = (uint32_t)ctx->h_rows.size();
+    const uint64_t n64 = (uint64_t)n_rows * rg->width;
+    if (n64 == 0) return HRT_OK;
+    const uint32_t n = (uint32_t)n64;
+    rc = ensure_workspace(ctx, n, rg->height);
+    if (rc != HRT_OK) return rc;
+    Workspace &w = ctx->ws;
+    if (!same_rows) {
+        HIP_TRY(ctx, hipMemcpyAsync(w.rows, ctx->h_rows.data(), sizeof(uint32_t) * n_rows, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        ctx->rows_tile = tl; ctx->rows_w = rg->width; ctx->rows_h = rg->height;
+    }
+
+    const bool count = (ctx->flags & HRT_CTX_COUNT) != 0;
+    const uint32_t wide_grid = std::min<uint32_t>((uint32_t)ctx->n_cu * 8u, (n + 255u) / 256u);
+    const uint32_t trav_grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (n + 255u) / 256u);
+
+    GenerateArgs ga{};
+    ga.rays = w.rays[0]; ga.rows = w.rows; ga.n_tile_pixels = n; ga.width = rg->width; ga.height = rg->height;
+    std::memcpy(ga.center, &rg->cameraCenter, 12); std::memcpy(ga.U, &rg->cameraU, 12);
+    std::memcpy(ga.V, &rg->cameraV, 12); std::memcpy(ga.W, &rg->cameraW, 12);
+
+    for (uint32_t sample = 0; sample < spp; ++sample) {
+        HIP_TRY(ctx, hipMemsetAsync(w.stages, 0, sizeof(StageCounters) * (kRayTraceDepth + 1), s));
+        { Timer tm(ctx, s, HRT_K_GENERATE); launch_generate(ga, s); }
+        int cur = 0;
+        for (uint32_t depth = 1; depth <= kRayTraceDepth; ++depth) {
+            const bool any_hit = depth >= kRayTraceDepth;      // a hit at the depth limit is black whatever it is (Shader.cu:102-107)
+            const uint32_t *n_ptr = depth == 1 ? nullptr : &w.stages[depth - 1].bin_count[1];
+            TraverseArgs ta{};
+            ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.rays = w.rays[cur];
+            ta.n_rays_ptr = n_ptr; ta.n_rays = n; ta.fetch_counter = &w.stages[depth].fetch;
+            ta.hit_tuvp = w.hit_tuvp; ta.hit_inst = w.hit_inst;
+            ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
+            ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;      // Shader.cu:232, :266
+            ta.refill_threshold = ctx->refill_threshold;
+            ta.count_nodes = any_hit ? &ctx->d_stats->nodes_any : &ctx->d_stats->nodes_closest;
+            ta.count_prims = any_hit ? &ctx->d_stats->prims_any : &ctx->d_stats->prims_closest;
+            { Timer tm(ctx, s, any_hit ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
+              launch_traverse(ta, any_hit, count, t->has_spheres, trav_grid, s); }
+
+            BinArgs ba{};
+            ba.n_rays_ptr = n_ptr; ba.n_rays = n; ba.hit_inst = w.hit_inst; ba.inst_program = ctx->d_inst_program; ba.depth = depth;
+            ba.bin_count = w.stages[depth].bin_count; ba.bin_items = w.bin_items; ba.bin_stride = n;
+            ba.total_rays = any_hit ? &ctx->d_stats->rays_any : &ctx->d_stats->rays_closest;
+            { Timer tm(ctx, s, HRT_K_BIN); launch_bin(ba, wide_grid, s); }
+
+            if (depth < kRayTraceDepth) {
+                ShadeArgs sa{};
+                sa.bin_count = w.stages[depth].bin_count; sa.bin_items = w.bin_items; sa.bin_stride = n;
+                sa.rays_in = w.rays[cur]; sa.rays_out = w.rays[cur ^ 1];
+                sa.hit_tuvp = w.hit_tuvp; sa.hit_inst = w.hit_inst; sa.hitgroups = ctx->d_hitgroups;
+                sa.states = reinterpret_cast<RngState *>(h_params->stateArray);
+                sa.chain = w.chain; sa.depth = depth;
+                for (int p = 0; p < (int)kNumPrograms; ++p)
+                    if (ctx->program_present[p]) { Timer tm(ctx, s, HRT_K_SHADE); launch_shade(sa, p, wide_grid, s); }
+            }
+            AccumArgs aa{};
+            aa.bin_count = w.stages[depth].bin_count; aa.bin_items = w.bin_items; aa.rays_in = w.rays[cur]; aa.hit_inst = w.hit_inst;
+            aa.hitgroups = ctx->d_hitgroups; aa.chain = w.chain; aa.accum = w.accum;
+            aa.bg[0] = ctx->miss.backgroundColor.x; aa.bg[1] = ctx->miss.backgroundColor.y; aa.bg[2] = ctx->miss.backgroundColor.z;
+            aa.depth = depth; aa.first_sample = sample == 0 ? 1u : 0u;
+            { Timer tm(ctx, s, HRT_K_ACCUMULATE); launch_accumulate(aa, wide_grid, s); }
+            cur ^= 1;
+        }
+    }
+    FinalizeArgs fa{};
+    fa.accum = w.accum; fa.rows = w.rows; fa.n_tile_pixels = n; fa.width = rg->width; fa.spp = spp;
+    fa.color = reinterpret_cast<float4 *>(rg->colorBuffer); fa.albedo = reinterpret_cast<float4 *>(rg->albedoBuffer);
+    fa.normal = reinterpret_cast<float4 *>(rg->normalBuffer); fa.linear = ctx->d_linear;
+    { Timer tm(ctx, s, HRT_K_FINALIZE); launch_finalize(fa, s); }
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->paths += (uint64_t)n * spp;
+    ctx->last_tlas = h_params->handle;
+    return HRT_OK;
+}
+
+int hrt_sync(HrtContext *ctx, void *stream) {
+    if (!ctx) return HRT_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return HRT_OK;
+}
+
+int hrt_to_rgba8(HrtContext *ctx, const HrtFloat4 *d_src, HrtUchar4 *d_dst, uint32_t width, uint32_t height, void *stream) {
+    if (!ctx || !d_src || !d_dst) return HRT_ERR_INVALID;
+    const uint64_t n = (uint64_t)width * height;
+    if (n > 0xffffffffull) return fail(ctx, HRT_ERR_INVALID, "frame too large");
+    (void)hipSetDevice(ctx->device);
+    launch_to_rgba8(reinterpret_cast<const float4 *>(d_src), reinterpret_cast<uchar4 *>(d_dst), (uint32_t)n, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return HRT_OK;
+}
+
+// ---- measurement ----------------------------------------------------------------------
+int hrt_stats_reset(HrtContext *ctx) {
+    if (!ctx) return HRT_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    HIP_TRY(ctx, hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)));
+    drain_spans(ctx);
+    for (int k = 0; k < HRT_K_COUNT; ++k) { ctx->kernel_ms[k] = 0.0; ctx->kernel_launches[k] = 0; }
+    ctx->paths = 0;
+    return HRT_OK;
+}
+
+int hrt_stats_get(HrtContext *ctx, HrtStats *out) {
+    if (!ctx || !out) return HRT_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    drain_spans(ctx);
+    DeviceStats ds;
+    HIP_TRY(ctx, hipMemcpy(&ds, ctx->d_stats, sizeof ds, hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof *out);
+    out->rays_closest = ds.rays_closest; out->rays_any = ds.rays_any; out->rays = ds.rays_closest + ds.rays_any;
+    out->paths = ctx->paths; out->node_visits = ds.nodes_closest + ds.nodes_any; out->prim_tests = ds.prims_closest + ds.prims_any;
+    out->node_visits_closest = ds.nodes_closest; out->prim_tests_closest = ds.prims_closest;
+    for (int k = 0; k < HRT_K_COUNT; ++k) { out->kernel_ms[k] = ctx->kernel_ms[k]; out->kernel_launches[k] = ctx->kernel_launches[k]; }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->tlas.find(ctx->last_tlas);
+    if (it != ctx->tlas.end()) {
+        const Bvh8 &b = it->second->bvh;
+        out->bvh_nodes = b.nodes.size(); out->bvh_triangles = b.n_triangles; out->bvh_spheres = b.n_spheres;
+        out->bvh_bytes = b.nodes.size() * sizeof(Bvh8Node) + b.prims.size() * sizeof(PrimRecord);
+    }
+    return HRT_OK;
+}
+
+// ---- introspection for the parity tests -----------------------------------------------
+int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_origins, const HrtFloat3 *d_directions, uint32_t n_rays,
+                   float tmin, float tmax, int any_hit, float *d_t, float *d_u, float *d_v, uint32_t *d_prim, uint32_t *d_inst, void *stream) {
+    if (!ctx || !d_origins || !d_directions || !d_t || !d_u || !d_v || !d_prim || !d_inst) return HRT_ERR_INVALID;
+    if (n_rays == 0) return HRT_OK;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipSetDevice(ctx->device);
+    Tlas *t;
+    { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->tlas.find(tlas); if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle"); t = it->second.get(); }
+    RayRec *rays = nullptr; float4 *tuvp = nullptr; uint32_t *inst = nullptr, *fetch = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&rays, sizeof(RayRec) * (size_t)n_rays));
+    HIP_TRY(ctx, hipMalloc((void **)&tuvp, sizeof(float4) * (size_t)n_rays));
+    HIP_TRY(ctx, hipMalloc((void **)&inst, sizeof(uint32_t) * (size_t)n_rays));
+    HIP_TRY(ctx, hipMalloc((void **)&fetch, sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMemsetAsync(fetch, 0, sizeof(uint32_t), s));
+    launch_pack_rays(reinterpret_cast<const float *>(d_origins), reinterpret_cast<const float *>(d_directions), n_rays, rays, s);
+    TraverseArgs ta{};
+    ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.rays = rays; ta.n_rays_ptr = nullptr; ta.n_rays = n_rays;
+    ta.fetch_counter = fetch; ta.hit_tuvp = tuvp; ta.hit_inst = inst; ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
+    ta.tmin = tmin; ta.tmax = tmax; ta.refill_threshold = ctx->refill_threshold;
+    ta.count_nodes = any_hit ? &ctx->d_stats->nodes_any : &ctx->d_stats->nodes_closest;
+    ta.count_prims = any_hit ? &ctx->d_stats->prims_any : &ctx->d_stats->prims_closest;
+    const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (n_rays + 255u) / 256u);
+    { Timer tm(ctx, s, any_hit ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
+      launch_traverse(ta, any_hit != 0, (ctx->flags & HRT_CTX_COUNT) != 0, t->has_spheres, grid, s); }
+    launch_unpack_hits(tuvp, inst, n_rays, d_t, d_u, d_v, d_prim, d_inst, s);
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(rays); (void)hipFree(tuvp); (void)hipFree(inst); (void)hipFree(fetch);
+    if (e != hipSuccess) return fail(ctx, HRT_ERR_HIP, "hrt_trace_rays: %s", hipGetErrorString(e));
+    ctx->last_tlas = tlas;
+    return HRT_OK;
+}
+
+int hrt_debug_set_linear_output(HrtContext *ctx, HrtFloat4 *d_linear) {
+    if (!ctx) return HRT_ERR_INVALID;
+    ctx->d_linear = reinterpret_cast<float4 *>(d_linear);
+    return HRT_OK;
+}
+
+static int fill_blob(const Bvh8 &b, HrtBvhBlob *out) {
+    std::memset(out, 0, sizeof *out);
+    out->n_nodes = b.nodes.size(); out->n_triangles = b.prims.size();
+    out->nodes = std::malloc(std::max<size_t>(1, sizeof(Bvh8Node) * b.nodes.size()));
+    out->triangles = std::malloc(std::max<size_t>(1, sizeof(PrimRecord) * b.prims.size()));
+    if (!out->nodes || !out->triangles) { std::free(out->nodes); std::free(out->triangles); std::memset(out, 0, sizeof *out); return HRT_ERR_OOM; }
+    std::memcpy(out->nodes, b.nodes.data(), sizeof(Bvh8Node) * b.nodes.size());
+    std::memcpy(out->triangles, b.prims.data(), sizeof(PrimRecord) * b.prims.size());
+    for (int a = 0; a < 3; ++a) { out->bounds[a] = b.lo[a]; out->bounds[3 + a] = b.hi[a]; }
+    return HRT_OK;
+}
+
+int hrt_host_build_bvh8(const float *h_triangles, uint32_t n_triangles, HrtBvhBlob *out) {
+    if (!out || (n_triangles && !h_triangles)) return HRT_ERR_INVALID;
+    std::vector<BuildPrim> prims(n_triangles);
+    for (uint32_t p = 0; p < n_triangles; ++p) {
+        BuildPrim &bp = prims[p]; std::memset(&bp, 0, sizeof bp);
+        const float *v = h_triangles + 9 * (size_t)p;
+        for (int a = 0; a < 3; ++a) {
+            bp.rec.a[a] = v[a]; bp.rec.b[a] = v[3 + a] - v[a]; bp.rec.c[a] = v[6 + a] - v[a];
+            bp.lo[a] = std::fmin(v[a], std::fmin(v[3 + a], v[6 + a]));
+            bp.hi[a] = std::fmax(v[a], std::fmax(v[3 + a], v[6 + a]));
+        }
+        bp.rec.prim = p; bp.rec.inst = 0; bp.rec.kind = kPrimKindTriangle;
+    }
+    Bvh8 b;
+    build_bvh8(prims, b, 0);
+    const char *err = validate_bvh8(b);
+    if (err[0]) { g_create_error = std::string("bvh8 validation: ") + err; return HRT_ERR_STATE; }
+    return fill_blob(b, out);
+}
+
+int hrt_tlas_download(HrtContext *ctx, HrtTraversable tlas, HrtBvhBlob *out) {
+    if (!ctx || !out) return HRT_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->tlas.find(tlas);
+    if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle");
+    return fill_blob(it->second->bvh, out);
+}
+
+void hrt_host_free(HrtBvhBlob *blob) {
+    if (!blob) return;
+    std::free(blob->nodes); std::free(blob->triangles);
+    std::memset(blob, 0, sizeof *blob);
+}
+
+}  // extern "C"

@@ -1,0 +1,660 @@
+// kernels.hip -- the wavefront path tracer's device code for gfx950 (CDNA4, wave64).
+//
+// Replaces the OptiX pipeline of the reference (shader/Shader.cu: raygen :246-273, miss
+// :276-287, closest-hit :94-242, :297-310; RT-core traversal requested at
+// src/Global/RendererImpl.cu:295-314) with explicit kernels:
+//
+//   k_rng_init      XORWOW curand_init restated (HostFunctions.cu:122-127)
+//   k_generate      primary rays                 (Shader.cu:246-267)
+//   k_traverse      persistent-wave BVH8 closest-hit / any-hit traversal (optixTrace, Shader.cu:70)
+//   k_bin_hits      sort hits by program with wave ballot + prefix count (SBT dispatch)
+//   k_shade<P>      one kernel per closest-hit program (Shader.cu:108-233)
+//   k_accumulate    path termination: miss colour / depth cut-off, innermost-first albedo fold
+//                   (Shader.cu:102-107, :236-238, :276-287)
+//   k_finalize      mean over samples + colorToFloat4 + AOVs (Shader.cu:270-272)
+//   k_to_rgba8      convertFloat4ToUchar4Kernel (RendererImpl.cu:672-678)
+//
+// Arithmetic that feeds control flow is written with a fixed operation order and compiled
+// with -ffp-contract=off so that it is bit-identical to the CPU oracle; fused multiply-adds
+// appear only where written explicitly (fmaf) in the conservative box test.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "device_types.h"
+
+#pragma clang fp contract(off)
+
+namespace hrt {
+
+// ---------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ uint32_t wave_first_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 add3(V3 a, V3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 sub3(V3 a, V3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 muls3(V3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 divs3(V3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ V3 neg3(V3 a) { return mk3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float len2_3(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// normalize(), include/Global/DeviceFunctions.cuh:397-404; rsqrtf pinned as 1/sqrtf
+__device__ __forceinline__ V3 normalize3(V3 a) {
+    const float len2 = len2_3(a);
+    if (len2 <= kFloatZero * kFloatZero) return mk3(0.0f, 0.0f, 1.0f);
+    const float invLen = 1.0f / sqrtf(len2);
+    return muls3(a, invLen);
+}
+__device__ __forceinline__ bool finite3(V3 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
+
+// ---------------------------------------------------------------------------------------
+// XORWOW (cuRAND curandStateXORWOW_t)
+// ---------------------------------------------------------------------------------------
+struct Xorwow { uint32_t d, v0, v1, v2, v3, v4; };
+
+__device__ __forceinline__ uint32_t xorwow_next(Xorwow &s) {
+    const uint32_t t = s.v0 ^ (s.v0 >> 2);
+    s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3; s.v3 = s.v4;
+    s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
+    s.d += 362437u;
+    return s.v4 + s.d;
+}
+// curand_uniform: (0, 1]
+__device__ __forceinline__ float xorwow_uniform(Xorwow &s) {
+    return (float)xorwow_next(s) * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+}
+__device__ __forceinline__ Xorwow rng_load(const RngState *st) {
+    const uint2 *p = reinterpret_cast<const uint2 *>(st);
+    const uint2 a = p[0], b = p[1], c = p[2];
+    Xorwow s; s.d = a.x; s.v0 = a.y; s.v1 = b.x; s.v2 = b.y; s.v3 = c.x; s.v4 = c.y;
+    return s;
+}
+__device__ __forceinline__ void rng_store(RngState *st, const Xorwow &s) {
+    uint2 *p = reinterpret_cast<uint2 *>(st);
+    p[0] = make_uint2(s.d, s.v0); p[1] = make_uint2(s.v1, s.v2); p[2] = make_uint2(s.v3, s.v4);
+}
+
+// curand_init(seed = tid ^ salt, subsequence = tid, offset = 0): src/Global/HostFunctions.cu:122-127,
+// bounds-checked and indexed by the frame width (quirk Q9), clock64() pinned to salt (Q8).
+// jump[k] = T^(2^(67+k)) as 160 columns of 5 words.
+__global__ __launch_bounds__(256) void k_rng_init(RngState *states, uint32_t n, uint64_t salt,
+                                                  const uint32_t *__restrict__ jump) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n) return;
+    const uint64_t seed = (uint64_t)tid ^ salt;
+    const uint32_t s0 = ((uint32_t)seed) ^ 0xaad26b49u;
+    const uint32_t s1 = ((uint32_t)(seed >> 32)) ^ 0xf7dcefddu;
+    const uint32_t t0 = 1099087573u * s0;
+    const uint32_t t1 = 2591861531u * s1;
+    uint32_t v[5];
+    const uint32_t d = 6615241u + t1 + t0;
+    v[0] = 123456789u + t0; v[1] = 362436069u ^ t0; v[2] = 521288629u + t1; v[3] = 88675123u ^ t1; v[4] = 5783321u + t0;
+    for (uint32_t k = 0; k < 32 && (tid >> k) != 0; ++k) {
+        if (((tid >> k) & 1u) == 0) continue;
+        const uint32_t *m = jump + (size_t)k * 800;
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
+        for (int w = 0; w < 5; ++w) {
+            const uint32_t word = v[w];
+            for (int b = 0; b < 32; ++b) {
+                const uint32_t msk = 0u - ((word >> b) & 1u);
+                const uint32_t *c = m + (w * 32 + b) * 5;
+                r0 ^= c[0] & msk; r1 ^= c[1] & msk; r2 ^= c[2] & msk; r3 ^= c[3] & msk; r4 ^= c[4] & msk;
+            }
+        }
+        v[0] = r0; v[1] = r1; v[2] = r2; v[3] = r3; v[4] = r4;
+    }
+    RngState out;
+    out.d = d; out.v[0] = v[0]; out.v[1] = v[1]; out.v[2] = v[2]; out.v[3] = v[3]; out.v[4] = v[4];
+    out.boxmuller_flag = 0; out.boxmuller_flag_double = 0; out.boxmuller_extra = 0.0f; out._pad = 0.0f;
+    out.boxmuller_extra_double = 0.0;
+    states[tid] = out;
+}
+
+// ---------------------------------------------------------------------------------------
+// generate: __raygen__raygenProgram up to the trace call, shader/Shader.cu:246-267
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_generate(GenerateArgs a) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.n_tile_pixels) return;
+    const uint32_t row = j / a.width;
+    const uint32_t ix = j - row * a.width;
+    const uint32_t iy = a.rows[row];
+    const float ndcx = (((float)ix + 0.5f) / (float)a.width) * 2.0f - 1.0f;        // :250
+    const float ndcy = (((float)iy + 0.5f) / (float)a.height) * 2.0f - 1.0f;       // :251
+    const V3 U = mk3(a.U[0], a.U[1], a.U[2]), V = mk3(a.V[0], a.V[1], a.V[2]), W = mk3(a.W[0], a.W[1], a.W[2]);
+    const float aspect = (float)a.width / (float)a.height;                        // :260
+    const V3 dir = normalize3(add3(add3(muls3(U, ndcx * aspect), muls3(V, ndcy)), W));   // :261
+    RayRec r;
+    r.o = make_float4(a.center[0], a.center[1], a.center[2], __uint_as_float(j));
+    r.d = make_float4(dir.x, dir.y, dir.z, __uint_as_float(iy * a.width + ix));
+    a.rays[j] = r;
+}
+
+// ---------------------------------------------------------------------------------------
+// traverse: persistent waves over a ray queue, BVH8 with compressed child boxes
+// ---------------------------------------------------------------------------------------
+constexpr int kLdsStack = 8;          // entries per lane staged in LDS
+constexpr int kSpillStack = 40;       // overflow entries per lane in scratch
+constexpr int kTraverseBlock = 256;
+
+struct TravState {
+    float ox, oy, oz, dx, dy, dz;
+    float idx, idy, idz;
+    float bt, bu, bv;
+    uint32_t bprim, binst;
+    uint32_t oct_inv4;
+    uint2 cur;
+    int sp;
+    uint32_t slot;
+};
+
+__device__ __forceinline__ float safe_rcp_dir(float d) {
+    const float lim = 1e-20f;
+    const float dd = fabsf(d) < lim ? copysignf(lim, d) : d;
+    return 1.0f / dd;
+}
+
+// canonical primitive test (DESIGN.md "canonical intersector"); updates the best hit.
+template <bool HAS_SPHERES>
+__device__ __forceinline__ bool test_prim(const float4 *__restrict__ prims, uint32_t pi, TravState &s,
+                                          float tmin, float tmax_ray,
+                                          const float *__restrict__ inst_inv, const uint32_t *__restrict__ inst_identity) {
+    const float4 A = prims[3 * (size_t)pi + 0];
+    const float4 B = prims[3 * (size_t)pi + 1];
+    const float4 C = prims[3 * (size_t)pi + 2];
+    float t, u = 0.0f, v = 0.0f;
+    uint32_t prim = __float_as_uint(A.w), inst;
+    const V3 o = mk3(s.ox, s.oy, s.oz), d = mk3(s.dx, s.dy, s.dz);
+    if (HAS_SPHERES && __float_as_uint(C.w) == 1u) {
+        inst = __float_as_uint(B.w);
+        V3 oo = o, dd = d;
+        if (!inst_identity[inst]) {
+            const float *m = inst_inv + 12 * (size_t)inst;
+            oo = mk3(((m[0] * o.x + m[1] * o.y) + m[2] * o.z) + m[3], ((m[4] * o.x + m[5] * o.y) + m[6] * o.z) + m[7],
+                     ((m[8] * o.x + m[9] * o.y) + m[10] * o.z) + m[11]);
+            dd = mk3((m[0] * d.x + m[1] * d.y) + m[2] * d.z, (m[4] * d.x + m[5] * d.y) + m[6] * d.z,
+                     (m[8] * d.x + m[9] * d.y) + m[10] * d.z);
+        }
+        const V3 oc = sub3(oo, mk3(A.x, A.y, A.z));
+        const float r = B.x;
+        const float a = dot3(dd, dd);
+        if (!(a != 0.0f)) return false;
+        const float b = dot3(oc, dd);
+        const float cc = dot3(oc, oc) - r * r;
+        const float disc = b * b - a * cc;
+        if (!(disc >= 0.0f)) return false;
+        const float sq = sqrtf(disc);
+        const float t0 = (-b - sq) / a;
+        if (t0 > tmin && t0 < tmax_ray) t = t0;
+        else {
+            const float t1 = (-b + sq) / a;
+            if (t1 > tmin && t1 < tmax_ray) t = t1; else return false;
+        }
+    } else {
+        inst = __float_as_uint(B.w);
+        const V3 e1 = mk3(B.x, B.y, B.z), e2 = mk3(C.x, C.y, C.z);
+        const V3 pvec = cross3(d, e2);
+        const float det = dot3(e1, pvec);
+        if (!(det != 0.0f)) return false;
+        const float inv = 1.0f / det;
+        const V3 tvec = sub3(o, mk3(A.x, A.y, A.z));
+        u = dot3(tvec, pvec) * inv;
+        if (!(u >= 0.0f && u <= 1.0f)) return false;
+        const V3 qvec = cross3(tvec, e1);
+        v = dot3(d, qvec) * inv;
+        if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+        t = dot3(e2, qvec) * inv;
+        if (!(t > tmin && t < tmax_ray)) return false;
+    }
+    // closest hit: min t, ties -> lowest (instance, primitive)
+    const bool has = s.bprim != kMissPrim;
+    bool better = !has || t < s.bt;
+    if (!better && t == s.bt) {
+        const uint64_t id = ((uint64_t)inst << 32) | prim, bid = ((uint64_t)s.binst << 32) | s.bprim;
+        better = id < bid;
+    }
+    if (better) { s.bt = t; s.bu = u; s.bv = v; s.bprim = prim; s.binst = inst; }
+    return better;
+}
+
+#define HRT_BYTE_F(w, k) ((float)(((w) >> (8 * (k))) & 0xffu))
+
+template <bool ANY_HIT, bool COUNT, bool HAS_SPHERES>
+__global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
+    __shared__ uint2 s_stack[kLdsStack][kTraverseBlock];
+    uint2 spill[kSpillStack];
+
+    const uint32_t n_rays = a.n_rays_ptr ? (a.n_rays_ptr[0] + a.n_rays_ptr[1] + a.n_rays_ptr[2] + a.n_rays_ptr[3]) : a.n_rays;
+    const uint4 *__restrict__ nodes = reinterpret_cast<const uint4 *>(a.nodes);
+    const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(a.prims);
+    const float tmin = a.tmin, tmax_ray = a.tmax;
+    const uint32_t tx = threadIdx.x;
+
+    TravState s;
+    bool alive = false;
+    bool exhausted = false;                 // wave-uniform
+    uint32_t cnt_nodes = 0, cnt_prims = 0;
+
+    for (;;) {
+        // ---- refill idle lanes from the global queue (one atomic per wave) ----
+        const uint64_t idle = __ballot(!alive);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (!exhausted && (n_idle >= (uint32_t)a.refill_threshold || idle == ~0ull)) {
+            uint32_t base = 0;
+            if (lane_prefix(idle) == 0 && !alive) base = atomicAdd(a.fetch_counter, n_idle);
+            // broadcast from the first idle lane
+            const int src = __ffsll((long long)idle) - 1;
+            base = (uint32_t)__shfl((int)base, src);
+            if (base + n_idle >= n_rays) exhausted = true;
+            const uint32_t mine = base + lane_prefix(idle);
+            if (!alive && mine < n_rays) {
+                const RayRec r = a.rays[mine];
+                s.ox = r.o.x; s.oy = r.o.y; s.oz = r.o.z;
+                s.dx = r.d.x; s.dy = r.d.y; s.dz = r.d.z;
+                s.idx = safe_rcp_dir(s.dx); s.idy = safe_rcp_dir(s.dy); s.idz = safe_rcp_dir(s.dz);
+                const uint32_t oct = (s.dx < 0.0f ? 4u : 0u) | (s.dy < 0.0f ? 2u : 0u) | (s.dz < 0.0f ? 1u : 0u);
+                s.oct_inv4 = (7u - oct) * 0x01010101u;
+                s.bt = tmax_ray; s.bu = 0.0f; s.bv = 0.0f; s.bprim = kMissPrim; s.binst = kMissPrim;
+                s.cur = make_uint2(0u, 0x80000000u);
+                s.sp = 0;
+                s.slot = mine;
+                alive = true;
+            }
+        }
+        if (__ballot(alive) == 0ull) break;     // queue drained and every lane finished
+
+        // ---- traverse until enough lanes have finished to make a refill worthwhile ----
+        for (;;) {
+            if (alive) {
+                uint2 tri = make_uint2(0u, 0u);
+                if (s.cur.y > 0x00ffffffu) {
+                    // ---- pop the nearest child of the current node group ----
+                    const uint32_t hits_imask = s.cur.y;
+                    const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
+                    s.cur.y &= ~(1u << bit);
+                    if (s.cur.y > 0x00ffffffu) {
+                        if (s.sp < kLdsStack) s_stack[s.sp][tx] = s.cur; else spill[s.sp - kLdsStack] = s.cur;
+                        ++s.sp;
+                    }
+                    const uint32_t slot_index = (bit - 24u) ^ (s.oct_inv4 & 0xffu);
+                    const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot_index));
+                    const uint4 *np = nodes + 5 * (size_t)(s.cur.x + rel);
+                    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+                    if (COUNT) ++cnt_nodes;
+
+                    const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
+                    const uint32_t e_imask = n0.w;
+                    const float aix = __uint_as_float((e_imask & 0xffu) << 23) * s.idx;
+                    const float aiy = __uint_as_float(((e_imask >> 8) & 0xffu) << 23) * s.idy;
+                    const float aiz = __uint_as_float(((e_imask >> 16) & 0xffu) << 23) * s.idz;
+                    const float aox = (px - s.ox) * s.idx, aoy = (py - s.oy) * s.idy, aoz = (pz - s.oz) * s.idz;
+                    const bool nx = s.dx < 0.0f, ny = s.dy < 0.0f, nz = s.dz < 0.0f;
+                    uint32_t hitmask = 0u;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t meta4 = h ? n1.w : n1.z;
+                        const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+                        const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
+                        const uint32_t bit_index4 = (meta4 ^ (s.oct_inv4 & inner_mask4)) & 0x1f1f1f1fu;
+                        const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+                        const uint32_t qlox = h ? n2.y : n2.x, qloy = h ? n2.w : n2.z, qloz = h ? n3.y : n3.x;
+                        const uint32_t qhix = h ? n3.w : n3.z, qhiy = h ? n4.y : n4.x, qhiz = h ? n4.w : n4.z;
+                        const uint32_t xn = nx ? qhix : qlox, xf = nx ? qlox : qhix;
+                        const uint32_t yn = ny ? qhiy : qloy, yf = ny ? qloy : qhiy;
+                        const uint32_t zn = nz ? qhiz : qloz, zf = nz ? qloz : qhiz;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float tnx = fmaf(HRT_BYTE_F(xn, j), aix, aox), tfx = fmaf(HRT_BYTE_F(xf, j), aix, aox);
+                            const float tny = fmaf(HRT_BYTE_F(yn, j), aiy, aoy), tfy = fmaf(HRT_BYTE_F(yf, j), aiy, aoy);
+                            const float tnz = fmaf(HRT_BYTE_F(zn, j), aiz, aoz), tfz = fmaf(HRT_BYTE_F(zf, j), aiz, aoz);
+                            const float tlo = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+                            const float thi = fminf(fminf(tfx, tfy), fminf(tfz, s.bt));
+                            const uint32_t cb = (child_bits4 >> (8 * j)) & 0xffu;
+                            const uint32_t bi = (bit_index4 >> (8 * j)) & 0xffu;
+                            // widened far plane keeps the test conservative
+                            if (tlo <= thi * 1.0000005f) hitmask |= cb << bi;
+                        }
+                    }
+                    s.cur = make_uint2(n1.x, (hitmask & 0xff000000u) | (e_imask >> 24));
+                    tri = make_uint2(n1.y, hitmask & 0x00ffffffu);
+                }
+
+                // ---- primitives of the leaves hit in this node ----
+                bool done = false;
+                while (tri.y) {
+                    const uint32_t k = (uint32_t)__ffs((int)tri.y) - 1u;
+                    tri.y &= tri.y - 1u;
+                    if (COUNT) ++cnt_prims;
+                    const bool better = test_prim<HAS_SPHERES>(prims, tri.x + k, s, tmin, tmax_ray, a.inst_inv, a.inst_identity);
+                    if (ANY_HIT && better) { done = true; break; }
+                }
+
+                // ---- next node group ----
+                if (!done && s.cur.y <= 0x00ffffffu) {
+                    if (s.sp > 0) {
+                        --s.sp;
+                        s.cur = s.sp < kLdsStack ? s_stack[s.sp][tx] : spill[s.sp - kLdsStack];
+                    } else done = true;
+                }
+                if (done) {
+                    a.hit_tuvp[s.slot] = make_float4(s.bt, s.bu, s.bv, __uint_as_float(s.bprim));
+                    a.hit_inst[s.slot] = s.binst;
+                    alive = false;
+                }
+            }
+            const uint64_t act = __ballot(alive);
+            if (act == 0ull) break;
+            if (!exhausted && (64u - (uint32_t)__popcll(act)) >= (uint32_t)a.refill_threshold) break;
+        }
+    }
+    if (COUNT) {
+        // wave-level reduction, one atomic pair per wave
+        for (int off = 32; off > 0; off >>= 1) {
+            cnt_nodes += (uint32_t)__shfl_down((int)cnt_nodes, off);
+            cnt_prims += (uint32_t)__shfl_down((int)cnt_prims, off);
+        }
+        if ((tx & 63u) == 0u) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(a.count_nodes), (unsigned long long)cnt_nodes);
+            atomicAdd(reinterpret_cast<unsigned long long *>(a.count_prims), (unsigned long long)cnt_prims);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// bin hits by closest-hit program: SBT dispatch as a wave-ballot compaction.
+// bin 0 = path ends here (miss, or any hit at depth >= rayTraceDepth), bin 1+P = program P.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bin_hits(BinArgs a) {
+    const uint32_t n = a.n_rays_ptr ? (a.n_rays_ptr[0] + a.n_rays_ptr[1] + a.n_rays_ptr[2] + a.n_rays_ptr[3]) : a.n_rays;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(a.total_rays), (unsigned long long)n);
+    }
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+        const uint32_t i = base + threadIdx.x;
+        uint32_t bin = 0xffu;
+        if (i < n) {
+            const uint32_t inst = a.hit_inst[i];
+            bin = (inst == kMissPrim || a.depth >= kRayTraceDepth) ? 0u : 1u + a.inst_program[inst];
+        }
+#pragma unroll
+        for (uint32_t b = 0; b < kNumBins; ++b) {
+            const uint64_t m = __ballot(bin == b);
+            if (m == 0ull) continue;
+            uint32_t off = 0;
+            if (bin == b && lane_prefix(m) == 0) off = atomicAdd(&a.bin_count[b], (uint32_t)__popcll(m));
+            off = (uint32_t)__shfl((int)off, __ffsll((long long)m) - 1);
+            if (bin == b) a.bin_items[(size_t)b * a.bin_stride + off + lane_prefix(m)] = i;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// shade: closesthitImpl for one (geometry, material) program, shader/Shader.cu:108-233
+// ---------------------------------------------------------------------------------------
+// randomSpaceVector, include/Global/DeviceFunctions.cuh:570-582 (length = 1)
+__device__ __forceinline__ V3 random_space_vector(Xorwow &rng) {
+    V3 ret; float lengthSquare;
+    do {
+        ret.x = -1.0f + 2.0f * xorwow_uniform(rng);      // randomDouble(state, -1, 1) :220-222
+        ret.y = -1.0f + 2.0f * xorwow_uniform(rng);
+        ret.z = -1.0f + 2.0f * xorwow_uniform(rng);
+        lengthSquare = len2_3(ret);
+    } while (lengthSquare < kFloatZero * kFloatZero);
+    ret = normalize3(ret);
+    return muls3(ret, 1.0f);
+}
+
+template <int PROGRAM>
+__global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
+    constexpr bool kSphere = PROGRAM == kProgramSphereRough || PROGRAM == kProgramSphereMetal;
+    constexpr bool kRough = PROGRAM == kProgramSphereRough || PROGRAM == kProgramTriangleRough;
+    const uint32_t n = a.bin_count[1 + PROGRAM];
+    uint32_t out_base = 0;                                  // programs are laid out one after another
+    for (int p = 0; p < PROGRAM; ++p) out_base += a.bin_count[1 + p];
+    const uint32_t *items = a.bin_items + (size_t)(1 + PROGRAM) * a.bin_stride;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) {
+        const uint32_t i = items[q];
+        const RayRec ray = a.rays_in[i];
+        const float4 hit = a.hit_tuvp[i];
+        const uint32_t inst = a.hit_inst[i];
+        const uint32_t local = __float_as_uint(ray.o.w), tid = __float_as_uint(ray.d.w);
+        const HitGroup hg = a.hitgroups[inst];               // SBT record of the instance, :108
+
+        const float t = hit.x;                                // optixGetRayTmax :111
+        const V3 rayOrigin = mk3(ray.o.x, ray.o.y, ray.o.z), rayDirection = mk3(ray.d.x, ray.d.y, ray.d.z);
+        const V3 hitPoint = add3(rayOrigin, muls3(rayDirection, t));      // :114
+        const uint32_t primitiveIndex = __float_as_uint(hit.w);           // :117
+
+        V3 normalVector;
+        if (kSphere) {                                                    // :122-136
+            const float *cp = reinterpret_cast<const float *>(hg.ptr0) + 3 * (size_t)primitiveIndex;
+            const V3 sphereCenter = mk3(cp[0], cp[1], cp[2]);
+            const float sphereRadius = reinterpret_cast<const float *>(hg.ptr1)[primitiveIndex];
+            const V3 outwardNormal = divs3(sub3(hitPoint, sphereCenter), sphereRadius);
+            const bool hitFrontFace = dot3(rayDirection, outwardNormal) < 0.0f;
+            normalVector = hitFrontFace ? outwardNormal : neg3(outwardNormal);
+        } else {                                                          // :137-155
+            const float *np = reinterpret_cast<const float *>(hg.ptr0) + 9 * (size_t)primitiveIndex;
+            const V3 n1 = mk3(np[0], np[1], np[2]), n2 = mk3(np[3], np[4], np[5]), n3 = mk3(np[6], np[7], np[8]);
+            const float u = hit.y, v = hit.z;
+            const float w = 1.0f - u - v;
+            const V3 _normal = add3(add3(muls3(n1, w), muls3(n2, u)), muls3(n3, v));
+            const bool hitFrontFace = dot3(rayDirection, _normal) < 0.0f;
+            normalVector = hitFrontFace ? _normal : neg3(_normal);
+        }
+
+        V3 reflectDirection;
+        RngState *state = a.states + tid;                                  // params.stateArray + tid
+        if (kRough) {                                                     // :169-179
+            Xorwow rng = rng_load(state);
+            reflectDirection = add3(normalVector, random_space_vector(rng));
+            rng_store(state, rng);
+            if (fabsf(len2_3(reflectDirection) - kFloatZero * kFloatZero) < kFloatZero) reflectDirection = normalVector;
+        } else {                                                          // :180-192
+            const V3 v = rayDirection, nn = normalVector;
+            reflectDirection = normalize3(sub3(v, muls3(nn, 2.0f * dot3(v, nn))));
+            if (hg.fuzz > 0.0f) {
+                Xorwow rng = rng_load(state);
+                reflectDirection = add3(reflectDirection, muls3(random_space_vector(rng), hg.fuzz));
+                rng_store(state, rng);
+            }
+        }
+        // :202-213
+        if (!finite3(reflectDirection) || len2_3(reflectDirection) <= kFloatZero * kFloatZero) {
+            reflectDirection = normalVector;
+            if (len2_3(reflectDirection) <= kFloatZero * kFloatZero || !finite3(reflectDirection))
+                reflectDirection = mk3(0.0f, 0.0f, 1.0f);
+        }
+        // the depth-1 AOV write (:216-227) is overwritten by the terminating program (quirk Q3): nothing to store
+
+        a.chain[(size_t)local * 4 + (a.depth - 1u)] = inst;               // albedo applied on the way back, :236-238
+        RayRec nr;                                                        // recursive rayTrace, :230-233
+        nr.o = make_float4(hitPoint.x, hitPoint.y, hitPoint.z, ray.o.w);
+        nr.d = make_float4(reflectDirection.x, reflectDirection.y, reflectDirection.z, ray.d.w);
+        a.rays_out[out_base + q] = nr;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// accumulate: paths that end at this depth.  __miss__ (Shader.cu:276-287) or the depth
+// cut-off (:102-107), then the albedo products of the unwinding recursion (:236-238),
+// innermost bounce first.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_accumulate(AccumArgs a) {
+    const uint32_t n = a.bin_count[0];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) {
+        const uint32_t i = a.bin_items[q];
+        const uint32_t local = __float_as_uint(a.rays_in[i].o.w);
+        const bool miss = a.hit_inst[i] == kMissPrim;
+        float rx = miss ? a.bg[0] : 0.0f, ry = miss ? a.bg[1] : 0.0f, rz = miss ? a.bg[2] : 0.0f;
+        const uint4 ch = reinterpret_cast<const uint4 *>(a.chain)[local];
+        const uint32_t chain[4] = {ch.x, ch.y, ch.z, ch.w};
+        for (int k = (int)a.depth - 2; k >= 0; --k) {
+            const HitGroup hg = a.hitgroups[chain[k]];
+            rx *= hg.albedo[0]; ry *= hg.albedo[1]; rz *= hg.albedo[2];
+        }
+        float4 acc;
+        if (a.first_sample) acc = make_float4(rx, ry, rz, 0.0f);
+        else { acc = a.accum[local]; acc.x += rx; acc.y += ry; acc.z += rz; }
+        a.accum[local] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// finalize: colorToFloat4(mean) and the (always zero, quirk Q3) AOVs, Shader.cu:270-272
+// ---------------------------------------------------------------------------------------
+// x^(1/2.4f) evaluated in double with +,-,*,/ only (no libm, no contraction), rounded to float
+// once: the same bits on every platform.  Replaces powf of DeviceFunctions.cuh:196-198.
+__device__ __forceinline__ float pow_inv_gamma(float xf) {
+    if (!(xf > 0.0f)) return 0.0f;
+    const double y = (double)(1.0f / 2.4f);
+    double x = (double)xf;
+    // x = m * 2^e with m in [sqrt(1/2), sqrt(2))
+    long long bits = __double_as_longlong(x);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    bits = (bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL;
+    double m = __longlong_as_double(bits);
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+    // ln(m) = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716
+    const double s = (m - 1.0) / (m + 1.0);
+    const double s2 = s * s;
+    double p = 1.0 / 27.0;
+    p = p * s2 + 1.0 / 25.0; p = p * s2 + 1.0 / 23.0; p = p * s2 + 1.0 / 21.0; p = p * s2 + 1.0 / 19.0;
+    p = p * s2 + 1.0 / 17.0; p = p * s2 + 1.0 / 15.0; p = p * s2 + 1.0 / 13.0; p = p * s2 + 1.0 / 11.0;
+    p = p * s2 + 1.0 / 9.0;  p = p * s2 + 1.0 / 7.0;  p = p * s2 + 1.0 / 5.0;  p = p * s2 + 1.0 / 3.0;
+    p = p * s2 + 1.0;
+    const double ln_m = 2.0 * s * p;
+    const double log2x = (double)e + ln_m * 1.4426950408889634;
+    const double z = y * log2x;                           // <= 0
+    const double zr = z < 0.0 ? (double)(long long)(z - 0.5) : (double)(long long)(z + 0.5);
+    const double f = (z - zr) * 0.6931471805599453;       // |f| <= 0.347
+    double q = 1.0 / 6227020800.0;                        // 1/13!
+    q = q * f + 1.0 / 479001600.0; q = q * f + 1.0 / 39916800.0; q = q * f + 1.0 / 3628800.0;
+    q = q * f + 1.0 / 362880.0;    q = q * f + 1.0 / 40320.0;    q = q * f + 1.0 / 5040.0;
+    q = q * f + 1.0 / 720.0;       q = q * f + 1.0 / 120.0;      q = q * f + 1.0 / 24.0;
+    q = q * f + 1.0 / 6.0;         q = q * f + 0.5;              q = q * f + 1.0;
+    q = q * f + 1.0;
+    const long long eb = (long long)((int)zr + 1023) << 52;
+    const double r = q * __longlong_as_double(eb);
+    return (float)r;
+}
+__device__ __forceinline__ float srgb_channel(float c) {
+    const float cx = fmaxf(0.0f, fminf(c, 1.0f));
+    const float px = pow_inv_gamma(cx);
+    const float sx = cx < 0.0031308f ? 12.92f * cx : 1.055f * px - 0.055f;
+    return fmaxf(0.0f, fminf(sx, 1.0f));
+}
+
+__global__ __launch_bounds__(256) void k_finalize(FinalizeArgs a) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.n_tile_pixels) return;
+    const uint32_t row = j / a.width;
+    const uint32_t ix = j - row * a.width;
+    const uint32_t p = a.rows[row] * a.width + ix;
+    float4 acc = a.accum[j];
+    if (a.spp > 1u) { const float n = (float)a.spp; acc.x /= n; acc.y /= n; acc.z /= n; }
+    if (a.linear) a.linear[p] = make_float4(acc.x, acc.y, acc.z, 1.0f);
+    a.color[p] = make_float4(srgb_channel(acc.x), srgb_channel(acc.y), srgb_channel(acc.z), 1.0f);
+    if (a.albedo) a.albedo[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (a.normal) a.normal[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// convertFloat4ToUchar4Kernel, src/Global/RendererImpl.cu:672-678 (colorToUchar4, DeviceFunctions.cuh:153-183)
+__global__ __launch_bounds__(256) void k_to_rgba8(const float4 *src, uchar4 *dst, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = src[i];
+    const float s[3] = {srgb_channel(c.x), srgb_channel(c.y), srgb_channel(c.z)};
+    uchar4 o;
+    uint32_t q;
+    q = (uint32_t)(s[0] * 256.0f); o.x = (unsigned char)(q < 255u ? q : 255u);
+    q = (uint32_t)(s[1] * 256.0f); o.y = (unsigned char)(q < 255u ? q : 255u);
+    q = (uint32_t)(s[2] * 256.0f); o.z = (unsigned char)(q < 255u ? q : 255u);
+    o.w = 255u;
+    dst[i] = o;
+}
+
+// ---------------------------------------------------------------------------------------
+// helpers for hrt_trace_rays (parity tests run the production traverse kernel on their own rays)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_rays(const float *o, const float *d, uint32_t n, RayRec *rays) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    RayRec r;
+    r.o = make_float4(o[3 * (size_t)i], o[3 * (size_t)i + 1], o[3 * (size_t)i + 2], __uint_as_float(i));
+    r.d = make_float4(d[3 * (size_t)i], d[3 * (size_t)i + 1], d[3 * (size_t)i + 2], __uint_as_float(i));
+    rays[i] = r;
+}
+__global__ __launch_bounds__(256) void k_unpack_hits(const float4 *tuvp, const uint32_t *inst, uint32_t n,
+                                                     float *t, float *u, float *v, uint32_t *prim, uint32_t *oinst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 h = tuvp[i];
+    t[i] = h.x; u[i] = h.y; v[i] = h.z; prim[i] = __float_as_uint(h.w); oinst[i] = inst[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------
+static inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+void launch_rng_init(RngState *states, uint32_t n, uint64_t salt, const uint32_t *d_jump, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_rng_init, dim3(ceil_div(n, 256)), dim3(256), 0, s, states, n, salt, d_jump);
+}
+void launch_generate(const GenerateArgs &a, hipStream_t s) {
+    if (a.n_tile_pixels) hipLaunchKernelGGL(k_generate, dim3(ceil_div(a.n_tile_pixels, 256)), dim3(256), 0, s, a);
+}
+void launch_traverse(const TraverseArgs &a, bool any_hit, bool count, bool has_spheres, uint32_t grid_blocks, hipStream_t s) {
+    const dim3 g(grid_blocks), b(kTraverseBlock);
+    const int sel = (any_hit ? 4 : 0) | (count ? 2 : 0) | (has_spheres ? 1 : 0);
+    switch (sel) {
+        case 0: hipLaunchKernelGGL((k_traverse<false, false, false>), g, b, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((k_traverse<false, false, true>), g, b, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_traverse<false, true, false>), g, b, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((k_traverse<false, true, true>), g, b, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((k_traverse<true, false, false>), g, b, 0, s, a); break;
+        case 5: hipLaunchKernelGGL((k_traverse<true, false, true>), g, b, 0, s, a); break;
+        case 6: hipLaunchKernelGGL((k_traverse<true, true, false>), g, b, 0, s, a); break;
+        default: hipLaunchKernelGGL((k_traverse<true, true, true>), g, b, 0, s, a); break;
+    }
+}
+void launch_bin(const BinArgs &a, uint32_t grid_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_bin_hits, dim3(grid_blocks), dim3(256), 0, s, a);
+}
+void launch_shade(const ShadeArgs &a, int program, uint32_t grid_blocks, hipStream_t s) {
+    const dim3 g(grid_blocks), b(256);
+    switch (program) {
+        case 0: hipLaunchKernelGGL((k_shade<0>), g, b, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((k_shade<1>), g, b, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_shade<2>), g, b, 0, s, a); break;
+        default: hipLaunchKernelGGL((k_shade<3>), g, b, 0, s, a); break;
+    }
+}
+void launch_accumulate(const AccumArgs &a, uint32_t grid_blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_blocks), dim3(256), 0, s, a);
+}
+void launch_finalize(const FinalizeArgs &a, hipStream_t s) {
+    if (a.n_tile_pixels) hipLaunchKernelGGL(k_finalize, dim3(ceil_div(a.n_tile_pixels, 256)), dim3(256), 0, s, a);
+}
+void launch_to_rgba8(const float4 *src, uchar4 *dst, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_to_rgba8, dim3(ceil_div(n, 256)), dim3(256), 0, s, src, dst, n);
+}
+void launch_pack_rays(const float *o, const float *d, uint32_t n, RayRec *rays, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_pack_rays, dim3(ceil_div(n, 256)), dim3(256), 0, s, o, d, n, rays);
+}
+void launch_unpack_hits(const float4 *tuvp, const uint32_t *inst, uint32_t n, float *t, float *u, float *v,
+                        uint32_t *prim, uint32_t *oinst, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_unpack_hits, dim3(ceil_div(n, 256)), dim3(256), 0, s, tuvp, inst, n, t, u, v, prim, oinst);
+}
+
+}  // namespace hrt

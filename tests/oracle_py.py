@@ -1,0 +1,185 @@
+"""ctypes wrapper around oracle/liboracle.so -- TEST INFRASTRUCTURE (see oracle/oracle.c header).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+LIB = ROOT / "oracle" / "liboracle.so"
+
+
+class OracleInstance(C.Structure):
+    _fields_ = [("transform", C.c_float * 12), ("geometry", C.c_int32), ("material", C.c_int32),
+                ("albedo", C.c_float * 3), ("fuzz", C.c_float), ("n_prims", C.c_uint32),
+                ("vertices", C.c_void_p), ("normals", C.c_void_p), ("centers", C.c_void_p), ("radii", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB.exists():
+        subprocess.check_call(["make", "-C", str(ROOT / "oracle")])
+    L = C.CDLL(str(LIB))
+    L.oracle_scene_create.restype = C.c_void_p
+    L.oracle_scene_create.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.oracle_scene_destroy.argtypes = [C.c_void_p]
+    L.oracle_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_bvh8_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                    C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]
+    L.oracle_rng_init.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+    L.oracle_rng_init_one.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+    L.oracle_rng_init_generic.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.oracle_rng_uniform.restype = C.c_float
+    L.oracle_rng_uniform.argtypes = [C.c_void_p]
+    L.oracle_rng_next.restype = C.c_uint32
+    L.oracle_rng_next.argtypes = [C.c_void_p]
+    L.oracle_color_to_float4.argtypes = [C.c_void_p, C.c_void_p]
+    L.oracle_color_to_uchar4.argtypes = [C.c_void_p, C.c_void_p]
+    L.oracle_to_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    L.oracle_configure_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_num_threads.restype = C.c_int
+    L.oracle_set_threads.argtypes = [C.c_int]
+    L.oracle_init()
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data if a is not None else None
+
+
+class OracleScene:
+    """Oracle-side scene built from the same dict the product's Renderer.load_scene takes."""
+
+    def __init__(self, scene, force_brute=False):
+        L = lib()
+        insts = scene["instances"]
+        self._keep = []
+        arr = (OracleInstance * max(len(insts), 1))()
+        for i, it in enumerate(insts):
+            for k in range(12):
+                arr[i].transform[k] = float(it["transform"][k])
+            arr[i].material = 0 if it["material"] == "rough" else 1
+            for k in range(3):
+                arr[i].albedo[k] = float(it["albedo"][k])
+            arr[i].fuzz = float(it["fuzz"]) if it["material"] == "metal" else 0.0
+            if it["geometry"] == "triangles":
+                v = np.ascontiguousarray(it["vertices"], dtype=np.float32)
+                n = np.ascontiguousarray(it["normals"], dtype=np.float32)
+                self._keep += [v, n]
+                arr[i].geometry = 1
+                arr[i].n_prims = v.shape[0]
+                arr[i].vertices = v.ctypes.data
+                arr[i].normals = n.ctypes.data
+            else:
+                c = np.ascontiguousarray(it["centers"], dtype=np.float32)
+                r = np.ascontiguousarray(it["radii"], dtype=np.float32)
+                self._keep += [c, r]
+                arr[i].geometry = 0
+                arr[i].n_prims = r.shape[0]
+                arr[i].centers = c.ctypes.data
+                arr[i].radii = r.ctypes.data
+        self._arr = arr
+        self.scene = scene
+        self.handle = C.c_void_p(L.oracle_scene_create(arr, len(insts), int(force_brute)))
+
+    def camera12(self):
+        L = lib()
+        cam = self.scene["camera"]
+        c = np.ascontiguousarray(cam["center"], dtype=np.float32)
+        t = np.ascontiguousarray(cam["target"], dtype=np.float32)
+        up = np.ascontiguousarray(cam["up"], dtype=np.float32)
+        out = np.zeros(12, dtype=np.float32)
+        out[0:3] = c
+        u, v, w = out[3:6], out[6:9], out[9:12]
+        uu, vv, ww = np.zeros(3, np.float32), np.zeros(3, np.float32), np.zeros(3, np.float32)
+        L.oracle_configure_camera(_p(c), _p(t), _p(up), int(cam.get("opengl", True)), _p(uu), _p(vv), _p(ww))
+        u[:], v[:], w[:] = uu, vv, ww
+        return out
+
+    def render(self, width, height, states, spp=1, rows=None, want_linear=True):
+        """states: (H*W, 12) uint32, updated in place.  Returns dict of (H,W,4) float32 arrays + counters."""
+        L = lib()
+        cam = self.camera12()
+        bg = np.ascontiguousarray(self.scene["background"], dtype=np.float32)
+        color = np.zeros((height, width, 4), np.float32)
+        albedo = np.full((height, width, 4), 7.0, np.float32)
+        normal = np.full((height, width, 4), 7.0, np.float32)
+        linear = np.zeros((height, width, 4), np.float32) if want_linear else None
+        cnt = np.zeros(3, np.uint64)
+        rows_a = None if rows is None else np.ascontiguousarray(rows, dtype=np.uint32)
+        L.oracle_render(self.handle, _p(cam), width, height, _p(states), _p(bg), spp,
+                        _p(rows_a), 0 if rows_a is None else rows_a.shape[0],
+                        _p(color), _p(albedo), _p(normal), _p(linear), _p(cnt))
+        return {"color": color, "albedo": albedo, "normal": normal, "linear": linear,
+                "rays": int(cnt[0]), "node_visits": int(cnt[1]), "prim_tests": int(cnt[2])}
+
+    def trace(self, origins, directions, tmin=1e-6, tmax=1e16, any_hit=False):
+        L = lib()
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        t, u, v = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        prim, inst = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        L.oracle_trace_rays(self.handle, _p(o), _p(d), n, tmin, tmax, int(any_hit), _p(t), _p(u), _p(v), _p(prim), _p(inst))
+        return t, u, v, prim, inst
+
+    def close(self):
+        if self.handle:
+            lib().oracle_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def rng_init(width, height, salt):
+    st = np.zeros((width * height, 12), dtype=np.uint32)
+    lib().oracle_rng_init(_p(st), width, height, salt)
+    return st
+
+
+def bvh8_trace(nodes_ptr, prims_ptr, origins, directions, tmin=1e-6, tmax=1e16, any_hit=False,
+               inst_inv=None, inst_identity=None):
+    """Walk a packed BVH8 blob of the product on the CPU.  Returns (t,u,v,prim,inst, node_visits, prim_tests)."""
+    L = lib()
+    o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+    n = o.shape[0]
+    t, u, v = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    prim, inst = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    cnt = np.zeros(2, np.uint64)
+    L.oracle_bvh8_trace(nodes_ptr, prims_ptr, _p(inst_inv), _p(inst_identity), _p(o), _p(d), n, tmin, tmax, int(any_hit),
+                        _p(t), _p(u), _p(v), _p(prim), _p(inst), _p(cnt))
+    return t, u, v, prim, inst, int(cnt[0]), int(cnt[1])
+
+
+def random_rays(n, seed, scale=1.6):
+    """Deterministic test rays: origins in a cube around the scenes, directions pointing roughly inwards."""
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-scale, scale, size=(n, 3)).astype(np.float32)
+    tgt = rng.uniform(-0.8, 0.8, size=(n, 3)).astype(np.float32)
+    d = (tgt - o).astype(np.float32)
+    # a few axis-parallel / zero-component directions: the slab test's edge cases
+    k = max(1, n // 50)
+    d[:k, 0] = 0.0
+    d[k:2 * k, 1] = 0.0
+    d[2 * k:3 * k, 1:] = 0.0
+    return o, d
