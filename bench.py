@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the render launch on the synthetic 1M-triangle scene at 1920x1080.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N > 1 under torch.distributed.run)
+One "step" = one hrt_render_launch of the whole frame at the configured spp (BASELINE config C4:
+1M random triangles, 1920x1080, 256 spp), scene/BVH/RNG states already resident in HBM.  For N > 1
+the frame is split into interleaved 8-row stripes (one tile per GPU, BVH replicated) and each step
+ends with the RCCL reduce of the per-tile radiance into rank 0's frame.
+
+Prints ONE JSON line on rank 0 with the metric, a `roofline` object for the dominant kernel
+(closest-hit traversal; algorithmic bytes per ray x rays / HIP-event time) and a `cpu_baseline`
+object (the CPU oracle, OpenMP, on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+RAY_BYTES, HIT_BYTES, NODE_BYTES, PRIM_BYTES = 32, 20, 80, 48      # DESIGN.md "algorithmic bytes"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C4", choices=["C1", "C2", "C3", "C4", "C5"])
+    ap.add_argument("--spp", type=int, default=0, help="override the config's samples per pixel")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(hrt, scene, target_seconds):
+    """The CPU oracle (kind "port": the reference has no CPU path to build) on a bounded sample
+    of the same workload: every k-th row of the 1080p frame at 1 spp, all host threads."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_py
+    W, H = scene["width"], scene["height"]
+    threads = oracle_py.lib().oracle_num_threads()
+    osc = oracle_py.OracleScene(scene)
+    states = oracle_py.rng_init(W, H, hrt.scenes.SEED_SALT)
+    probe_rows = np.arange(4, H, 64, dtype=np.uint32)                    # ~17 rows: calibrate
+    t0 = time.perf_counter()
+    r = osc.render(W, H, states, 1, rows=probe_rows, want_linear=False)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    rate = r["rays"] / dt
+    rows_target = int(np.clip(target_seconds * rate / (r["rays"] / len(probe_rows)), 16, H))
+    step = max(1, H // rows_target)
+    rows = np.arange(0, H, step, dtype=np.uint32)
+    t0 = time.perf_counter()
+    r = osc.render(W, H, states, 1, rows=rows, want_linear=False)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    osc.close()
+    return {"value": round(r["rays"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": int(threads), "kind": "port",
+            "sample": f"{len(rows)} of {H} rows (every {step}th) x {W} px, 1 spp, {r['rays']} rays in {dt:.1f} s, "
+                      f"oracle/oracle.c OpenMP x{threads}"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    hrt = importlib.import_module("nvidia-optix-ray-tracer_amd")
+    scene = hrt.scenes.BASELINE_CONFIGS[args.config]()
+    if args.spp > 0:
+        scene["spp"] = args.spp
+    W, H, spp = scene["width"], scene["height"], scene["spp"]
+
+    r = hrt.Renderer(local_rank, hrt.CTX_TIMING)
+    t0 = time.perf_counter()
+    r.load_scene(scene)
+    build_s = time.perf_counter() - t0
+    r.set_frame(W, H, hrt.scenes.SEED_SALT, aov=False)
+    tile = hrt.tile_for_rank(H, rank, world) if world > 1 else None
+
+    def step():
+        r.render(spp, tile=tile, sync=False)
+        if world > 1:
+            dist.reduce(r.color, dst=0, op=dist.ReduceOp.SUM)     # per-tile radiance -> rank 0 (x + 0 is exact)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        if world > 1:
+            r.color.zero_()
+        step()
+    fence()
+    r.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if world > 1 and rank != 0:
+            pass
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    st = r.stats()
+
+    # max over ranks of the time, sum over ranks of the rays
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rays = torch.tensor([float(st.rays), float(st.rays_closest), st.kernel_ms[hrt.K_TRAVERSE],
+                         float(st.kernel_launches[hrt.K_TRAVERSE])], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    elapsed = float(tt.item())
+    total_rays = float(rays[0].item())
+
+    # ---- per-ray node / primitive counts of the closest-hit kernel: one extra untimed sample pass ----
+    r.set_flags(hrt.CTX_COUNT)
+    r.reset_stats()
+    r.render(1, tile=tile, sync=True)
+    sc = r.stats()
+    nodes_per_ray = sc.node_visits_closest / max(sc.rays_closest, 1)
+    prims_per_ray = sc.prim_tests_closest / max(sc.rays_closest, 1)
+    bytes_per_ray = RAY_BYTES + NODE_BYTES * nodes_per_ray + PRIM_BYTES * prims_per_ray + HIT_BYTES
+
+    if rank == 0:
+        trav_ms = st.kernel_ms[hrt.K_TRAVERSE]
+        trav_launches = max(int(st.kernel_launches[hrt.K_TRAVERSE]), 1)
+        avg_launch_ms = trav_ms / trav_launches
+        rays_per_launch = st.rays_closest / trav_launches
+        achieved = bytes_per_ray * rays_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        traffic = None
+        tf = ROOT / "profiles" / "traverse_traffic.json"
+        if tf.exists():
+            try:
+                traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s at 1920x1080, 1M-tri scene",
+            "value": round(total_rays / elapsed / 1e6, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{scene['name']}: {sum(len(i.get('vertices', ())) for i in scene['instances'])} triangles, "
+                                   f"{W}x{H}, {spp} spp, depth {5}, tile-split x{world} (8-row stripes, BVH replicated)",
+                       "rays_per_step": int(total_rays / max(args.steps, 1)), "rays_per_path": round(st.rays / max(st.paths, 1), 4),
+                       "bvh_nodes": int(st.bvh_nodes), "bvh_bytes": int(st.bvh_bytes), "bvh_build_s": round(build_s, 2)},
+            "roofline": {"bound": "hbm", "kernel": "k_traverse (closest hit)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 3),
+                         "prims_per_ray": round(prims_per_ray, 3), "avg_launch_ms": round(avg_launch_ms, 4),
+                         "rays_per_launch": round(rays_per_launch, 1), "launches": trav_launches},
+            "kernel_ms": {hrt.KERNEL_NAMES[k]: round(st.kernel_ms[k], 3) for k in range(hrt.K_COUNT)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(hrt, scene, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

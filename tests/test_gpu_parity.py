@@ -201,7 +201,7 @@ def test_empty_scene_and_all_miss(hrt, oracle, renderer):
     ref, _ = _render_both(hrt, oracle, renderer, scene, 40, 30, 1)
     _check_image(renderer, ref)
     assert ref["rays"] == 40 * 30
-    bg = np.array([0x1.b56792p-1, 0x1.d00ab6p-1, 0x1.e8ccbep-1], dtype=np.float32)   # SURVEY.md 8(c) probe of the reference
+    bg = np.array([float.fromhex(x) for x in ("0x1.b56792p-1", "0x1.d00ab6p-1", "0x1.e8ccbep-1")], dtype=np.float32)   # SURVEY.md 8(c) probe of the reference
     assert np.abs(renderer.color.cpu().numpy()[..., :3] - bg).max() <= 1e-6
 
 
