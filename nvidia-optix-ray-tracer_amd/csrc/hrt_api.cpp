@@ -45,8 +45,9 @@ struct Tlas {
     uint64_t generation = 0;
 };
 
-struct StageCounters { uint32_t bin_count[8]; uint32_t fetch; uint32_t pad[7]; };   // 64 B
-static_assert(sizeof(StageCounters) == 64, "stage counters are one 64-byte line");
+// per-depth counters, zeroed once per sample: bin sizes + 8 slice counters on 128-byte lines of their own
+struct StageCounters { uint32_t bin_count[32]; uint32_t fetch[8 * 32]; };
+static_assert(sizeof(StageCounters) == 128 + 8 * 128, "stage counters layout");
 
 struct DeviceStats { uint64_t rays_closest, rays_any, nodes_closest, prims_closest, nodes_any, prims_any; };
 
@@ -600,7 +601,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
             const uint32_t *n_ptr = depth == 1 ? nullptr : &w.stages[depth - 1].bin_count[1];
             TraverseArgs ta{};
             ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.rays = w.rays[cur];
-            ta.n_rays_ptr = n_ptr; ta.n_rays = n; ta.fetch_counter = &w.stages[depth].fetch;
+            ta.n_rays_ptr = n_ptr; ta.n_rays = n; ta.fetch_counter = w.stages[depth].fetch;
             ta.hit_tuvp = w.hit_tuvp; ta.hit_inst = w.hit_inst;
             ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
             ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;      // Shader.cu:232, :266
@@ -710,8 +711,8 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
     HIP_TRY(ctx, hipMalloc((void **)&rays, sizeof(RayRec) * (size_t)n_rays));
     HIP_TRY(ctx, hipMalloc((void **)&tuvp, sizeof(float4) * (size_t)n_rays));
     HIP_TRY(ctx, hipMalloc((void **)&inst, sizeof(uint32_t) * (size_t)n_rays));
-    HIP_TRY(ctx, hipMalloc((void **)&fetch, sizeof(uint32_t)));
-    HIP_TRY(ctx, hipMemsetAsync(fetch, 0, sizeof(uint32_t), s));
+    HIP_TRY(ctx, hipMalloc((void **)&fetch, sizeof(uint32_t) * 8 * 32));
+    HIP_TRY(ctx, hipMemsetAsync(fetch, 0, sizeof(uint32_t) * 8 * 32, s));
     launch_pack_rays(reinterpret_cast<const float *>(d_origins), reinterpret_cast<const float *>(d_directions), n_rays, rays, s);
     TraverseArgs ta{};
     ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.rays = rays; ta.n_rays_ptr = nullptr; ta.n_rays = n_rays;

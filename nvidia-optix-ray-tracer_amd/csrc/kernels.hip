@@ -143,6 +143,9 @@ __global__ __launch_bounds__(256) void k_generate(GenerateArgs a) {
 constexpr int kLdsStack = 8;          // entries per lane staged in LDS
 constexpr int kSpillStack = 40;       // overflow entries per lane in scratch
 constexpr int kTraverseBlock = 256;
+constexpr uint32_t kFetchChunk = 128;        // rays per slice handed to a wave
+constexpr uint32_t kFetchShards = 8;         // slice counters (one per XCD-group of blocks)
+constexpr uint32_t kFetchShardStride = 32;   // u32s between counters: one 128-byte line each
 
 struct TravState {
     float ox, oy, oz, dx, dy, dz;
@@ -242,30 +245,51 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     bool exhausted = false;                 // wave-uniform
     uint32_t cnt_nodes = 0, cnt_prims = 0;
 
+    // wave-local slice of the queue: [wbeg, wend).  Slices of kFetchChunk rays are handed out by
+    // kFetchShards counters (chunk c of shard s covers rays (c * kFetchShards + s) * kFetchChunk ...),
+    // so one launch costs n_rays / kFetchChunk atomics spread over 8 addresses instead of one
+    // atomic per refill on a single word (measured: the single word capped the kernel).
+    uint32_t wbeg = 0, wend = 0;
+    const uint32_t home = blockIdx.x & (kFetchShards - 1);
+    uint32_t kstart = 0;
+
     for (;;) {
-        // ---- refill idle lanes from the global queue (one atomic per wave) ----
+        // ---- refill idle lanes from the wave's slice ----
         const uint64_t idle = __ballot(!alive);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         if (!exhausted && (n_idle >= (uint32_t)a.refill_threshold || idle == ~0ull)) {
-            uint32_t base = 0;
-            if (lane_prefix(idle) == 0 && !alive) base = atomicAdd(a.fetch_counter, n_idle);
-            // broadcast from the first idle lane
-            const int src = __ffsll((long long)idle) - 1;
-            base = (uint32_t)__shfl((int)base, src);
-            if (base + n_idle >= n_rays) exhausted = true;
-            const uint32_t mine = base + lane_prefix(idle);
-            if (!alive && mine < n_rays) {
-                const RayRec r = a.rays[mine];
-                s.ox = r.o.x; s.oy = r.o.y; s.oz = r.o.z;
-                s.dx = r.d.x; s.dy = r.d.y; s.dz = r.d.z;
-                s.idx = safe_rcp_dir(s.dx); s.idy = safe_rcp_dir(s.dy); s.idz = safe_rcp_dir(s.dz);
-                const uint32_t oct = (s.dx < 0.0f ? 4u : 0u) | (s.dy < 0.0f ? 2u : 0u) | (s.dz < 0.0f ? 1u : 0u);
-                s.oct_inv4 = (7u - oct) * 0x01010101u;
-                s.bt = tmax_ray; s.bu = 0.0f; s.bv = 0.0f; s.bprim = kMissPrim; s.binst = kMissPrim;
-                s.cur = make_uint2(0u, 0x80000000u);
-                s.sp = 0;
-                s.slot = mine;
-                alive = true;
+            if (wbeg >= wend) {
+                for (uint32_t k = kstart; k < kFetchShards && wbeg >= wend; ++k) {
+                    const uint32_t shard = (home + k) & (kFetchShards - 1);
+                    uint32_t c = 0;
+                    if ((tx & 63u) == 0u) c = atomicAdd(a.fetch_counter + shard * kFetchShardStride, 1u);
+                    c = (uint32_t)__shfl((int)c, 0);
+                    const uint64_t beg = ((uint64_t)c * kFetchShards + shard) * kFetchChunk;
+                    if (beg < (uint64_t)n_rays) {
+                        wbeg = (uint32_t)beg;
+                        wend = (uint32_t)(beg + kFetchChunk < (uint64_t)n_rays ? beg + kFetchChunk : (uint64_t)n_rays);
+                    } else kstart = k + 1;             // this shard is drained for good
+                }
+                if (wbeg >= wend) exhausted = true;
+            }
+            if (!exhausted) {
+                const uint32_t take = n_idle < wend - wbeg ? n_idle : wend - wbeg;
+                const uint32_t rank = lane_prefix(idle);
+                const uint32_t mine = wbeg + rank;
+                wbeg += take;
+                if (!alive && rank < take) {
+                    const RayRec r = a.rays[mine];
+                    s.ox = r.o.x; s.oy = r.o.y; s.oz = r.o.z;
+                    s.dx = r.d.x; s.dy = r.d.y; s.dz = r.d.z;
+                    s.idx = safe_rcp_dir(s.dx); s.idy = safe_rcp_dir(s.dy); s.idz = safe_rcp_dir(s.dz);
+                    const uint32_t oct = (s.dx < 0.0f ? 4u : 0u) | (s.dy < 0.0f ? 2u : 0u) | (s.dz < 0.0f ? 1u : 0u);
+                    s.oct_inv4 = (7u - oct) * 0x01010101u;
+                    s.bt = tmax_ray; s.bu = 0.0f; s.bv = 0.0f; s.bprim = kMissPrim; s.binst = kMissPrim;
+                    s.cur = make_uint2(0u, 0x80000000u);
+                    s.sp = 0;
+                    s.slot = mine;
+                    alive = true;
+                }
             }
         }
         if (__ballot(alive) == 0ull) break;     // queue drained and every lane finished
@@ -372,26 +396,69 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
 // bin 0 = path ends here (miss, or any hit at depth >= rayTraceDepth), bin 1+P = program P.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bin_hits(BinArgs a) {
+    // Each block owns one contiguous slice of the queue: pass 1 counts its rays per bin (wave
+    // ballots), ONE atomic per bin per block reserves the output ranges, pass 2 writes the ray
+    // indices with ballot prefix counts.  (One atomic per wave on a single word serialised at
+    // ~88 atomics/us and cost 0.45 ms per launch.)
+    __shared__ uint32_t s_wave_cnt[4][kNumBins];
+    __shared__ uint32_t s_base[kNumBins];
     const uint32_t n = a.n_rays_ptr ? (a.n_rays_ptr[0] + a.n_rays_ptr[1] + a.n_rays_ptr[2] + a.n_rays_ptr[3]) : a.n_rays;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0)
         atomicAdd(reinterpret_cast<unsigned long long *>(a.total_rays), (unsigned long long)n);
+    const uint32_t per_block = ((n + gridDim.x - 1) / gridDim.x + 255u) & ~255u;
+    const uint64_t begin64 = (uint64_t)blockIdx.x * per_block;
+    if (begin64 >= n) return;
+    const uint32_t begin = (uint32_t)begin64;
+    const uint32_t end = begin + per_block < n ? begin + per_block : n;
+    const uint32_t wave = threadIdx.x >> 6;
+
+    auto bin_of = [&](uint32_t i) -> uint32_t {
+        if (i >= end) return 0xffu;
+        const uint32_t inst = a.hit_inst[i];
+        return (inst == kMissPrim || a.depth >= kRayTraceDepth) ? 0u : 1u + a.inst_program[inst];
+    };
+
+    uint32_t cnt[kNumBins];
+#pragma unroll
+    for (uint32_t b = 0; b < kNumBins; ++b) cnt[b] = 0;
+    for (uint32_t base = begin; base < end; base += 256u) {
+        const uint32_t bin = bin_of(base + threadIdx.x);
+#pragma unroll
+        for (uint32_t b = 0; b < kNumBins; ++b) cnt[b] += (uint32_t)__popcll(__ballot(bin == b));
     }
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += stride) {
+    if ((threadIdx.x & 63u) == 0u) {
+#pragma unroll
+        for (uint32_t b = 0; b < kNumBins; ++b) s_wave_cnt[wave][b] = cnt[b];
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumBins) {
+        const uint32_t tot = s_wave_cnt[0][threadIdx.x] + s_wave_cnt[1][threadIdx.x] + s_wave_cnt[2][threadIdx.x] + s_wave_cnt[3][threadIdx.x];
+        s_base[threadIdx.x] = tot ? atomicAdd(&a.bin_count[threadIdx.x], tot) : 0u;
+    }
+    __syncthreads();
+    // running write offsets, per bin: block base + everything earlier waves / earlier chunks wrote
+    uint32_t run[kNumBins];
+#pragma unroll
+    for (uint32_t b = 0; b < kNumBins; ++b) run[b] = s_base[b];
+    for (uint32_t base = begin; base < end; base += 256u) {
         const uint32_t i = base + threadIdx.x;
-        uint32_t bin = 0xffu;
-        if (i < n) {
-            const uint32_t inst = a.hit_inst[i];
-            bin = (inst == kMissPrim || a.depth >= kRayTraceDepth) ? 0u : 1u + a.inst_program[inst];
+        const uint32_t bin = bin_of(i);
+        uint64_t m[kNumBins];
+#pragma unroll
+        for (uint32_t b = 0; b < kNumBins; ++b) m[b] = __ballot(bin == b);
+        __syncthreads();                       // previous chunk's s_wave_cnt fully consumed
+        if ((threadIdx.x & 63u) == 0u) {
+#pragma unroll
+            for (uint32_t b = 0; b < kNumBins; ++b) s_wave_cnt[wave][b] = (uint32_t)__popcll(m[b]);
         }
+        __syncthreads();
 #pragma unroll
         for (uint32_t b = 0; b < kNumBins; ++b) {
-            const uint64_t m = __ballot(bin == b);
-            if (m == 0ull) continue;
-            uint32_t off = 0;
-            if (bin == b && lane_prefix(m) == 0) off = atomicAdd(&a.bin_count[b], (uint32_t)__popcll(m));
-            off = (uint32_t)__shfl((int)off, __ffsll((long long)m) - 1);
-            if (bin == b) a.bin_items[(size_t)b * a.bin_stride + off + lane_prefix(m)] = i;
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; ++w) { const uint32_t c = s_wave_cnt[w][b]; total += c; if (w < wave) before += c; }
+            if (bin == b) a.bin_items[(size_t)b * a.bin_stride + run[b] + before + lane_prefix(m[b])] = i;
+            run[b] += total;
         }
     }
 }
