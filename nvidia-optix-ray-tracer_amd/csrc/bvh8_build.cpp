@@ -166,8 +166,8 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads) {
     for (uint32_t i = 0; i < n; ++i)
         for (int a = 0; a < 3; ++a) smax = std::max(smax, std::max(std::fabs(prims[i].lo[a]), std::fabs(prims[i].hi[a])));
     // Padding keeps the quantised slab test conservative w.r.t. the canonical intersector's
-    // own rounding (DESIGN.md "conservative boxes"): ~2e-6 of the scene scale.
-    const float pad = 2e-6f * smax;
+    // own rounding (DESIGN.md "conservative boxes"): 4e-6 of the scene scale.
+    const float pad = 4e-6f * smax;
     for (uint32_t i = 0; i < n; ++i) {
         B.idx[i] = i;
         for (int a = 0; a < 3; ++a) {

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_generate(GenerateArgs a) {
 // traverse: persistent waves over a ray queue, BVH8 with compressed child boxes
 // ---------------------------------------------------------------------------------------
 constexpr int kLdsStack = 8;          // entries per lane staged in LDS
-constexpr int kSpillStack = 40;       // overflow entries per lane in scratch
+constexpr int kSpillStack = 56;       // overflow entries per lane in scratch
 constexpr int kTraverseBlock = 256;
 constexpr uint32_t kFetchChunk = 128;        // rays per slice handed to a wave
 constexpr uint32_t kFetchShards = 8;         // slice counters (one per XCD-group of blocks)
@@ -296,10 +296,11 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
 
         // ---- traverse until enough lanes have finished to make a refill worthwhile ----
         for (;;) {
+            // ---- node phase: every lane with a pending node group opens its nearest child ----
+            uint2 tri = make_uint2(0u, 0u);
+            bool done = false;
             if (alive) {
-                uint2 tri = make_uint2(0u, 0u);
                 if (s.cur.y > 0x00ffffffu) {
-                    // ---- pop the nearest child of the current node group ----
                     const uint32_t hits_imask = s.cur.y;
                     const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
                     s.cur.y &= ~(1u << bit);
@@ -342,25 +343,44 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                             const float thi = fminf(fminf(tfx, tfy), fminf(tfz, s.bt));
                             const uint32_t cb = (child_bits4 >> (8 * j)) & 0xffu;
                             const uint32_t bi = (bit_index4 >> (8 * j)) & 0xffu;
-                            // widened far plane keeps the test conservative
-                            if (tlo <= thi * 1.0000005f) hitmask |= cb << bi;
+                            // conservative: the builder pads and rounds the child boxes outwards
+                            if (tlo <= thi) hitmask |= cb << bi;
                         }
                     }
                     s.cur = make_uint2(n1.x, (hitmask & 0xff000000u) | (e_imask >> 24));
                     tri = make_uint2(n1.y, hitmask & 0x00ffffffu);
+                } else {
+                    tri = s.cur;                    // a postponed leaf group came back from the stack
+                    s.cur = make_uint2(0u, 0u);
                 }
+            }
 
-                // ---- primitives of the leaves hit in this node ----
-                bool done = false;
-                while (tri.y) {
+            // ---- leaf phase, wave-uniform: test one primitive per lane and pass; when too few
+            //      lanes have leaf work the groups are postponed (pushed) so that the wave goes
+            //      back to nodes instead of idling 80 % of its lanes (Ylitie et al. 2017, sec. 4.3) ----
+            const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
+            for (;;) {
+                const uint64_t m = __ballot(alive && !done && tri.y != 0u);
+                if (m == 0ull) break;
+                if ((uint32_t)__popcll(m) * 100u < n_alive * (uint32_t)a.postpone_pct) {
+                    if (alive && !done && tri.y != 0u) {
+                        if (s.sp < kLdsStack) s_stack[s.sp][tx] = tri; else spill[s.sp - kLdsStack] = tri;
+                        ++s.sp;
+                        tri.y = 0u;
+                    }
+                    break;
+                }
+                if (alive && !done && tri.y != 0u) {
                     const uint32_t k = (uint32_t)__ffs((int)tri.y) - 1u;
                     tri.y &= tri.y - 1u;
                     if (COUNT) ++cnt_prims;
                     const bool better = test_prim<HAS_SPHERES>(prims, tri.x + k, s, tmin, tmax_ray, a.inst_inv, a.inst_identity);
-                    if (ANY_HIT && better) { done = true; break; }
+                    if (ANY_HIT && better) done = true;
                 }
+            }
 
-                // ---- next node group ----
+            // ---- next group ----
+            if (alive) {
                 if (!done && s.cur.y <= 0x00ffffffu) {
                     if (s.sp > 0) {
                         --s.sp;

@@ -726,8 +726,8 @@ void oracle_set_threads(int n) {
 /* CPU walk of the PRODUCT's packed BVH8 blob (layout: nvidia-optix-ray-tracer_amd/csrc/bvh8.h). */
 /* Test infrastructure: lets the CPU suite check the builder's node encoding and gives   */
 /* the per-ray node-visit / primitive-test counts of SURVEY.md 8(d) on the same bytes.   */
-/* Same canonical intersector as above; the box test mirrors the kernel's (fmaf, widened */
-/* far plane), traversal order = octant order, no triangle postponing.                    */
+/* Same canonical intersector as above; the box test mirrors the kernel's (fmaf)          */
+/*, traversal order = octant order, no triangle postponing.                    */
 /* ------------------------------------------------------------------------------------ */
 typedef struct { float a[3]; uint32_t prim; float b[3]; uint32_t inst; float c[3]; uint32_t kind; } prim48;
 
@@ -792,7 +792,7 @@ void oracle_bvh8_trace(const void *nodes_blob, const void *prims_blob,
                     const float tnz = fmaf(d.z < 0.0f ? qhz : qlz, aiz, aoz), tfz = fmaf(d.z < 0.0f ? qlz : qhz, aiz, aoz);
                     const float tlo = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
                     const float thi = fminf(fminf(tfx, tfy), fminf(tfz, bt));
-                    if (tlo <= thi * 1.0000005f) hitmask |= child_bits << bit_index;
+                    if (tlo <= thi) hitmask |= child_bits << bit_index;
                 }
                 cur_x = nd[4]; cur_y = (hitmask & 0xff000000u) | (e_imask >> 24);
                 tri_x = nd[5]; tri_y = hitmask & 0x00ffffffu;
