@@ -39,6 +39,7 @@ static_assert(sizeof(HitGroup) == 32, "HitGroupParams is 32 bytes");
 struct GenerateArgs {
     RayRec *rays;
     const uint32_t *rows;          // tile rows -> frame rows
+    uint32_t first_pixel;          // tile-local index of rays[0] (sub-tiles)
     uint32_t n_tile_pixels, width, height;
     float center[3], U[3], V[3], W[3];
 };

@@ -95,9 +95,11 @@ struct HrtContext {
     std::vector<TimedSpan> spans; std::vector<hipEvent_t> event_pool; size_t events_used = 0;
     double kernel_ms[HRT_K_COUNT] = {0}; uint64_t kernel_launches[HRT_K_COUNT] = {0};
     float4 *d_linear = nullptr;
-    int refill_threshold = 24;
+    int refill_threshold = 8;
     int traverse_blocks_per_cu = 6;
     int postpone_pct = 25;
+    int substreams = 3;                         // sub-tiles rendered on their own HIP streams so that one's tail overlaps another's bulk
+    std::vector<hipStream_t> sub_streams; std::vector<hipEvent_t> sub_done; hipEvent_t ev_begin = nullptr;
 };
 
 namespace {
@@ -293,7 +295,7 @@ int ensure_workspace(HrtContext *ctx, uint32_t n, uint32_t height) {
         HIP_TRY(ctx, hipMalloc((void **)&w.rows, sizeof(uint32_t) * (size_t)height));
         w.rows_capacity = height;
     }
-    if (!w.stages) HIP_TRY(ctx, hipMalloc((void **)&w.stages, sizeof(StageCounters) * (kRayTraceDepth + 1)));
+    if (!w.stages) HIP_TRY(ctx, hipMalloc((void **)&w.stages, sizeof(StageCounters) * (kRayTraceDepth + 1) * 8));
     return HRT_OK;
 }
 
@@ -350,6 +352,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
         hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)) != hipSuccess)
         return fail(nullptr, HRT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(hipGetLastError()));
     if (const char *e = std::getenv("HRT_TRAVERSE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 16) ctx->traverse_blocks_per_cu = v; }
+    if (const char *e = std::getenv("HRT_SUBSTREAMS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) ctx->substreams = v; }
     if (const char *e = std::getenv("HRT_POSTPONE_PCT")) { const int v = std::atoi(e); if (v >= 0 && v <= 100) ctx->postpone_pct = v; }
     if (const char *e = std::getenv("HRT_REFILL_THRESHOLD")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->refill_threshold = v; }
     *out_ctx = ctx.release();
@@ -375,6 +378,9 @@ int hrt_ctx_destroy(HrtContext *ctx) {
                     ctx->d_jump, ctx->d_stats, ctx->d_hitgroups, ctx->d_inst_program};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->sub_done) (void)hipEventDestroy(e);
+    for (hipStream_t st : ctx->sub_streams) (void)hipStreamDestroy(st);
+    if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     delete ctx;
     return HRT_OK;
 }
@@ -586,56 +592,90 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
     }
 
     const bool count = (ctx->flags & HRT_CTX_COUNT) != 0;
-    const uint32_t wide_grid = std::min<uint32_t>((uint32_t)ctx->n_cu * 8u, (n + 255u) / 256u);
-    const uint32_t trav_grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (n + 255u) / 256u);
 
-    GenerateArgs ga{};
-    ga.rays = w.rays[0]; ga.rows = w.rows; ga.n_tile_pixels = n; ga.width = rg->width; ga.height = rg->height;
-    std::memcpy(ga.center, &rg->cameraCenter, 12); std::memcpy(ga.U, &rg->cameraU, 12);
-    std::memcpy(ga.V, &rg->cameraV, 12); std::memcpy(ga.W, &rg->cameraW, 12);
+    // ---- sub-tiles: contiguous ranges of the tile's pixels, each on its own stream.  A traverse
+    //      launch ends with a tail (the longest rays, ~0.3 ms) during which most CUs idle; with
+    //      2-3 independent sub-tiles in flight one sub-tile's tail overlaps another's bulk. ----
+    uint32_t S = (uint32_t)ctx->substreams;
+    while (S > 1 && n / S < 131072u) --S;
+    if (S > 1) {
+        while (ctx->sub_streams.size() < S) {
+            hipStream_t st; HIP_TRY(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); ctx->sub_streams.push_back(st);
+            hipEvent_t ev; HIP_TRY(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming)); ctx->sub_done.push_back(ev);
+        }
+        if (!ctx->ev_begin) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_begin, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, s));
+        for (uint32_t k = 0; k < S; ++k) HIP_TRY(ctx, hipStreamWaitEvent(ctx->sub_streams[k], ctx->ev_begin, 0));
+    }
+    struct Sub { uint32_t j0, n; hipStream_t st; StageCounters *stages; uint32_t grid_wide, grid_trav; };
+    std::vector<Sub> subs(S);
+    for (uint32_t k = 0; k < S; ++k) {
+        const uint32_t j0 = (uint32_t)((uint64_t)n * k / S), j1 = (uint32_t)((uint64_t)n * (k + 1) / S);
+        subs[k].j0 = j0; subs[k].n = j1 - j0; subs[k].st = S > 1 ? ctx->sub_streams[k] : s;
+        subs[k].stages = w.stages + (size_t)k * (kRayTraceDepth + 1);
+        subs[k].grid_wide = std::min<uint32_t>((uint32_t)ctx->n_cu * 8u, (subs[k].n + 255u) / 256u);
+        subs[k].grid_trav = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (subs[k].n + 255u) / 256u);
+    }
 
     for (uint32_t sample = 0; sample < spp; ++sample) {
-        HIP_TRY(ctx, hipMemsetAsync(w.stages, 0, sizeof(StageCounters) * (kRayTraceDepth + 1), s));
-        { Timer tm(ctx, s, HRT_K_GENERATE); launch_generate(ga, s); }
+        for (const Sub &sb : subs) {
+            HIP_TRY(ctx, hipMemsetAsync(sb.stages, 0, sizeof(StageCounters) * (kRayTraceDepth + 1), sb.st));
+            GenerateArgs ga{};
+            ga.rays = w.rays[0] + sb.j0; ga.rows = w.rows; ga.first_pixel = sb.j0; ga.n_tile_pixels = sb.n;
+            ga.width = rg->width; ga.height = rg->height;
+            std::memcpy(ga.center, &rg->cameraCenter, 12); std::memcpy(ga.U, &rg->cameraU, 12);
+            std::memcpy(ga.V, &rg->cameraV, 12); std::memcpy(ga.W, &rg->cameraW, 12);
+            Timer tm(ctx, sb.st, HRT_K_GENERATE); launch_generate(ga, sb.st);
+        }
         int cur = 0;
         for (uint32_t depth = 1; depth <= kRayTraceDepth; ++depth) {
             const bool any_hit = depth >= kRayTraceDepth;      // a hit at the depth limit is black whatever it is (Shader.cu:102-107)
-            const uint32_t *n_ptr = depth == 1 ? nullptr : &w.stages[depth - 1].bin_count[1];
-            TraverseArgs ta{};
-            ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.rays = w.rays[cur];
-            ta.n_rays_ptr = n_ptr; ta.n_rays = n; ta.fetch_counter = w.stages[depth].fetch;
-            ta.hit_tuvp = w.hit_tuvp; ta.hit_inst = w.hit_inst;
-            ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
-            ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;      // Shader.cu:232, :266
-            ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct;
-            ta.count_nodes = any_hit ? &ctx->d_stats->nodes_any : &ctx->d_stats->nodes_closest;
-            ta.count_prims = any_hit ? &ctx->d_stats->prims_any : &ctx->d_stats->prims_closest;
-            { Timer tm(ctx, s, any_hit ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
-              launch_traverse(ta, any_hit, count, t->has_spheres, trav_grid, s); }
+            for (const Sub &sb : subs) {
+                hipStream_t st = sb.st;
+                const uint32_t *n_ptr = depth == 1 ? nullptr : &sb.stages[depth - 1].bin_count[1];
+                uint32_t *bin_items = w.bin_items + (size_t)sb.j0 * kNumBins;
+                TraverseArgs ta{};
+                ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.rays = w.rays[cur] + sb.j0;
+                ta.n_rays_ptr = n_ptr; ta.n_rays = sb.n; ta.fetch_counter = sb.stages[depth].fetch;
+                ta.hit_tuvp = w.hit_tuvp + sb.j0; ta.hit_inst = w.hit_inst + sb.j0;
+                ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
+                ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;      // Shader.cu:232, :266
+                ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct;
+                ta.count_nodes = any_hit ? &ctx->d_stats->nodes_any : &ctx->d_stats->nodes_closest;
+                ta.count_prims = any_hit ? &ctx->d_stats->prims_any : &ctx->d_stats->prims_closest;
+                { Timer tm(ctx, st, any_hit ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
+                  launch_traverse(ta, any_hit, count, t->has_spheres, sb.grid_trav, st); }
 
-            BinArgs ba{};
-            ba.n_rays_ptr = n_ptr; ba.n_rays = n; ba.hit_inst = w.hit_inst; ba.inst_program = ctx->d_inst_program; ba.depth = depth;
-            ba.bin_count = w.stages[depth].bin_count; ba.bin_items = w.bin_items; ba.bin_stride = n;
-            ba.total_rays = any_hit ? &ctx->d_stats->rays_any : &ctx->d_stats->rays_closest;
-            { Timer tm(ctx, s, HRT_K_BIN); launch_bin(ba, wide_grid, s); }
+                BinArgs ba{};
+                ba.n_rays_ptr = n_ptr; ba.n_rays = sb.n; ba.hit_inst = w.hit_inst + sb.j0; ba.inst_program = ctx->d_inst_program; ba.depth = depth;
+                ba.bin_count = sb.stages[depth].bin_count; ba.bin_items = bin_items; ba.bin_stride = sb.n;
+                ba.total_rays = any_hit ? &ctx->d_stats->rays_any : &ctx->d_stats->rays_closest;
+                { Timer tm(ctx, st, HRT_K_BIN); launch_bin(ba, sb.grid_wide, st); }
 
-            if (depth < kRayTraceDepth) {
-                ShadeArgs sa{};
-                sa.bin_count = w.stages[depth].bin_count; sa.bin_items = w.bin_items; sa.bin_stride = n;
-                sa.rays_in = w.rays[cur]; sa.rays_out = w.rays[cur ^ 1];
-                sa.hit_tuvp = w.hit_tuvp; sa.hit_inst = w.hit_inst; sa.hitgroups = ctx->d_hitgroups;
-                sa.states = reinterpret_cast<RngState *>(h_params->stateArray);
-                sa.chain = w.chain; sa.depth = depth;
-                for (int p = 0; p < (int)kNumPrograms; ++p)
-                    if (ctx->program_present[p]) { Timer tm(ctx, s, HRT_K_SHADE); launch_shade(sa, p, wide_grid, s); }
+                if (depth < kRayTraceDepth) {
+                    ShadeArgs sa{};
+                    sa.bin_count = sb.stages[depth].bin_count; sa.bin_items = bin_items; sa.bin_stride = sb.n;
+                    sa.rays_in = w.rays[cur] + sb.j0; sa.rays_out = w.rays[cur ^ 1] + sb.j0;
+                    sa.hit_tuvp = w.hit_tuvp + sb.j0; sa.hit_inst = w.hit_inst + sb.j0; sa.hitgroups = ctx->d_hitgroups;
+                    sa.states = reinterpret_cast<RngState *>(h_params->stateArray);
+                    sa.chain = w.chain; sa.depth = depth;
+                    for (int p = 0; p < (int)kNumPrograms; ++p)
+                        if (ctx->program_present[p]) { Timer tm(ctx, st, HRT_K_SHADE); launch_shade(sa, p, sb.grid_wide, st); }
+                }
+                AccumArgs aa{};
+                aa.bin_count = sb.stages[depth].bin_count; aa.bin_items = bin_items; aa.rays_in = w.rays[cur] + sb.j0; aa.hit_inst = w.hit_inst + sb.j0;
+                aa.hitgroups = ctx->d_hitgroups; aa.chain = w.chain; aa.accum = w.accum;
+                aa.bg[0] = ctx->miss.backgroundColor.x; aa.bg[1] = ctx->miss.backgroundColor.y; aa.bg[2] = ctx->miss.backgroundColor.z;
+                aa.depth = depth; aa.first_sample = sample == 0 ? 1u : 0u;
+                { Timer tm(ctx, st, HRT_K_ACCUMULATE); launch_accumulate(aa, sb.grid_wide, st); }
             }
-            AccumArgs aa{};
-            aa.bin_count = w.stages[depth].bin_count; aa.bin_items = w.bin_items; aa.rays_in = w.rays[cur]; aa.hit_inst = w.hit_inst;
-            aa.hitgroups = ctx->d_hitgroups; aa.chain = w.chain; aa.accum = w.accum;
-            aa.bg[0] = ctx->miss.backgroundColor.x; aa.bg[1] = ctx->miss.backgroundColor.y; aa.bg[2] = ctx->miss.backgroundColor.z;
-            aa.depth = depth; aa.first_sample = sample == 0 ? 1u : 0u;
-            { Timer tm(ctx, s, HRT_K_ACCUMULATE); launch_accumulate(aa, wide_grid, s); }
             cur ^= 1;
+        }
+    }
+    if (S > 1) {
+        for (uint32_t k = 0; k < S; ++k) {
+            HIP_TRY(ctx, hipEventRecord(ctx->sub_done[k], ctx->sub_streams[k]));
+            HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->sub_done[k], 0));
         }
     }
     FinalizeArgs fa{};

@@ -121,8 +121,9 @@ __global__ __launch_bounds__(256) void k_rng_init(RngState *states, uint32_t n, 
 // generate: __raygen__raygenProgram up to the trace call, shader/Shader.cu:246-267
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_generate(GenerateArgs a) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= a.n_tile_pixels) return;
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= a.n_tile_pixels) return;
+    const uint32_t j = a.first_pixel + q;
     const uint32_t row = j / a.width;
     const uint32_t ix = j - row * a.width;
     const uint32_t iy = a.rows[row];
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void k_generate(GenerateArgs a) {
     RayRec r;
     r.o = make_float4(a.center[0], a.center[1], a.center[2], __uint_as_float(j));
     r.d = make_float4(dir.x, dir.y, dir.z, __uint_as_float(iy * a.width + ix));
-    a.rays[j] = r;
+    a.rays[q] = r;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -742,7 +742,7 @@ void oracle_bvh8_trace(const void *nodes_blob, const void *prims_blob,
                        const float *origins, const float *dirs, uint32_t n_rays,
                        float tmin, float tmax, int any_hit,
                        float *t_out, float *u_out, float *v_out, uint32_t *prim_out, uint32_t *inst_out,
-                       uint64_t *out_counters /* node visits, prim tests */) {
+                       uint64_t *out_counters /* node visits, prim tests */, uint32_t *per_ray_nodes /* or NULL */) {
     const uint32_t *nodes = (const uint32_t *)nodes_blob;          /* 20 words per node */
     const prim48 *prims = (const prim48 *)prims_blob;
     uint64_t tot_nodes = 0, tot_prims = 0;
@@ -757,6 +757,7 @@ void oracle_bvh8_trace(const void *nodes_blob, const void *prims_blob,
         uint32_t stack_x[64], stack_y[64]; int sp = 0;
         uint32_t cur_x = 0, cur_y = 0x80000000u;
         int done = 0;
+        uint32_t my_nodes = 0;
         while (!done) {
             uint32_t tri_x = 0, tri_y = 0;
             if (cur_y > 0x00ffffffu) {
@@ -767,7 +768,7 @@ void oracle_bvh8_trace(const void *nodes_blob, const void *prims_blob,
                 const uint32_t slot_index = (bit - 24u) ^ oct_inv;
                 const uint32_t rel = (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot_index));
                 const uint32_t *nd = nodes + 20 * (size_t)(cur_x + rel);
-                ++tot_nodes;
+                ++tot_nodes; ++my_nodes;
                 float p[3]; memcpy(p, nd, 12);
                 const uint32_t e_imask = nd[3];
                 uint32_t eb; float sx, sy, sz;
@@ -820,6 +821,7 @@ void oracle_bvh8_trace(const void *nodes_blob, const void *prims_blob,
         }
         t_out[ri] = best.hit ? best.t : tmax; u_out[ri] = best.u; v_out[ri] = best.v;
         prim_out[ri] = best.hit ? best.prim : 0xffffffffu; inst_out[ri] = best.hit ? best.inst : 0xffffffffu;
+        if (per_ray_nodes) per_ray_nodes[ri] = my_nodes;
     }
     if (out_counters) { out_counters[0] = tot_nodes; out_counters[1] = tot_prims; }
 }

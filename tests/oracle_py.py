@@ -39,7 +39,7 @@ def lib():
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.oracle_bvh8_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                     C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_void_p]
+                                    C.c_void_p, C.c_void_p, C.c_void_p]
     L.oracle_rng_init.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
     L.oracle_rng_init_one.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
     L.oracle_rng_init_generic.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -157,7 +157,7 @@ def rng_init(width, height, salt):
 
 
 def bvh8_trace(nodes_ptr, prims_ptr, origins, directions, tmin=1e-6, tmax=1e16, any_hit=False,
-               inst_inv=None, inst_identity=None):
+               inst_inv=None, inst_identity=None, per_ray_nodes=None):
     """Walk a packed BVH8 blob of the product on the CPU.  Returns (t,u,v,prim,inst, node_visits, prim_tests)."""
     L = lib()
     o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
@@ -167,7 +167,7 @@ def bvh8_trace(nodes_ptr, prims_ptr, origins, directions, tmin=1e-6, tmax=1e16, 
     prim, inst = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
     cnt = np.zeros(2, np.uint64)
     L.oracle_bvh8_trace(nodes_ptr, prims_ptr, _p(inst_inv), _p(inst_identity), _p(o), _p(d), n, tmin, tmax, int(any_hit),
-                        _p(t), _p(u), _p(v), _p(prim), _p(inst), _p(cnt))
+                        _p(t), _p(u), _p(v), _p(prim), _p(inst), _p(cnt), _p(per_ray_nodes))
     return t, u, v, prim, inst, int(cnt[0]), int(cnt[1])
 
 
