@@ -98,7 +98,7 @@ def main():
     def step():
         r.render(spp, tile=tile, sync=False)
         if world > 1:
-            dist.reduce(r.color, dst=0, op=dist.ReduceOp.SUM)     # per-tile radiance -> rank 0 (x + 0 is exact)
+            hrt.reduce_tiles(r.color, dst=0)                      # per-tile radiance -> rank 0 (x + 0 is exact)
 
     def fence():
         torch.cuda.synchronize(dev)

@@ -148,8 +148,8 @@ def load_library():
     return lib
 
 
-from .host import Renderer, configure_camera, tile_for_rank  # noqa: E402  (host-side mirror of the launch sequence)
+from .host import Renderer, configure_camera, tile_for_rank, reduce_tiles  # noqa: E402  (host-side mirror of the launch sequence)
 from . import scenes  # noqa: E402
 
-__all__ = ["load_library", "Renderer", "configure_camera", "tile_for_rank", "scenes", "HrtError",
+__all__ = ["load_library", "Renderer", "configure_camera", "tile_for_rank", "reduce_tiles", "scenes", "HrtError",
            "GlobalParams", "RayGenParams", "MissParams", "HitGroupParams", "SbtRecord", "Instance", "Tile", "Stats"]

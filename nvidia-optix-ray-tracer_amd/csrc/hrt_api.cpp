@@ -98,7 +98,7 @@ struct HrtContext {
     int refill_threshold = 8;
     int traverse_blocks_per_cu = 6;
     int postpone_pct = 25;
-    int substreams = 3;                         // sub-tiles rendered on their own HIP streams so that one's tail overlaps another's bulk
+    int substreams = 1;                         // sub-tiles rendered on their own HIP streams so that one's tail overlaps another's bulk
     std::vector<hipStream_t> sub_streams; std::vector<hipEvent_t> sub_done; hipEvent_t ev_begin = nullptr;
 };
 

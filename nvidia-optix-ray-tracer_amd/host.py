@@ -58,6 +58,15 @@ def tile_for_rank(height, rank, world_size, stripe_rows=8):
     return Tile(0, height, stripe_rows, world_size, rank)
 
 
+def reduce_tiles(frame, dst=0):
+    """The one exchange step of the multi-GPU split: sum the per-rank frames (each zero outside its
+    own row stripes, so x + 0 is exact) into rank ``dst`` over torch.distributed (RCCL on GPUs)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM)
+    return frame
+
+
 class Renderer:
     """One context + one scene: build, then ``render()`` as often as needed."""
 

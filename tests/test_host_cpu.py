@@ -1,0 +1,145 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports what include/hrt.h
+declares, struct layouts match the reference's, there is no CPU fallback, the host BVH8 builder
+produces a valid tree whose CPU walk (oracle-side walker, test infrastructure) equals brute force."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol(hrt):
+    lib = hrt.load_library()
+    header = (ROOT / "include" / "hrt.h").read_text()
+    declared = sorted(set(re.findall(r"\b(hrt_[a-z0-9_]+)\s*\(", header)))
+    assert declared, "no declarations found in include/hrt.h"
+    for name in declared:
+        assert hasattr(lib, name), f"libhrt.so does not export {name}"
+    assert sorted(hrt.EXPORTS) == declared
+    assert b"gfx950" in lib.hrt_version()
+
+
+def test_struct_layouts_match_reference(hrt):
+    assert C.sizeof(hrt.GlobalParams) == 16
+    assert C.sizeof(hrt.RayGenParams) == 80
+    assert [getattr(hrt.RayGenParams, f).offset for f in ("width", "height", "colorBuffer", "albedoBuffer", "normalBuffer",
+                                                           "cameraCenter", "cameraU", "cameraV", "cameraW")] == [0, 4, 8, 16, 24, 32, 44, 56, 68]
+    assert C.sizeof(hrt.MissParams) == 12 and C.sizeof(hrt.HitGroupParams) == 32
+    assert hrt.HitGroupParams.albedo.offset == 16 and hrt.HitGroupParams.fuzz.offset == 28
+    assert C.sizeof(hrt.SbtRecord) == 64 and hrt.SbtRecord.data.offset == 32          # OPTIX_SBT_RECORD_HEADER_SIZE
+    assert C.sizeof(hrt.Instance) == 80 and hrt.Instance.sbtOffset.offset == 52 and hrt.Instance.traversableHandle.offset == 64
+
+
+def test_no_cpu_fallback(hrt, gpu_available):
+    if gpu_available:
+        pytest.skip("a GPU is present")
+    lib = hrt.load_library()
+    ctx = C.c_void_p()
+    assert lib.hrt_ctx_create(0, 0, C.byref(ctx)) == -2            # HRT_ERR_NO_DEVICE
+    assert not ctx.value and b"no CPU path" in lib.hrt_last_error(None)
+    with pytest.raises(hrt.HrtError):
+        hrt.Renderer(0)
+
+
+def test_sbt_header_packing(hrt):
+    lib = hrt.load_library()
+    rec = hrt.SbtRecord()
+    assert lib.hrt_sbt_record_pack_header(hrt.PROGRAM_TRIANGLE_METAL, C.byref(rec)) == 0
+    assert bytes(rec.header[:4]) == b"HRT\x03" and not any(rec.header[4:])
+    assert lib.hrt_sbt_record_pack_header(7, C.byref(rec)) == -1
+    assert lib.hrt_sbt_record_pack_header(0, None) == -1
+
+
+def _build(hrt, tris):
+    lib = hrt.load_library()
+    v = np.ascontiguousarray(tris, np.float32).reshape(-1, 3, 3)
+    blob = hrt.BvhBlob()
+    rc = lib.hrt_host_build_bvh8(v.ctypes.data, v.shape[0], C.byref(blob))
+    assert rc == 0, lib.hrt_last_error(None)
+    return lib, blob
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 9, 200, 5000])
+def test_host_bvh8_build_and_cpu_walk(hrt, oracle, n):
+    scene = hrt.scenes.random_soup(n, 0.2, 13)
+    lib, blob = _build(hrt, scene["instances"][0]["vertices"])
+    assert blob.n_triangles == n and blob.n_nodes >= 1
+    o, d = oracle.random_rays(3000, n)
+    want = oracle.OracleScene(scene, force_brute=True).trace(o, d)
+    got = oracle.bvh8_trace(blob.nodes, blob.triangles, o, d)
+    assert all(np.array_equal(a, b) for a, b in zip(got[:5], want))
+    any_w = oracle.OracleScene(scene, force_brute=True).trace(o, d, any_hit=True)
+    any_g = oracle.bvh8_trace(blob.nodes, blob.triangles, o, d, any_hit=True)
+    assert np.array_equal(any_g[3] != 0xFFFFFFFF, any_w[3] != 0xFFFFFFFF)
+    lib.hrt_host_free(C.byref(blob))
+    assert not blob.nodes
+
+
+def test_host_bvh8_degenerate_inputs(hrt, oracle):
+    """Duplicates, zero-area triangles, identical centroids, huge coordinate range."""
+    rng = np.random.default_rng(3)
+    base = rng.uniform(-1, 1, (50, 3, 3)).astype(np.float32)
+    tris = np.concatenate([base, base[:10], np.zeros((8, 3, 3), np.float32),                  # duplicates, all-zero triangles
+                           np.repeat(rng.uniform(-1, 1, (1, 3, 3)).astype(np.float32), 40, 0),   # 40 identical triangles
+                           (base[:5] * 1000 + 500).astype(np.float32)])                       # far away and large
+    scene = {"instances": [hrt.scenes._tri_instance(tris, hrt.scenes.WHITE)], "camera": hrt.scenes._soup_camera(),
+             "background": hrt.scenes.BACKGROUND}
+    lib, blob = _build(hrt, tris)
+    o, d = oracle.random_rays(4000, 17)
+    want = oracle.OracleScene(scene, force_brute=True).trace(o, d)
+    got = oracle.bvh8_trace(blob.nodes, blob.triangles, o, d)
+    assert all(np.array_equal(a, b) for a, b in zip(got[:5], want))
+    lib.hrt_host_free(C.byref(blob))
+
+
+def test_empty_bvh(hrt, oracle):
+    lib = hrt.load_library()
+    blob = hrt.BvhBlob()
+    assert lib.hrt_host_build_bvh8(None, 0, C.byref(blob)) == 0
+    assert blob.n_nodes == 1 and blob.n_triangles == 0
+    got = oracle.bvh8_trace(blob.nodes, blob.triangles, [[0, 0, 3]], [[0, 0, -1]])
+    assert got[3][0] == 0xFFFFFFFF
+    lib.hrt_host_free(C.byref(blob))
+
+
+def test_splitmix64_known_answers(hrt):
+    out = hrt.scenes.splitmix64(0, 3)
+    assert [int(x) for x in out] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+    u = hrt.scenes.uniform_f32(1, 1000, -2.0, 3.0)
+    assert u.dtype == np.float32 and u.min() >= -2.0 and u.max() < 3.0
+
+
+def test_scenes_are_deterministic_and_sized(hrt):
+    c1 = hrt.scenes.cornell_box()
+    assert sum(len(i["vertices"]) for i in c1["instances"]) == 32 and (c1["width"], c1["height"], c1["spp"]) == (256, 256, 1)
+    c2 = hrt.scenes.sphere_in_box()
+    assert sum(len(i["vertices"]) for i in c2["instances"] if i["geometry"] == "triangles") == 12
+    assert [i["geometry"] for i in c2["instances"]].count("spheres") == 1 and (c2["width"], c2["spp"]) == (512, 16)
+    a, b = hrt.scenes.random_soup(1000, 0.03, 1), hrt.scenes.random_soup(1000, 0.03, 1)
+    assert np.array_equal(a["instances"][0]["vertices"], b["instances"][0]["vertices"])
+    v = a["instances"][0]["vertices"]
+    assert v.shape == (1000, 3, 3) and np.abs(v.mean(axis=1)).max() <= 1.0 + 1e-6
+    n = a["instances"][0]["normals"]
+    assert np.allclose(np.linalg.norm(n[:, 0], axis=1), 1, atol=1e-5) and np.array_equal(n[:, 0], n[:, 2])
+    c5 = hrt.scenes.soup_1m_8mat(n_triangles=800)
+    assert len(c5["instances"]) == 8 and [i["material"] for i in c5["instances"]] == ["rough"] * 4 + ["metal"] * 4
+    assert [i["fuzz"] for i in c5["instances"][4:]] == [0.0, 0.1, 0.3, 0.5]
+    assert sum(len(i["vertices"]) for i in c5["instances"]) == 800
+
+
+def test_tiles_partition_the_frame(hrt):
+    for height, world in ((1080, 8), (1080, 4), (50, 3), (7, 2), (16, 1)):
+        seen = np.zeros(height, int)
+        for rank in range(world):
+            t = hrt.tile_for_rank(height, rank, world)
+            rows = [y for y in range(t.y_begin, t.y_end) if (y // t.stripe_rows) % t.stripe_period == t.stripe_phase]
+            seen[rows] += 1
+        assert (seen == 1).all()
+    sizes = []
+    for rank in range(8):
+        t = hrt.tile_for_rank(1080, rank, 8)
+        sizes.append(sum(1 for y in range(1080) if (y // t.stripe_rows) % t.stripe_period == t.stripe_phase))
+    assert max(sizes) - min(sizes) <= 8

@@ -1,0 +1,216 @@
+"""CPU tests of the oracle (oracle/oracle.c): pins and self-consistency.  No GPU needed.
+
+The oracle's parity status is "unpinned" w.r.t. a real OptiX frame (see its header); what CAN be
+pinned is pinned here: the XORWOW algebra against rocRAND, the one reference-derived KAT of
+SURVEY.md, the committed fixtures, and BVH-vs-brute-force equality of the canonical intersector.
+"""
+import ctypes as C
+import json
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+GOLD = Path(__file__).resolve().parent / "golden"
+ROCRAND_CONST = (0x2C7F967F, 0xA03697CB, 1228688033, 2073658381)
+
+
+def _draws(oracle, seed, sub, n=8, consts=None):
+    L = oracle.lib()
+    st = np.zeros(12, np.uint32)
+    if consts is None:
+        L.oracle_rng_init_one(st.ctypes.data, seed, sub)
+    else:
+        L.oracle_rng_init_generic(st.ctypes.data, seed, sub, *consts)
+    return [int(L.oracle_rng_next(st.ctypes.data)) for _ in range(n)], st
+
+
+def test_xorwow_against_committed_rocrand_vectors(oracle):
+    data = json.loads((GOLD / "rocrand_xorwow_vectors.json").read_text())
+    for vec in data["vectors"]:
+        got, _ = _draws(oracle, vec["seed"], vec["subsequence"], len(vec["draws"]), ROCRAND_CONST)
+        assert got == vec["draws"], f"seed {vec['seed']} subsequence {vec['subsequence']}"
+
+
+def test_xorwow_against_live_rocrand_engine(oracle):
+    """Same pin, but against the engine compiled now (skipped when the rocRAND headers are absent)."""
+    src = Path(__file__).resolve().parent / "helpers" / "rocrand_xorwow_ref.cpp"
+    so = src.with_name("librocrand_ref.so")
+    if not so.exists():
+        if not Path("/opt/rocm/include/rocrand/rocrand_xorwow.h").exists():
+            pytest.skip("rocRAND headers not installed")
+        subprocess.check_call(["g++", "-O1", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", str(src), "-o", str(so)])
+    R = C.CDLL(str(so))
+    R.rocrand_xorwow_draw.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        seed = int(rng.integers(0, 2**63)); sub = int(rng.integers(0, 2**31))
+        ref = np.zeros(6, np.uint32)
+        R.rocrand_xorwow_draw(seed, sub, 0, ref.ctypes.data, 6)
+        got, _ = _draws(oracle, seed, sub, 6, ROCRAND_CONST)
+        assert got == [int(x) for x in ref]
+
+
+def test_xorwow_subsequence_composition_and_state_layout(oracle):
+    L = oracle.lib()
+    # subsequence 0 must not touch the seeded state; d is unchanged by any subsequence skip
+    _, s0 = _draws(oracle, 77, 0, 0)
+    _, s5 = _draws(oracle, 77, 5, 0)
+    assert s0[0] == s5[0] and not np.array_equal(s0[1:6], s5[1:6])
+    assert np.all(s0[6:] == 0) and s0.nbytes == 48
+    # cuRAND's published seeding for seed 0: v = {123456789 + t0, 362436069 ^ t0, ...}, t0 = 1099087573 * 0xaad26b49
+    t0 = (1099087573 * 0xAAD26B49) & 0xFFFFFFFF
+    t1 = (2591861531 * 0xF7DCEFDD) & 0xFFFFFFFF
+    want = [(6615241 + t1 + t0) & 0xFFFFFFFF, (123456789 + t0) & 0xFFFFFFFF, 362436069 ^ t0, (521288629 + t1) & 0xFFFFFFFF,
+            88675123 ^ t1, (5783321 + t0) & 0xFFFFFFFF]
+    assert [int(x) for x in s0[:6]] != want          # seed 77, not 0
+    _, z = _draws(oracle, 0, 0, 0)
+    assert [int(x) for x in z[:6]] == want
+    # uniform is (0, 1] with 2^-32 spacing: x * 2^-32 + 2^-33
+    st = z.copy()
+    x = L.oracle_rng_next(st.ctypes.data)
+    st = z.copy()
+    u = L.oracle_rng_uniform(st.ctypes.data)
+    assert u == np.float32(np.float32(x) * np.float32(2.3283064e-10) + np.float32(2.3283064e-10) / np.float32(2.0))
+    assert 0.0 < u <= 1.0
+
+
+def test_rng_init_matches_per_pixel_definition(oracle, hrt):
+    """oracle_rng_init(W,H,salt)[i] == curand_init(i ^ salt, i, 0): src/Global/HostFunctions.cu:126 with clock64() pinned."""
+    salt = hrt.scenes.SEED_SALT
+    st = oracle.rng_init(37, 5, salt)
+    L = oracle.lib()
+    for i in (0, 1, 36, 37, 100, 184):
+        one = np.zeros(12, np.uint32)
+        L.oracle_rng_init_one(one.ctypes.data, i ^ salt, i)
+        assert np.array_equal(st[i], one)
+
+
+def test_reference_kat_color_to_float4(oracle):
+    kat = json.loads((GOLD / "reference_kat.json").read_text())
+    want = np.array([float.fromhex(h) for h in kat["colorToFloat4_background_hex"]], dtype=np.float32)
+    rgb = np.array([0.7, 0.8, 0.9], np.float32)
+    out = np.zeros(4, np.float32)
+    oracle.lib().oracle_color_to_float4(rgb.ctypes.data, out.ctypes.data)
+    assert np.array_equal(out, want)
+
+
+def test_color_edge_cases(oracle):
+    L = oracle.lib()
+    out = np.zeros(4, np.float32)
+    one = float(np.float32(1.055) * np.float32(1.0) - np.float32(0.055))      # 0.99999994: white never reaches 1.0 in the reference
+    assert one < 1.0
+    for rgb, want in (([0, 0, 0], [0, 0, 0]), ([1, 2, -1], [one, one, 0]), ([0.002, 0.0031308, 0.5], None)):
+        a = np.array(rgb, np.float32)
+        L.oracle_color_to_float4(a.ctypes.data, out.ctypes.data)
+        if want is not None:
+            assert [float(x) for x in out[:3]] == want
+        else:
+            assert out[0] == np.float32(12.92) * np.float32(0.002)
+            assert abs(out[2] - 0.7353569) < 1e-6
+        assert out[3] == 1.0
+    b = np.zeros(4, np.uint8)
+    a = np.array([1.0, 0.0, 0.5], np.float32)
+    L.oracle_color_to_uchar4(a.ctypes.data, b.ctypes.data)
+    assert list(b) == [255, 0, 188, 255]          # min(u32(s * 256), 255), DeviceFunctions.cuh:178
+
+
+def test_camera_matches_host_mirror(oracle, hrt):
+    """Oracle camera basis == the product's host-side restatement, bit for bit, GL and non-GL."""
+    for opengl in (True, False):
+        cam = {"center": np.array([5, 0.3, -0.2], np.float32), "target": np.array([0, 0, 0.1], np.float32),
+               "up": np.array([0, 0.1, 2.0], np.float32), "opengl": opengl}
+        osc = oracle.OracleScene({"instances": [], "camera": cam, "background": hrt.scenes.BACKGROUND})
+        c12 = osc.camera12()
+        u, v, w = hrt.configure_camera(cam["center"], cam["target"], cam["up"], opengl)
+        assert np.array_equal(c12[3:6], u) and np.array_equal(c12[6:9], v) and np.array_equal(c12[9:12], w)
+        assert abs(np.linalg.norm(u) - 1) < 1e-6 and abs(np.linalg.norm(v) - 1) < 1e-6
+        assert np.array_equal(w, cam["target"] - cam["center"])          # W is not normalised
+
+
+def test_oracle_bvh_equals_bruteforce(oracle, hrt):
+    scene = hrt.scenes.mixed_test_scene(2500, 50, 11)
+    a, b = oracle.OracleScene(scene), oracle.OracleScene(scene, force_brute=True)
+    o, d = oracle.random_rays(20000, 1)
+    for any_hit in (False, True):
+        ra, rb = a.trace(o, d, any_hit=any_hit), b.trace(o, d, any_hit=any_hit)
+        if any_hit:
+            assert np.array_equal(ra[3] != 0xFFFFFFFF, rb[3] != 0xFFFFFFFF)
+        else:
+            assert all(np.array_equal(x, y) for x, y in zip(ra, rb))
+    assert 0.3 < (rb[3] != 0xFFFFFFFF).mean() < 1.0
+
+
+def test_closest_hit_tie_break_lowest_instance_then_primitive(oracle, hrt):
+    """Two coincident triangles in two instances, and twice in one instance: the canonical
+    intersector reports the lowest (instance, primitive)."""
+    tri = np.array([[[-1, -1, 0], [1, -1, 0], [0, 1, 0]]], np.float32)
+    two = np.concatenate([tri, tri])
+    inst = [hrt.scenes._tri_instance(two, hrt.scenes.WHITE), hrt.scenes._tri_instance(tri, hrt.scenes.RED)]
+    scene = {"instances": inst, "camera": hrt.scenes._soup_camera(), "background": hrt.scenes.BACKGROUND}
+    t, u, v, prim, ins = oracle.OracleScene(scene, force_brute=True).trace([[0, 0, 2]], [[0, 0, -1]])
+    assert prim[0] == 0 and ins[0] == 0 and t[0] == 2.0
+
+
+def test_golden_images(oracle, hrt):
+    for name, scene in (("c1_64", hrt.scenes.cornell_box(64, 64, 1)), ("c2_48_spp4", hrt.scenes.sphere_in_box(48, 48, 4)),
+                        ("mixed_61x37_spp2", hrt.scenes.mixed_test_scene(600, 16, 7, 61, 37, 2))):
+        g = np.load(GOLD / f"oracle_{name}.npz")
+        W, H, spp = int(g["width"]), int(g["height"]), int(g["spp"])
+        st = oracle.rng_init(W, H, hrt.scenes.SEED_SALT)
+        r = oracle.OracleScene(scene).render(W, H, st, spp)
+        assert np.array_equal(r["linear"].view(np.uint32), g["linear"].view(np.uint32)), name
+        assert np.array_equal(r["color"].view(np.uint32), g["color"].view(np.uint32)), name
+        assert r["rays"] == int(g["rays"]) and np.array_equal(st[-64:], g["states_tail"])
+
+
+def test_golden_hits(oracle, hrt):
+    g = np.load(GOLD / "oracle_hits_mixed.npz")
+    scene = hrt.scenes.mixed_test_scene(600, 16, 7)
+    o, d = oracle.random_rays(4000, 3)
+    t, u, v, prim, inst = oracle.OracleScene(scene).trace(o, d)           # BVH path against brute-force fixture
+    assert np.array_equal(prim, g["prim"]) and np.array_equal(inst, g["inst"])
+    assert np.array_equal(t.view(np.uint32), g["t"].view(np.uint32))
+    assert np.array_equal(u.view(np.uint32), g["u"].view(np.uint32)) and np.array_equal(v.view(np.uint32), g["v"].view(np.uint32))
+
+
+def test_reference_quirks_q3_q4(oracle, hrt):
+    """Q3: albedo/normal AOVs are always zero.  Q4: a path that hits 5 surfaces is black; rays per path in 1..5."""
+    scene = hrt.scenes.cornell_box(48, 48, 1)
+    st = oracle.rng_init(48, 48, 1)
+    r = oracle.OracleScene(scene).render(48, 48, st, 1)
+    assert not r["albedo"].any() and not r["normal"].any()
+    assert 48 * 48 <= r["rays"] <= 5 * 48 * 48
+    # closed box around the camera: every path makes 5 hits -> black frame, exactly 5 rays per pixel
+    box = np.array(hrt.scenes._box((-1, -1, -1), (1, 1, 1), skip_bottom=False), np.float32)
+    closed = {"instances": [hrt.scenes._tri_instance(box, hrt.scenes.WHITE)], "background": hrt.scenes.BACKGROUND,
+              "camera": {"center": np.zeros(3, np.float32), "target": np.array([0, 0, 1], np.float32), "up": np.array([0, 1, 0], np.float32)}}
+    st = oracle.rng_init(16, 16, 3)
+    r = oracle.OracleScene(closed).render(16, 16, st, 1)
+    assert r["rays"] == 5 * 16 * 16 and not r["linear"][..., :3].any()
+
+
+def test_rows_subset_equals_full_frame_rows(oracle, hrt):
+    scene = hrt.scenes.mixed_test_scene(500, 10, 2, 40, 30, 2)
+    salt = 4242
+    full = oracle.OracleScene(scene).render(40, 30, oracle.rng_init(40, 30, salt), 2)
+    rows = np.array([y for y in range(30) if (y // 4) % 3 == 1], np.uint32)
+    part = oracle.OracleScene(scene).render(40, 30, oracle.rng_init(40, 30, salt), 2, rows=rows)
+    assert np.array_equal(part["linear"][rows], full["linear"][rows])
+    others = np.setdiff1d(np.arange(30), rows)
+    assert not part["color"][others].any()
+
+
+def test_spp_mean_definition(oracle, hrt):
+    """spp launches = successive 1-spp frames on the persistent streams, summed in order, divided once."""
+    scene = hrt.scenes.cornell_box(24, 24, 1)
+    osc = oracle.OracleScene(scene)
+    st = oracle.rng_init(24, 24, 9)
+    frames = [osc.render(24, 24, st, 1)["linear"][..., :3].copy() for _ in range(3)]
+    acc = frames[0]
+    for f in frames[1:]:
+        acc = (acc + f).astype(np.float32)
+    mean = (acc / np.float32(3)).astype(np.float32)
+    three = osc.render(24, 24, oracle.rng_init(24, 24, 9), 3)["linear"][..., :3]
+    assert np.array_equal(three.view(np.uint32), mean.view(np.uint32))
