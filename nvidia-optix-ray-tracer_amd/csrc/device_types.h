@@ -57,6 +57,7 @@ struct TraverseArgs {
     const uint32_t *inst_identity;
     float tmin, tmax;
     int refill_threshold;          // refill when at least this many lanes are idle
+    int tail_split;                // split long rays across idle lanes once the queue is drained
     int postpone_pct;              // leaf work is postponed while fewer than this % of the alive lanes have any
     uint64_t *count_nodes, *count_prims;
 };

@@ -98,6 +98,7 @@ struct HrtContext {
     int refill_threshold = 8;
     int traverse_blocks_per_cu = 6;
     int postpone_pct = 25;
+    int tail_split = 1;
     int substreams = 1;                         // sub-tiles rendered on their own HIP streams so that one's tail overlaps another's bulk
     std::vector<hipStream_t> sub_streams; std::vector<hipEvent_t> sub_done; hipEvent_t ev_begin = nullptr;
 };
@@ -352,6 +353,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
         hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)) != hipSuccess)
         return fail(nullptr, HRT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(hipGetLastError()));
     if (const char *e = std::getenv("HRT_TRAVERSE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 16) ctx->traverse_blocks_per_cu = v; }
+    if (const char *e = std::getenv("HRT_TAIL_SPLIT")) ctx->tail_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_SUBSTREAMS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) ctx->substreams = v; }
     if (const char *e = std::getenv("HRT_POSTPONE_PCT")) { const int v = std::atoi(e); if (v >= 0 && v <= 100) ctx->postpone_pct = v; }
     if (const char *e = std::getenv("HRT_REFILL_THRESHOLD")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->refill_threshold = v; }
@@ -640,7 +642,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
                 ta.hit_tuvp = w.hit_tuvp + sb.j0; ta.hit_inst = w.hit_inst + sb.j0;
                 ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
                 ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;      // Shader.cu:232, :266
-                ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct;
+                ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.tail_split = ctx->tail_split;
                 ta.count_nodes = any_hit ? &ctx->d_stats->nodes_any : &ctx->d_stats->nodes_closest;
                 ta.count_prims = any_hit ? &ctx->d_stats->prims_any : &ctx->d_stats->prims_closest;
                 { Timer tm(ctx, st, any_hit ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
@@ -759,7 +761,7 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
     TraverseArgs ta{};
     ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.rays = rays; ta.n_rays_ptr = nullptr; ta.n_rays = n_rays;
     ta.fetch_counter = fetch; ta.hit_tuvp = tuvp; ta.hit_inst = inst; ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
-    ta.tmin = tmin; ta.tmax = tmax; ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct;
+    ta.tmin = tmin; ta.tmax = tmax; ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.tail_split = ctx->tail_split;
     ta.count_nodes = any_hit ? &ctx->d_stats->nodes_any : &ctx->d_stats->nodes_closest;
     ta.count_prims = any_hit ? &ctx->d_stats->prims_any : &ctx->d_stats->prims_closest;
     const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (n_rays + 255u) / 256u);

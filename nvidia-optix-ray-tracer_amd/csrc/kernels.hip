@@ -155,7 +155,7 @@ struct TravState {
     uint32_t bprim, binst;
     uint32_t oct_inv4;
     uint2 cur;
-    int sp;
+    int sp, base;                 // stack = entries [base, sp): the bottom can be given away (tail splitting)
     uint32_t slot;
 };
 
@@ -218,8 +218,7 @@ __device__ __forceinline__ bool test_prim(const float4 *__restrict__ prims, uint
         if (!(t > tmin && t < tmax_ray)) return false;
     }
     // closest hit: min t, ties -> lowest (instance, primitive)
-    const bool has = s.bprim != kMissPrim;
-    bool better = !has || t < s.bt;
+    bool better = t < s.bt;
     if (!better && t == s.bt) {
         const uint64_t id = ((uint64_t)inst << 32) | prim, bid = ((uint64_t)s.binst << 32) | s.bprim;
         better = id < bid;
@@ -233,6 +232,10 @@ __device__ __forceinline__ bool test_prim(const float4 *__restrict__ prims, uint
 template <bool ANY_HIT, bool COUNT, bool HAS_SPHERES>
 __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     __shared__ uint2 s_stack[kLdsStack][kTraverseBlock];
+    // tail splitting: one mailbox per lane that owns a split ray (indexed by its home thread)
+    __shared__ float s_mb_t[kTraverseBlock], s_mb_u[kTraverseBlock], s_mb_v[kTraverseBlock];
+    __shared__ uint32_t s_mb_prim[kTraverseBlock], s_mb_inst[kTraverseBlock], s_mb_pending[kTraverseBlock];
+    __shared__ uint32_t s_pair[kTraverseBlock];
     uint2 spill[kSpillStack];
 
     const uint32_t n_rays = a.n_rays_ptr ? (a.n_rays_ptr[0] + a.n_rays_ptr[1] + a.n_rays_ptr[2] + a.n_rays_ptr[3]) : a.n_rays;
@@ -244,6 +247,9 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     TravState s;
     bool alive = false;
     bool exhausted = false;                 // wave-uniform
+    bool shared = false;                    // this lane works on a ray that has been split across lanes
+    uint32_t home = tx;                     // thread whose mailbox collects the split ray's result
+    const uint32_t wave_base = tx & ~63u;
     uint32_t cnt_nodes = 0, cnt_prims = 0;
 
     // wave-local slice of the queue: [wbeg, wend).  Slices of kFetchChunk rays are handed out by
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     // so one launch costs n_rays / kFetchChunk atomics spread over 8 addresses instead of one
     // atomic per refill on a single word (measured: the single word capped the kernel).
     uint32_t wbeg = 0, wend = 0;
-    const uint32_t home = blockIdx.x & (kFetchShards - 1);
+    const uint32_t home_shard = blockIdx.x & (kFetchShards - 1);
     uint32_t kstart = 0;
 
     for (;;) {
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
         if (!exhausted && (n_idle >= (uint32_t)a.refill_threshold || idle == ~0ull)) {
             if (wbeg >= wend) {
                 for (uint32_t k = kstart; k < kFetchShards && wbeg >= wend; ++k) {
-                    const uint32_t shard = (home + k) & (kFetchShards - 1);
+                    const uint32_t shard = (home_shard + k) & (kFetchShards - 1);
                     uint32_t c = 0;
                     if ((tx & 63u) == 0u) c = atomicAdd(a.fetch_counter + shard * kFetchShardStride, 1u);
                     c = (uint32_t)__shfl((int)c, 0);
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                     s.oct_inv4 = (7u - oct) * 0x01010101u;
                     s.bt = tmax_ray; s.bu = 0.0f; s.bv = 0.0f; s.bprim = kMissPrim; s.binst = kMissPrim;
                     s.cur = make_uint2(0u, 0x80000000u);
-                    s.sp = 0;
+                    s.sp = 0; s.base = 0;
                     s.slot = mine;
                     alive = true;
                 }
@@ -297,10 +303,59 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
 
         // ---- traverse until enough lanes have finished to make a refill worthwhile ----
         for (;;) {
+            // ---- tail: the queue is drained, lanes are idle and a few long rays remain.  A busy lane
+            //      gives the BOTTOM entry of its stack (the largest pending subtree) to an idle lane
+            //      of the same wave, which continues with a copy of the ray and of the best hit so
+            //      far; results are merged through an LDS mailbox when the pieces finish. ----
+            if (a.tail_split && exhausted) {
+                const uint64_t idle = __ballot(!alive);
+                const uint64_t donors = __ballot(alive && s.sp > s.base);
+                const uint32_t n_idle = (uint32_t)__popcll(idle), n_don = (uint32_t)__popcll(donors);
+                const uint32_t n_pairs = n_idle < n_don ? n_idle : n_don;
+                if (n_pairs) {
+                    const uint32_t drank = lane_prefix(donors), irank = lane_prefix(idle);
+                    const bool is_donor = alive && s.sp > s.base && drank < n_pairs;
+                    const bool is_recv = !alive && irank < n_pairs;
+                    uint2 give = make_uint2(0u, 0u);
+                    if (is_donor) {
+                        give = s.base < kLdsStack ? s_stack[s.base][tx] : spill[s.base - kLdsStack];
+                        ++s.base;
+                        if (!shared) {
+                            shared = true; home = tx;
+                            s_mb_t[tx] = s.bt; s_mb_u[tx] = s.bu; s_mb_v[tx] = s.bv; s_mb_prim[tx] = s.bprim; s_mb_inst[tx] = s.binst;
+                            s_mb_pending[tx] = 2u;
+                        } else atomicAdd(&s_mb_pending[home], 1u);
+                        s_pair[wave_base + drank] = tx & 63u;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const int src = is_recv ? (int)s_pair[wave_base + irank] : (int)(tx & 63u);
+                    // every lane shuffles; only receivers keep what they read
+                    const float r_ox = __shfl(s.ox, src), r_oy = __shfl(s.oy, src), r_oz = __shfl(s.oz, src);
+                    const float r_dx = __shfl(s.dx, src), r_dy = __shfl(s.dy, src), r_dz = __shfl(s.dz, src);
+                    const float r_ix = __shfl(s.idx, src), r_iy = __shfl(s.idy, src), r_iz = __shfl(s.idz, src);
+                    const float r_bt = __shfl(s.bt, src), r_bu = __shfl(s.bu, src), r_bv = __shfl(s.bv, src);
+                    const uint32_t r_bp = (uint32_t)__shfl((int)s.bprim, src), r_bi = (uint32_t)__shfl((int)s.binst, src);
+                    const uint32_t r_oct = (uint32_t)__shfl((int)s.oct_inv4, src), r_slot = (uint32_t)__shfl((int)s.slot, src);
+                    const uint32_t r_home = (uint32_t)__shfl((int)home, src);
+                    const uint32_t r_gx = (uint32_t)__shfl((int)give.x, src), r_gy = (uint32_t)__shfl((int)give.y, src);
+                    if (is_recv) {
+                        s.ox = r_ox; s.oy = r_oy; s.oz = r_oz; s.dx = r_dx; s.dy = r_dy; s.dz = r_dz;
+                        s.idx = r_ix; s.idy = r_iy; s.idz = r_iz;
+                        s.bt = r_bt; s.bu = r_bu; s.bv = r_bv; s.bprim = r_bp; s.binst = r_bi;
+                        s.oct_inv4 = r_oct; s.slot = r_slot;
+                        s.cur = make_uint2(r_gx, r_gy);
+                        s.sp = 0; s.base = 0;
+                        home = r_home; shared = true; alive = true;
+                    }
+                }
+            }
+
             // ---- node phase: every lane with a pending node group opens its nearest child ----
             uint2 tri = make_uint2(0u, 0u);
             bool done = false;
-            if (alive) {
+            if (ANY_HIT && alive && shared && s_mb_prim[home] != kMissPrim) done = true;   // another piece already found a hit
+            if (alive && !done) {
                 if (s.cur.y > 0x00ffffffu) {
                     const uint32_t hits_imask = s.cur.y;
                     const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
@@ -383,16 +438,39 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
             // ---- next group ----
             if (alive) {
                 if (!done && s.cur.y <= 0x00ffffffu) {
-                    if (s.sp > 0) {
+                    if (s.sp > s.base) {
                         --s.sp;
                         s.cur = s.sp < kLdsStack ? s_stack[s.sp][tx] : spill[s.sp - kLdsStack];
                     } else done = true;
                 }
-                if (done) {
+                if (done && !shared) {
                     a.hit_tuvp[s.slot] = make_float4(s.bt, s.bu, s.bv, __uint_as_float(s.bprim));
                     a.hit_inst[s.slot] = s.binst;
                     alive = false;
                 }
+            }
+            // pieces of split rays finish one lane at a time: merge into the home mailbox, the last one writes
+            uint64_t fin = __ballot(alive && done && shared);
+            while (fin) {
+                const uint32_t l = (uint32_t)__ffsll((long long)fin) - 1u;
+                fin &= fin - 1ull;
+                if ((tx & 63u) == l) {
+                    const float mt = s_mb_t[home];
+                    const uint64_t mid = ((uint64_t)s_mb_inst[home] << 32) | s_mb_prim[home];
+                    const uint64_t id = ((uint64_t)s.binst << 32) | s.bprim;
+                    const bool better = ANY_HIT ? (s.bprim != kMissPrim && s_mb_prim[home] == kMissPrim)
+                                                : (s.bt < mt || (s.bt == mt && id < mid));
+                    if (better) { s_mb_t[home] = s.bt; s_mb_u[home] = s.bu; s_mb_v[home] = s.bv; s_mb_prim[home] = s.bprim; s_mb_inst[home] = s.binst; }
+                    const uint32_t pend = s_mb_pending[home] - 1u;
+                    s_mb_pending[home] = pend;
+                    if (pend == 0u) {
+                        a.hit_tuvp[s.slot] = make_float4(s_mb_t[home], s_mb_u[home], s_mb_v[home], __uint_as_float(s_mb_prim[home]));
+                        a.hit_inst[s.slot] = s_mb_inst[home];
+                    }
+                    alive = false; shared = false; home = tx;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
             const uint64_t act = __ballot(alive);
             if (act == 0ull) break;

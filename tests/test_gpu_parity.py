@@ -96,6 +96,7 @@ def test_traverse_counts_agree_with_cpu_walk(hrt, oracle, gpu_available, monkeyp
     so the totals agree exactly; with it on (the default) they may differ by a few percent."""
     import ctypes as C
     monkeypatch.setenv("HRT_POSTPONE_PCT", "0")
+    monkeypatch.setenv("HRT_TAIL_SPLIT", "0")
     renderer = hrt.Renderer(0, hrt.CTX_COUNT)
     scene = hrt.scenes.random_soup(20000, 0.05, 3)
     renderer.load_scene(scene)
@@ -110,6 +111,7 @@ def test_traverse_counts_agree_with_cpu_walk(hrt, oracle, gpu_available, monkeyp
     assert s.node_visits == res[5] and s.prim_tests == res[6]
     renderer.close()
     monkeypatch.delenv("HRT_POSTPONE_PCT")
+    monkeypatch.delenv("HRT_TAIL_SPLIT")
     r2 = hrt.Renderer(0, hrt.CTX_COUNT)
     r2.load_scene(scene)
     r2.reset_stats()
