@@ -139,7 +139,6 @@ def main():
     nodes_per_ray = sc.node_visits_closest / max(sc.rays_closest, 1)
     prims_per_ray = sc.prim_tests_closest / max(sc.rays_closest, 1)
     bytes_per_ray = RAY_BYTES + NODE_BYTES * nodes_per_ray + PRIM_BYTES * prims_per_ray + HIT_BYTES
-
     if rank == 0:
         trav_ms = st.kernel_ms[hrt.K_TRAVERSE]
         trav_launches = max(int(st.kernel_launches[hrt.K_TRAVERSE]), 1)

@@ -121,6 +121,8 @@ typedef struct HrtStats {
     uint64_t kernel_launches[HRT_K_COUNT];
     uint64_t bvh_nodes, bvh_triangles, bvh_spheres;   /* of the TLAS last launched               */
     uint64_t bvh_bytes;
+    uint64_t debug[4];                     /* HRT_CTX_COUNT, closest-hit kernel: wave iterations, wave leaf passes,
+                                              sum of alive lanes over iterations, reserved                     */
 } HrtStats;
 
 int  hrt_stats_reset(HrtContext *ctx);

@@ -69,7 +69,7 @@ class Stats(C.Structure):
                 ("node_visits_closest", C.c_uint64), ("prim_tests_closest", C.c_uint64),
                 ("kernel_ms", C.c_double * K_COUNT), ("kernel_launches", C.c_uint64 * K_COUNT),
                 ("bvh_nodes", C.c_uint64), ("bvh_triangles", C.c_uint64), ("bvh_spheres", C.c_uint64),
-                ("bvh_bytes", C.c_uint64)]
+                ("bvh_bytes", C.c_uint64), ("debug", C.c_uint64 * 4)]
 
 
 class BvhBlob(C.Structure):

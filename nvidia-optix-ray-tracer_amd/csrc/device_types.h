@@ -57,9 +57,11 @@ struct TraverseArgs {
     const uint32_t *inst_identity;
     float tmin, tmax;
     int refill_threshold;          // refill when at least this many lanes are idle
+    uint32_t fetch_chunk;          // rays per slice a wave takes from the queue
     int tail_split;                // split long rays across idle lanes once the queue is drained
     int postpone_pct;              // leaf work is postponed while fewer than this % of the alive lanes have any
     uint64_t *count_nodes, *count_prims;
+    uint64_t *debug;               // COUNT only: [0] wave iterations, [1] wave leaf passes, [2] sum of alive lanes per iteration
 };
 
 struct BinArgs {

@@ -49,7 +49,7 @@ struct Tlas {
 struct StageCounters { uint32_t bin_count[32]; uint32_t fetch[8 * 32]; };
 static_assert(sizeof(StageCounters) == 128 + 8 * 128, "stage counters layout");
 
-struct DeviceStats { uint64_t rays_closest, rays_any, nodes_closest, prims_closest, nodes_any, prims_any; };
+struct DeviceStats { uint64_t rays_closest, rays_any, nodes_closest, prims_closest, nodes_any, prims_any; uint64_t debug[4]; };
 
 struct Workspace {
     uint32_t capacity = 0, rows_capacity = 0;
@@ -96,9 +96,10 @@ struct HrtContext {
     double kernel_ms[HRT_K_COUNT] = {0}; uint64_t kernel_launches[HRT_K_COUNT] = {0};
     float4 *d_linear = nullptr;
     int refill_threshold = 8;
-    int traverse_blocks_per_cu = 6;
+    int traverse_blocks_per_cu = 5;
     int postpone_pct = 25;
     int tail_split = 1;
+    int fetch_chunk = 64;
     int substreams = 1;                         // sub-tiles rendered on their own HIP streams so that one's tail overlaps another's bulk
     std::vector<hipStream_t> sub_streams; std::vector<hipEvent_t> sub_done; hipEvent_t ev_begin = nullptr;
 };
@@ -353,6 +354,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
         hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)) != hipSuccess)
         return fail(nullptr, HRT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(hipGetLastError()));
     if (const char *e = std::getenv("HRT_TRAVERSE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 16) ctx->traverse_blocks_per_cu = v; }
+    if (const char *e = std::getenv("HRT_FETCH_CHUNK")) { const int v = std::atoi(e); if (v >= 8 && v <= 4096) ctx->fetch_chunk = v; }
     if (const char *e = std::getenv("HRT_TAIL_SPLIT")) ctx->tail_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_SUBSTREAMS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) ctx->substreams = v; }
     if (const char *e = std::getenv("HRT_POSTPONE_PCT")) { const int v = std::atoi(e); if (v >= 0 && v <= 100) ctx->postpone_pct = v; }
@@ -642,9 +644,10 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
                 ta.hit_tuvp = w.hit_tuvp + sb.j0; ta.hit_inst = w.hit_inst + sb.j0;
                 ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
                 ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;      // Shader.cu:232, :266
-                ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.tail_split = ctx->tail_split;
+                ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fetch_chunk;
                 ta.count_nodes = any_hit ? &ctx->d_stats->nodes_any : &ctx->d_stats->nodes_closest;
                 ta.count_prims = any_hit ? &ctx->d_stats->prims_any : &ctx->d_stats->prims_closest;
+                ta.debug = any_hit ? nullptr : ctx->d_stats->debug;
                 { Timer tm(ctx, st, any_hit ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
                   launch_traverse(ta, any_hit, count, t->has_spheres, sb.grid_trav, st); }
 
@@ -731,6 +734,7 @@ int hrt_stats_get(HrtContext *ctx, HrtStats *out) {
     out->rays_closest = ds.rays_closest; out->rays_any = ds.rays_any; out->rays = ds.rays_closest + ds.rays_any;
     out->paths = ctx->paths; out->node_visits = ds.nodes_closest + ds.nodes_any; out->prim_tests = ds.prims_closest + ds.prims_any;
     out->node_visits_closest = ds.nodes_closest; out->prim_tests_closest = ds.prims_closest;
+    for (int k = 0; k < 4; ++k) out->debug[k] = ds.debug[k];
     for (int k = 0; k < HRT_K_COUNT; ++k) { out->kernel_ms[k] = ctx->kernel_ms[k]; out->kernel_launches[k] = ctx->kernel_launches[k]; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     auto it = ctx->tlas.find(ctx->last_tlas);
@@ -761,9 +765,10 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
     TraverseArgs ta{};
     ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.rays = rays; ta.n_rays_ptr = nullptr; ta.n_rays = n_rays;
     ta.fetch_counter = fetch; ta.hit_tuvp = tuvp; ta.hit_inst = inst; ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
-    ta.tmin = tmin; ta.tmax = tmax; ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.tail_split = ctx->tail_split;
+    ta.tmin = tmin; ta.tmax = tmax; ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fetch_chunk;
     ta.count_nodes = any_hit ? &ctx->d_stats->nodes_any : &ctx->d_stats->nodes_closest;
     ta.count_prims = any_hit ? &ctx->d_stats->prims_any : &ctx->d_stats->prims_closest;
+    ta.debug = any_hit ? nullptr : ctx->d_stats->debug;
     const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (n_rays + 255u) / 256u);
     { Timer tm(ctx, s, any_hit ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
       launch_traverse(ta, any_hit != 0, (ctx->flags & HRT_CTX_COUNT) != 0, t->has_spheres, grid, s); }

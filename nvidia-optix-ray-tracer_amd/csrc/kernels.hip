@@ -144,7 +144,6 @@ __global__ __launch_bounds__(256) void k_generate(GenerateArgs a) {
 constexpr int kLdsStack = 8;          // entries per lane staged in LDS
 constexpr int kSpillStack = 56;       // overflow entries per lane in scratch
 constexpr int kTraverseBlock = 256;
-constexpr uint32_t kFetchChunk = 128;        // rays per slice handed to a wave
 constexpr uint32_t kFetchShards = 8;         // slice counters (one per XCD-group of blocks)
 constexpr uint32_t kFetchShardStride = 32;   // u32s between counters: one 128-byte line each
 
@@ -155,6 +154,7 @@ struct TravState {
     uint32_t bprim, binst;
     uint32_t oct_inv4;
     uint2 cur;
+    uint2 ptri;                   // leaf group being consumed, one primitive per iteration
     int sp, base;                 // stack = entries [base, sp): the bottom can be given away (tail splitting)
     uint32_t slot;
 };
@@ -167,12 +167,9 @@ __device__ __forceinline__ float safe_rcp_dir(float d) {
 
 // canonical primitive test (DESIGN.md "canonical intersector"); updates the best hit.
 template <bool HAS_SPHERES>
-__device__ __forceinline__ bool test_prim(const float4 *__restrict__ prims, uint32_t pi, TravState &s,
+__device__ __forceinline__ bool test_prim(const float4 A, const float4 B, const float4 C, TravState &s,
                                           float tmin, float tmax_ray,
                                           const float *__restrict__ inst_inv, const uint32_t *__restrict__ inst_identity) {
-    const float4 A = prims[3 * (size_t)pi + 0];
-    const float4 B = prims[3 * (size_t)pi + 1];
-    const float4 C = prims[3 * (size_t)pi + 2];
     float t, u = 0.0f, v = 0.0f;
     uint32_t prim = __float_as_uint(A.w), inst;
     const V3 o = mk3(s.ox, s.oy, s.oz), d = mk3(s.dx, s.dy, s.dz);
@@ -229,6 +226,39 @@ __device__ __forceinline__ bool test_prim(const float4 *__restrict__ prims, uint
 
 #define HRT_BYTE_F(w, k) ((float)(((w) >> (8 * (k))) & 0xffu))
 
+// ---- hand-placed loads of the traversal pipeline ---------------------------------------------
+// hipcc waits for a load at the first instruction that touches its destination -- including the
+// register copies it makes when a load sits under an exec mask or merges with another value --
+// which serialised "issue primitive loads, issue node loads, test primitive, open node".  The
+// eight loads of one iteration are therefore issued from asm statements and waited for with
+// hand-counted vmcnt: the primitive (3 loads, issued first) needs vmcnt(5), the node vmcnt(0).
+// VMEM operations the compiler adds around them (scratch, stores) are counted by the hardware
+// in the same in-order queue, so they can only make these waits longer, never too short.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void issue_prim_loads(const void *p, f32x4 &a, f32x4 &b, f32x4 &c) {
+    asm volatile("global_load_dwordx4 %0, %3, off\n\t"
+                 "global_load_dwordx4 %1, %3, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:32"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void issue_node_loads(const void *p, u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, u32x4 &e) {
+    asm volatile("global_load_dwordx4 %0, %5, off\n\t"
+                 "global_load_dwordx4 %1, %5, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %5, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %5, off offset:48\n\t"
+                 "global_load_dwordx4 %4, %5, off offset:64"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e) : "v"(p) : "memory");
+}
+// the data registers are in/out operands so that no use can be scheduled above the wait
+__device__ __forceinline__ void wait_prim_loads(f32x4 &a, f32x4 &b, f32x4 &c) {
+    asm volatile("s_waitcnt vmcnt(5)" : "+v"(a), "+v"(b), "+v"(c) :: "memory");
+}
+__device__ __forceinline__ void wait_node_loads(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, u32x4 &e) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) :: "memory");
+}
+
 template <bool ANY_HIT, bool COUNT, bool HAS_SPHERES>
 __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     __shared__ uint2 s_stack[kLdsStack][kTraverseBlock];
@@ -252,9 +282,54 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     const uint32_t wave_base = tx & ~63u;
     uint32_t cnt_nodes = 0, cnt_prims = 0;
 
-    // wave-local slice of the queue: [wbeg, wend).  Slices of kFetchChunk rays are handed out by
-    // kFetchShards counters (chunk c of shard s covers rays (c * kFetchShards + s) * kFetchChunk ...),
-    // so one launch costs n_rays / kFetchChunk atomics spread over 8 addresses instead of one
+    // Software pipeline: the loads of the NEXT node (n0..n4) and of the primitive tested in this
+    // iteration (pa..pc) are issued together, primitive first, right after the current node has
+    // been processed; the leaf test then waits only for the primitive (vmcnt leaves the five
+    // younger node loads in flight) and the next node phase for the node.  One iteration exposes
+    // max(node, primitive) latency instead of their sum.
+    u32x4 n0 = {0u, 0u, 0u, 0u}, n1 = n0, n2 = n0, n3 = n0, n4 = n0;
+    bool has_node = false;                  // n0..n4 hold (or will hold) the node to open next
+
+    // pop the next node group / leaf group from the stack as needed, then take the nearest child
+    // of the node group in hand.  Returns the index of the node to load (has_node tells if any).
+    auto advance_select = [&]() -> uint32_t {
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            if (s.cur.y <= 0x00ffffffu && s.sp > s.base) {
+                const uint2 top = (s.sp - 1) < kLdsStack ? s_stack[s.sp - 1][tx] : spill[s.sp - 1 - kLdsStack];
+                if (top.y > 0x00ffffffu) { s.cur = top; --s.sp; }
+                else if (s.ptri.y == 0u) { s.ptri = top; --s.sp; }
+            }
+        }
+        uint32_t idx = 0u;
+        if (s.cur.y > 0x00ffffffu) {
+            const uint32_t hits_imask = s.cur.y;
+            const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
+            s.cur.y &= ~(1u << bit);
+            const uint32_t slot_index = (bit - 24u) ^ (s.oct_inv4 & 0xffu);
+            const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot_index));
+            idx = s.cur.x + rel;
+            if (s.cur.y > 0x00ffffffu) {            // siblings still to visit: keep them on the stack
+                if (s.sp < kLdsStack) s_stack[s.sp][tx] = s.cur; else spill[s.sp - kLdsStack] = s.cur;
+                ++s.sp;
+            }
+            s.cur = make_uint2(0u, 0u);
+            has_node = true;
+        } else has_node = false;
+        return idx;
+    };
+    // divergent form for the rare paths (refill, split): select and load at once
+    auto advance = [&]() {
+        const uint32_t idx = advance_select();
+        if (has_node) {
+            const u32x4 *np = reinterpret_cast<const u32x4 *>(nodes + 5 * (size_t)idx);
+            n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
+        }
+    };
+
+    // wave-local slice of the queue: [wbeg, wend).  Slices of fetch_chunk rays are handed out by
+    // kFetchShards counters (chunk c of shard s covers rays (c * kFetchShards + s) * fetch_chunk ...),
+    // so one launch costs n_rays / fetch_chunk atomics spread over 8 addresses instead of one
     // atomic per refill on a single word (measured: the single word capped the kernel).
     uint32_t wbeg = 0, wend = 0;
     const uint32_t home_shard = blockIdx.x & (kFetchShards - 1);
@@ -271,10 +346,10 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                     uint32_t c = 0;
                     if ((tx & 63u) == 0u) c = atomicAdd(a.fetch_counter + shard * kFetchShardStride, 1u);
                     c = (uint32_t)__shfl((int)c, 0);
-                    const uint64_t beg = ((uint64_t)c * kFetchShards + shard) * kFetchChunk;
+                    const uint64_t beg = ((uint64_t)c * kFetchShards + shard) * (uint64_t)a.fetch_chunk;
                     if (beg < (uint64_t)n_rays) {
                         wbeg = (uint32_t)beg;
-                        wend = (uint32_t)(beg + kFetchChunk < (uint64_t)n_rays ? beg + kFetchChunk : (uint64_t)n_rays);
+                        wend = (uint32_t)(beg + a.fetch_chunk < (uint64_t)n_rays ? beg + a.fetch_chunk : (uint64_t)n_rays);
                     } else kstart = k + 1;             // this shard is drained for good
                 }
                 if (wbeg >= wend) exhausted = true;
@@ -293,9 +368,11 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                     s.oct_inv4 = (7u - oct) * 0x01010101u;
                     s.bt = tmax_ray; s.bu = 0.0f; s.bv = 0.0f; s.bprim = kMissPrim; s.binst = kMissPrim;
                     s.cur = make_uint2(0u, 0x80000000u);
+                    s.ptri = make_uint2(0u, 0u);
                     s.sp = 0; s.base = 0;
                     s.slot = mine;
                     alive = true;
+                    advance();                          // issues the root's loads
                 }
             }
         }
@@ -307,13 +384,13 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
             //      gives the BOTTOM entry of its stack (the largest pending subtree) to an idle lane
             //      of the same wave, which continues with a copy of the ray and of the best hit so
             //      far; results are merged through an LDS mailbox when the pieces finish. ----
-            if (a.tail_split && exhausted) {
-                const uint64_t idle = __ballot(!alive);
+            if (!COUNT && a.tail_split && exhausted) {
+                const uint64_t idle2 = __ballot(!alive);
                 const uint64_t donors = __ballot(alive && s.sp > s.base);
-                const uint32_t n_idle = (uint32_t)__popcll(idle), n_don = (uint32_t)__popcll(donors);
-                const uint32_t n_pairs = n_idle < n_don ? n_idle : n_don;
+                const uint32_t n_idle2 = (uint32_t)__popcll(idle2), n_don = (uint32_t)__popcll(donors);
+                const uint32_t n_pairs = n_idle2 < n_don ? n_idle2 : n_don;
                 if (n_pairs) {
-                    const uint32_t drank = lane_prefix(donors), irank = lane_prefix(idle);
+                    const uint32_t drank = lane_prefix(donors), irank = lane_prefix(idle2);
                     const bool is_donor = alive && s.sp > s.base && drank < n_pairs;
                     const bool is_recv = !alive && irank < n_pairs;
                     uint2 give = make_uint2(0u, 0u);
@@ -344,109 +421,127 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                         s.idx = r_ix; s.idy = r_iy; s.idz = r_iz;
                         s.bt = r_bt; s.bu = r_bu; s.bv = r_bv; s.bprim = r_bp; s.binst = r_bi;
                         s.oct_inv4 = r_oct; s.slot = r_slot;
-                        s.cur = make_uint2(r_gx, r_gy);
+                        if (r_gy > 0x00ffffffu) { s.cur = make_uint2(r_gx, r_gy); s.ptri = make_uint2(0u, 0u); }
+                        else { s.cur = make_uint2(0u, 0u); s.ptri = make_uint2(r_gx, r_gy); }
                         s.sp = 0; s.base = 0;
                         home = r_home; shared = true; alive = true;
+                        advance();
                     }
                 }
             }
 
-            // ---- node phase: every lane with a pending node group opens its nearest child ----
-            uint2 tri = make_uint2(0u, 0u);
             bool done = false;
             if (ANY_HIT && alive && shared && s_mb_prim[home] != kMissPrim) done = true;   // another piece already found a hit
-            if (alive && !done) {
-                if (s.cur.y > 0x00ffffffu) {
-                    const uint32_t hits_imask = s.cur.y;
-                    const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
-                    s.cur.y &= ~(1u << bit);
-                    if (s.cur.y > 0x00ffffffu) {
-                        if (s.sp < kLdsStack) s_stack[s.sp][tx] = s.cur; else spill[s.sp - kLdsStack] = s.cur;
-                        ++s.sp;
-                    }
-                    const uint32_t slot_index = (bit - 24u) ^ (s.oct_inv4 & 0xffu);
-                    const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot_index));
-                    const uint4 *np = nodes + 5 * (size_t)(s.cur.x + rel);
-                    const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
-                    if (COUNT) ++cnt_nodes;
 
-                    const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
-                    const uint32_t e_imask = n0.w;
-                    const float aix = __uint_as_float((e_imask & 0xffu) << 23) * s.idx;
-                    const float aiy = __uint_as_float(((e_imask >> 8) & 0xffu) << 23) * s.idy;
-                    const float aiz = __uint_as_float(((e_imask >> 16) & 0xffu) << 23) * s.idz;
-                    const float aox = (px - s.ox) * s.idx, aoy = (py - s.oy) * s.idy, aoz = (pz - s.oz) * s.idz;
-                    const bool nx = s.dx < 0.0f, ny = s.dy < 0.0f, nz = s.dz < 0.0f;
-                    uint32_t hitmask = 0u;
+            // ---- A. node phase: process the node whose loads were issued last iteration ----
+            uint2 tri = make_uint2(0u, 0u);
+            wait_node_loads(n0, n1, n2, n3, n4);
+            if (alive && !done && has_node) {
+                if (COUNT) ++cnt_nodes;
+                const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
+                const uint32_t e_imask = n0.w;
+                const float aix = __uint_as_float((e_imask & 0xffu) << 23) * s.idx;
+                const float aiy = __uint_as_float(((e_imask >> 8) & 0xffu) << 23) * s.idy;
+                const float aiz = __uint_as_float(((e_imask >> 16) & 0xffu) << 23) * s.idz;
+                const float aox = (px - s.ox) * s.idx, aoy = (py - s.oy) * s.idy, aoz = (pz - s.oz) * s.idz;
+                const bool nx = s.dx < 0.0f, ny = s.dy < 0.0f, nz = s.dz < 0.0f;
+                uint32_t hitmask = 0u;
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const uint32_t meta4 = h ? n1.w : n1.z;
-                        const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-                        const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
-                        const uint32_t bit_index4 = (meta4 ^ (s.oct_inv4 & inner_mask4)) & 0x1f1f1f1fu;
-                        const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
-                        const uint32_t qlox = h ? n2.y : n2.x, qloy = h ? n2.w : n2.z, qloz = h ? n3.y : n3.x;
-                        const uint32_t qhix = h ? n3.w : n3.z, qhiy = h ? n4.y : n4.x, qhiz = h ? n4.w : n4.z;
-                        const uint32_t xn = nx ? qhix : qlox, xf = nx ? qlox : qhix;
-                        const uint32_t yn = ny ? qhiy : qloy, yf = ny ? qloy : qhiy;
-                        const uint32_t zn = nz ? qhiz : qloz, zf = nz ? qloz : qhiz;
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t meta4 = h ? n1.w : n1.z;
+                    const uint32_t is_inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+                    const uint32_t inner_mask4 = (is_inner4 >> 4) * 0xffu;
+                    const uint32_t bit_index4 = (meta4 ^ (s.oct_inv4 & inner_mask4)) & 0x1f1f1f1fu;
+                    const uint32_t child_bits4 = (meta4 >> 5) & 0x07070707u;
+                    const uint32_t qlox = h ? n2.y : n2.x, qloy = h ? n2.w : n2.z, qloz = h ? n3.y : n3.x;
+                    const uint32_t qhix = h ? n3.w : n3.z, qhiy = h ? n4.y : n4.x, qhiz = h ? n4.w : n4.z;
+                    const uint32_t xn = nx ? qhix : qlox, xf = nx ? qlox : qhix;
+                    const uint32_t yn = ny ? qhiy : qloy, yf = ny ? qloy : qhiy;
+                    const uint32_t zn = nz ? qhiz : qloz, zf = nz ? qloz : qhiz;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float tnx = fmaf(HRT_BYTE_F(xn, j), aix, aox), tfx = fmaf(HRT_BYTE_F(xf, j), aix, aox);
-                            const float tny = fmaf(HRT_BYTE_F(yn, j), aiy, aoy), tfy = fmaf(HRT_BYTE_F(yf, j), aiy, aoy);
-                            const float tnz = fmaf(HRT_BYTE_F(zn, j), aiz, aoz), tfz = fmaf(HRT_BYTE_F(zf, j), aiz, aoz);
-                            const float tlo = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
-                            const float thi = fminf(fminf(tfx, tfy), fminf(tfz, s.bt));
-                            const uint32_t cb = (child_bits4 >> (8 * j)) & 0xffu;
-                            const uint32_t bi = (bit_index4 >> (8 * j)) & 0xffu;
-                            // conservative: the builder pads and rounds the child boxes outwards
-                            if (tlo <= thi) hitmask |= cb << bi;
-                        }
+                    for (int j = 0; j < 4; ++j) {
+                        const float tnx = fmaf(HRT_BYTE_F(xn, j), aix, aox), tfx = fmaf(HRT_BYTE_F(xf, j), aix, aox);
+                        const float tny = fmaf(HRT_BYTE_F(yn, j), aiy, aoy), tfy = fmaf(HRT_BYTE_F(yf, j), aiy, aoy);
+                        const float tnz = fmaf(HRT_BYTE_F(zn, j), aiz, aoz), tfz = fmaf(HRT_BYTE_F(zf, j), aiz, aoz);
+                        const float tlo = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+                        const float thi = fminf(fminf(tfx, tfy), fminf(tfz, s.bt));
+                        const uint32_t cb = (child_bits4 >> (8 * j)) & 0xffu;
+                        const uint32_t bi = (bit_index4 >> (8 * j)) & 0xffu;
+                        // conservative: the builder pads and rounds the child boxes outwards
+                        if (tlo <= thi) hitmask |= cb << bi;
                     }
-                    s.cur = make_uint2(n1.x, (hitmask & 0xff000000u) | (e_imask >> 24));
-                    tri = make_uint2(n1.y, hitmask & 0x00ffffffu);
-                } else {
-                    tri = s.cur;                    // a postponed leaf group came back from the stack
-                    s.cur = make_uint2(0u, 0u);
                 }
+                s.cur = make_uint2(n1.x, (hitmask & 0xff000000u) | (e_imask >> 24));
+                tri = make_uint2(n1.y, hitmask & 0x00ffffffu);
+                has_node = false;
             }
 
-            // ---- leaf phase, wave-uniform: test one primitive per lane and pass; when too few
-            //      lanes have leaf work the groups are postponed (pushed) so that the wave goes
-            //      back to nodes instead of idling 80 % of its lanes (Ylitie et al. 2017, sec. 4.3) ----
-            const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
-            for (;;) {
-                const uint64_t m = __ballot(alive && !done && tri.y != 0u);
-                if (m == 0ull) break;
-                if ((uint32_t)__popcll(m) * 100u < n_alive * (uint32_t)a.postpone_pct) {
-                    if (alive && !done && tri.y != 0u) {
-                        if (s.sp < kLdsStack) s_stack[s.sp][tx] = tri; else spill[s.sp - kLdsStack] = tri;
-                        ++s.sp;
-                        tri.y = 0u;
-                    }
-                    break;
-                }
-                if (alive && !done && tri.y != 0u) {
+            // COUNT builds walk in the canonical order (every leaf of a node is tested before the next
+            // node is chosen, no postponing, no splitting): the counters then equal a CPU walk of the
+            // same BVH bytes and define the algorithmic traffic per ray.
+            if (COUNT) {
+                while (alive && !done && tri.y != 0u) {
                     const uint32_t k = (uint32_t)__ffs((int)tri.y) - 1u;
                     tri.y &= tri.y - 1u;
-                    if (COUNT) ++cnt_prims;
-                    const bool better = test_prim<HAS_SPHERES>(prims, tri.x + k, s, tmin, tmax_ray, a.inst_inv, a.inst_identity);
+                    ++cnt_prims;
+                    const float4 *pp = prims + 3 * (size_t)(tri.x + k);
+                    const bool better = test_prim<HAS_SPHERES>(pp[0], pp[1], pp[2], s, tmin, tmax_ray, a.inst_inv, a.inst_identity);
                     if (ANY_HIT && better) done = true;
                 }
             }
 
-            // ---- next group ----
-            if (alive) {
-                if (!done && s.cur.y <= 0x00ffffffu) {
-                    if (s.sp > s.base) {
-                        --s.sp;
-                        s.cur = s.sp < kLdsStack ? s_stack[s.sp][tx] : spill[s.sp - kLdsStack];
-                    } else done = true;
+            // ---- B. bookkeeping + issue of the next loads (primitive first, then the next node) ----
+            if (alive && !done && tri.y != 0u) {
+                if (s.ptri.y == 0u) s.ptri = tri;
+                else {
+                    if (s.sp < kLdsStack) s_stack[s.sp][tx] = tri; else spill[s.sp - kLdsStack] = tri;
+                    ++s.sp;
                 }
+            }
+            const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
+            // leaf pass: ONE per iteration, one primitive per lane out of its pending leaf group.  It
+            // is skipped (wave-uniform) while few lanes have leaf work and none depends on it.
+            bool has_prim = false, do_pass = false;
+            uint32_t pidx = 0u;
+            {
+                const bool has = alive && !done && s.ptri.y != 0u;
+                const uint64_t m = __ballot(has);
+                const uint64_t must = __ballot(has && s.cur.y <= 0x00ffffffu);     // no node work in hand
+                do_pass = m != 0ull && (must != 0ull || (uint32_t)__popcll(m) * 100u >= n_alive * (uint32_t)a.postpone_pct);
+                if (do_pass) {
+                    if (has) {
+                        const uint32_t k = (uint32_t)__ffs((int)s.ptri.y) - 1u;
+                        s.ptri.y &= s.ptri.y - 1u;
+                        pidx = s.ptri.x + k;
+                    }
+                    has_prim = has;
+                }
+            }
+            // all stack traffic (LDS, and scratch for the overflow part -- scratch shares vmcnt with
+            // the global loads) happens BEFORE the loads are issued
+            uint32_t nidx = 0u;
+            if (alive && !done) nidx = advance_select();
+            // the loads are unconditional (every lane, index 0 when a lane has nothing to load) and
+            // hand-issued: primitive first, node second (see issue_prim_loads)
+            f32x4 pa, pb, pc;
+            issue_prim_loads(prims + 3 * (size_t)pidx, pa, pb, pc);
+            issue_node_loads(nodes + 5 * (size_t)nidx, n0, n1, n2, n3, n4);
+
+            // ---- C. leaf test (waits for the primitive only) ----
+            wait_prim_loads(pa, pb, pc);
+            if (has_prim) {
+                const bool better = test_prim<HAS_SPHERES>(make_float4(pa.x, pa.y, pa.z, pa.w), make_float4(pb.x, pb.y, pb.z, pb.w),
+                                                           make_float4(pc.x, pc.y, pc.z, pc.w), s, tmin, tmax_ray, a.inst_inv, a.inst_identity);
+                if (ANY_HIT && better) done = true;
+            }
+
+            // ---- finished? ----
+            if (alive) {
+                if (!done && !has_node && s.ptri.y == 0u) done = true;
                 if (done && !shared) {
                     a.hit_tuvp[s.slot] = make_float4(s.bt, s.bu, s.bv, __uint_as_float(s.bprim));
                     a.hit_inst[s.slot] = s.binst;
-                    alive = false;
+                    alive = false; has_node = false;
                 }
             }
             // pieces of split rays finish one lane at a time: merge into the home mailbox, the last one writes
@@ -467,7 +562,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                         a.hit_tuvp[s.slot] = make_float4(s_mb_t[home], s_mb_u[home], s_mb_v[home], __uint_as_float(s_mb_prim[home]));
                         a.hit_inst[s.slot] = s_mb_inst[home];
                     }
-                    alive = false; shared = false; home = tx;
+                    alive = false; shared = false; home = tx; has_node = false;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
