@@ -95,8 +95,8 @@ struct HrtContext {
     std::vector<TimedSpan> spans; std::vector<hipEvent_t> event_pool; size_t events_used = 0;
     double kernel_ms[HRT_K_COUNT] = {0}; uint64_t kernel_launches[HRT_K_COUNT] = {0};
     float4 *d_linear = nullptr;
-    int refill_threshold = 8;
-    int traverse_blocks_per_cu = 5;
+    int refill_threshold = 16;
+    int traverse_blocks_per_cu = 12;            // one-wave workgroups of the traverse kernel per CU
     int postpone_pct = 25;
     int tail_split = 1;
     int fetch_chunk = 64;
@@ -353,7 +353,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
         hipMalloc((void **)&ctx->d_stats, sizeof(DeviceStats)) != hipSuccess ||
         hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)) != hipSuccess)
         return fail(nullptr, HRT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(hipGetLastError()));
-    if (const char *e = std::getenv("HRT_TRAVERSE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 16) ctx->traverse_blocks_per_cu = v; }
+    if (const char *e = std::getenv("HRT_TRAVERSE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) ctx->traverse_blocks_per_cu = v; }
     if (const char *e = std::getenv("HRT_FETCH_CHUNK")) { const int v = std::atoi(e); if (v >= 8 && v <= 4096) ctx->fetch_chunk = v; }
     if (const char *e = std::getenv("HRT_TAIL_SPLIT")) ctx->tail_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_SUBSTREAMS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) ctx->substreams = v; }
@@ -618,7 +618,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         subs[k].j0 = j0; subs[k].n = j1 - j0; subs[k].st = S > 1 ? ctx->sub_streams[k] : s;
         subs[k].stages = w.stages + (size_t)k * (kRayTraceDepth + 1);
         subs[k].grid_wide = std::min<uint32_t>((uint32_t)ctx->n_cu * 8u, (subs[k].n + 255u) / 256u);
-        subs[k].grid_trav = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (subs[k].n + 255u) / 256u);
+        subs[k].grid_trav = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (subs[k].n + 63u) / 64u);
     }
 
     for (uint32_t sample = 0; sample < spp; ++sample) {
@@ -769,7 +769,7 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
     ta.count_nodes = any_hit ? &ctx->d_stats->nodes_any : &ctx->d_stats->nodes_closest;
     ta.count_prims = any_hit ? &ctx->d_stats->prims_any : &ctx->d_stats->prims_closest;
     ta.debug = any_hit ? nullptr : ctx->d_stats->debug;
-    const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (n_rays + 255u) / 256u);
+    const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (n_rays + 63u) / 64u);
     { Timer tm(ctx, s, any_hit ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
       launch_traverse(ta, any_hit != 0, (ctx->flags & HRT_CTX_COUNT) != 0, t->has_spheres, grid, s); }
     launch_unpack_hits(tuvp, inst, n_rays, d_t, d_u, d_v, d_prim, d_inst, s);

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_generate(GenerateArgs a) {
 // ---------------------------------------------------------------------------------------
 constexpr int kLdsStack = 8;          // entries per lane staged in LDS
 constexpr int kSpillStack = 56;       // overflow entries per lane in scratch
-constexpr int kTraverseBlock = 256;
+constexpr int kTraverseBlock = 64;         // one wave per workgroup
 constexpr uint32_t kFetchShards = 8;         // slice counters (one per XCD-group of blocks)
 constexpr uint32_t kFetchShardStride = 32;   // u32s between counters: one 128-byte line each
 
@@ -226,73 +226,86 @@ __device__ __forceinline__ bool test_prim(const float4 A, const float4 B, const 
 
 #define HRT_BYTE_F(w, k) ((float)(((w) >> (8 * (k))) & 0xffu))
 
-// ---- hand-placed loads of the traversal pipeline ---------------------------------------------
-// hipcc waits for a load at the first instruction that touches its destination -- including the
-// register copies it makes when a load sits under an exec mask or merges with another value --
-// which serialised "issue primitive loads, issue node loads, test primitive, open node".  The
-// eight loads of one iteration are therefore issued from asm statements and waited for with
-// hand-counted vmcnt: the primitive (3 loads, issued first) needs vmcnt(5), the node vmcnt(0).
-// VMEM operations the compiler adds around them (scratch, stores) are counted by the hardware
-// in the same in-order queue, so they can only make these waits longer, never too short.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void issue_prim_loads(const void *p, f32x4 &a, f32x4 &b, f32x4 &c) {
-    asm volatile("global_load_dwordx4 %0, %3, off\n\t"
-                 "global_load_dwordx4 %1, %3, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %3, off offset:32"
-                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(p) : "memory");
+// ---- cooperative gathers of the traversal pipeline ------------------------------------------------
+// One ray per lane means 64 unrelated 80-byte nodes (and 48-byte primitives) per wave and step.
+// Loaded lane by lane (5 + 3 dwordx4 per lane) that is 8 wave-instructions x 64 separate L1
+// look-ups; measured, this address divergence -- not HBM, not L2 -- bounded the kernel (83 G
+// steps/s on a 20 KB tree against 232 G with identical rays).  Instead the wave gathers the 64
+// nodes with 5 LDS-DMA instructions (global_load_lds_dwordx4): LDS byte x of the 5120-byte
+// staging image belongs to node slot x / 80, so lanes 5k..5k+4 of an instruction read the five
+// consecutive 16-byte pieces of ONE node -- coalesced into one or two line look-ups -- and the
+// data lands in LDS at wave base + 16 * lane, i.e. already as [slot][piece].  Each lane then
+// reads its own slot back with ds_read_b128 (stride 80 B / 48 B is bank-conflict-free).
+// The asm has no VGPR destination, so nothing can be read before it has landed except through
+// LDS, and the two waits below carry a "memory" clobber: register-safe.  vmcnt is counted by
+// hand: primitive pieces (3) are issued first, node pieces (5) second, so the primitive needs
+// vmcnt(5) and the node vmcnt(0); VMEM operations the compiler adds can only lengthen the waits.
+__device__ __forceinline__ void gather_node_pieces(uint32_t lds_base, const void *p0, const void *p1, const void *p2,
+                                                   const void *p3, const void *p4) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "s"(lds_base) : "memory", "scc");
 }
-__device__ __forceinline__ void issue_node_loads(const void *p, u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, u32x4 &e) {
-    asm volatile("global_load_dwordx4 %0, %5, off\n\t"
-                 "global_load_dwordx4 %1, %5, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %5, off offset:32\n\t"
-                 "global_load_dwordx4 %3, %5, off offset:48\n\t"
-                 "global_load_dwordx4 %4, %5, off offset:64"
-                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e) : "v"(p) : "memory");
+__device__ __forceinline__ void gather_prim_pieces(uint32_t lds_base, const void *p0, const void *p1, const void *p2) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(p0), "v"(p1), "v"(p2), "s"(lds_base) : "memory", "scc");
 }
-// the data registers are in/out operands so that no use can be scheduled above the wait
-__device__ __forceinline__ void wait_prim_loads(f32x4 &a, f32x4 &b, f32x4 &c) {
-    asm volatile("s_waitcnt vmcnt(5)" : "+v"(a), "+v"(b), "+v"(c) :: "memory");
-}
-__device__ __forceinline__ void wait_node_loads(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, u32x4 &e) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) :: "memory");
-}
+__device__ __forceinline__ void wait_prim_gather() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+__device__ __forceinline__ void wait_node_gather() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <bool ANY_HIT, bool COUNT, bool HAS_SPHERES>
 __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
+    static_assert(kTraverseBlock == 64, "one wave per workgroup: staging images and mailboxes are per wave");
     __shared__ uint2 s_stack[kLdsStack][kTraverseBlock];
-    // tail splitting: one mailbox per lane that owns a split ray (indexed by its home thread)
+    __shared__ uint4 s_node_stage[5 * 64];          // 64 node slots x 80 B, filled by LDS-DMA
+    __shared__ uint4 s_prim_stage[3 * 64];          // 64 primitive slots x 48 B
+    // tail splitting: one mailbox per lane that owns a split ray (indexed by its home lane)
     __shared__ float s_mb_t[kTraverseBlock], s_mb_u[kTraverseBlock], s_mb_v[kTraverseBlock];
     __shared__ uint32_t s_mb_prim[kTraverseBlock], s_mb_inst[kTraverseBlock], s_mb_pending[kTraverseBlock];
     __shared__ uint32_t s_pair[kTraverseBlock];
     uint2 spill[kSpillStack];
 
     const uint32_t n_rays = a.n_rays_ptr ? (a.n_rays_ptr[0] + a.n_rays_ptr[1] + a.n_rays_ptr[2] + a.n_rays_ptr[3]) : a.n_rays;
-    const uint4 *__restrict__ nodes = reinterpret_cast<const uint4 *>(a.nodes);
+    const char *__restrict__ node_bytes = reinterpret_cast<const char *>(a.nodes);
+    const char *__restrict__ prim_bytes = reinterpret_cast<const char *>(a.prims);
     const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(a.prims);
     const float tmin = a.tmin, tmax_ray = a.tmax;
-    const uint32_t tx = threadIdx.x;
+    const uint32_t tx = threadIdx.x;                // = lane
+
+    // gather geometry: in DMA instruction i this lane fetches piece g_off[i] of the slot owned by lane g_own[i]
+    uint32_t gn_own[5], gn_off[5], gp_own[3], gp_off[3];
+#pragma unroll
+    for (uint32_t i = 0; i < 5; ++i) { const uint32_t x = 64u * i + tx; gn_own[i] = x / 5u; gn_off[i] = (x % 5u) * 16u; }
+#pragma unroll
+    for (uint32_t i = 0; i < 3; ++i) { const uint32_t x = 64u * i + tx; gp_own[i] = x / 3u; gp_off[i] = (x % 3u) * 16u; }
+    const uint32_t node_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)reinterpret_cast<uintptr_t>(&s_node_stage[0]));
+    const uint32_t prim_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)reinterpret_cast<uintptr_t>(&s_prim_stage[0]));
 
     TravState s;
     bool alive = false;
     bool exhausted = false;                 // wave-uniform
     bool shared = false;                    // this lane works on a ray that has been split across lanes
-    uint32_t home = tx;                     // thread whose mailbox collects the split ray's result
-    const uint32_t wave_base = tx & ~63u;
+    uint32_t home = tx;                     // lane whose mailbox collects the split ray's result
     uint32_t cnt_nodes = 0, cnt_prims = 0;
 
-    // Software pipeline: the loads of the NEXT node (n0..n4) and of the primitive tested in this
-    // iteration (pa..pc) are issued together, primitive first, right after the current node has
-    // been processed; the leaf test then waits only for the primitive (vmcnt leaves the five
-    // younger node loads in flight) and the next node phase for the node.  One iteration exposes
-    // max(node, primitive) latency instead of their sum.
-    u32x4 n0 = {0u, 0u, 0u, 0u}, n1 = n0, n2 = n0, n3 = n0, n4 = n0;
-    bool has_node = false;                  // n0..n4 hold (or will hold) the node to open next
+    // what the next iteration gathers for this lane
+    bool has_node = false, has_prim = false;
+    uint32_t nidx = 0u, pidx = 0u;
 
     // pop the next node group / leaf group from the stack as needed, then take the nearest child
-    // of the node group in hand.  Returns the index of the node to load (has_node tells if any).
-    auto advance_select = [&]() -> uint32_t {
+    // of the node group in hand: sets has_node / nidx
+    auto advance_select = [&]() {
 #pragma unroll
         for (int rep = 0; rep < 2; ++rep) {
             if (s.cur.y <= 0x00ffffffu && s.sp > s.base) {
@@ -301,30 +314,20 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                 else if (s.ptri.y == 0u) { s.ptri = top; --s.sp; }
             }
         }
-        uint32_t idx = 0u;
         if (s.cur.y > 0x00ffffffu) {
             const uint32_t hits_imask = s.cur.y;
             const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
             s.cur.y &= ~(1u << bit);
             const uint32_t slot_index = (bit - 24u) ^ (s.oct_inv4 & 0xffu);
             const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot_index));
-            idx = s.cur.x + rel;
+            nidx = s.cur.x + rel;
             if (s.cur.y > 0x00ffffffu) {            // siblings still to visit: keep them on the stack
                 if (s.sp < kLdsStack) s_stack[s.sp][tx] = s.cur; else spill[s.sp - kLdsStack] = s.cur;
                 ++s.sp;
             }
             s.cur = make_uint2(0u, 0u);
             has_node = true;
-        } else has_node = false;
-        return idx;
-    };
-    // divergent form for the rare paths (refill, split): select and load at once
-    auto advance = [&]() {
-        const uint32_t idx = advance_select();
-        if (has_node) {
-            const u32x4 *np = reinterpret_cast<const u32x4 *>(nodes + 5 * (size_t)idx);
-            n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3]; n4 = np[4];
-        }
+        } else { has_node = false; nidx = 0u; }
     };
 
     // wave-local slice of the queue: [wbeg, wend).  Slices of fetch_chunk rays are handed out by
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                 for (uint32_t k = kstart; k < kFetchShards && wbeg >= wend; ++k) {
                     const uint32_t shard = (home_shard + k) & (kFetchShards - 1);
                     uint32_t c = 0;
-                    if ((tx & 63u) == 0u) c = atomicAdd(a.fetch_counter + shard * kFetchShardStride, 1u);
+                    if (tx == 0u) c = atomicAdd(a.fetch_counter + shard * kFetchShardStride, 1u);
                     c = (uint32_t)__shfl((int)c, 0);
                     const uint64_t beg = ((uint64_t)c * kFetchShards + shard) * (uint64_t)a.fetch_chunk;
                     if (beg < (uint64_t)n_rays) {
@@ -371,8 +374,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                     s.ptri = make_uint2(0u, 0u);
                     s.sp = 0; s.base = 0;
                     s.slot = mine;
-                    alive = true;
-                    advance();                          // issues the root's loads
+                    alive = true; has_prim = false; pidx = 0u;
+                    advance_select();                   // the root becomes this lane's next node
                 }
             }
         }
@@ -402,11 +405,11 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                             s_mb_t[tx] = s.bt; s_mb_u[tx] = s.bu; s_mb_v[tx] = s.bv; s_mb_prim[tx] = s.bprim; s_mb_inst[tx] = s.binst;
                             s_mb_pending[tx] = 2u;
                         } else atomicAdd(&s_mb_pending[home], 1u);
-                        s_pair[wave_base + drank] = tx & 63u;
+                        s_pair[drank] = tx;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    const int src = is_recv ? (int)s_pair[wave_base + irank] : (int)(tx & 63u);
+                    const int src = is_recv ? (int)s_pair[irank] : (int)tx;
                     // every lane shuffles; only receivers keep what they read
                     const float r_ox = __shfl(s.ox, src), r_oy = __shfl(s.oy, src), r_oz = __shfl(s.oz, src);
                     const float r_dx = __shfl(s.dx, src), r_dy = __shfl(s.dy, src), r_dz = __shfl(s.dz, src);
@@ -424,19 +427,45 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                         if (r_gy > 0x00ffffffu) { s.cur = make_uint2(r_gx, r_gy); s.ptri = make_uint2(0u, 0u); }
                         else { s.cur = make_uint2(0u, 0u); s.ptri = make_uint2(r_gx, r_gy); }
                         s.sp = 0; s.base = 0;
-                        home = r_home; shared = true; alive = true;
-                        advance();
+                        home = r_home; shared = true; alive = true; has_prim = false; pidx = 0u;
+                        advance_select();
                     }
                 }
+            }
+
+            // ---- G. gather what every lane needs next: primitives first, nodes second ----
+            {
+                const void *pp[3], *np[5];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    pp[i] = prim_bytes + (size_t)(uint32_t)__shfl((int)pidx, (int)gp_own[i]) * 48u + gp_off[i];
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+                    np[i] = node_bytes + (size_t)(uint32_t)__shfl((int)nidx, (int)gn_own[i]) * 80u + gn_off[i];
+                gather_prim_pieces(prim_lds, pp[0], pp[1], pp[2]);
+                gather_node_pieces(node_lds, np[0], np[1], np[2], np[3], np[4]);
             }
 
             bool done = false;
             if (ANY_HIT && alive && shared && s_mb_prim[home] != kMissPrim) done = true;   // another piece already found a hit
 
-            // ---- A. node phase: process the node whose loads were issued last iteration ----
+            // ---- C. leaf test: waits for the primitive pieces only ----
+            wait_prim_gather();
+            if (!COUNT && alive && !done && has_prim) {
+                const float4 pa = reinterpret_cast<const float4 *>(s_prim_stage)[3 * tx + 0];
+                const float4 pb = reinterpret_cast<const float4 *>(s_prim_stage)[3 * tx + 1];
+                const float4 pc = reinterpret_cast<const float4 *>(s_prim_stage)[3 * tx + 2];
+                const bool better = test_prim<HAS_SPHERES>(pa, pb, pc, s, tmin, tmax_ray, a.inst_inv, a.inst_identity);
+                if (ANY_HIT && better) done = true;
+            }
+            has_prim = false; pidx = 0u;
+
+            // ---- A. node phase ----
             uint2 tri = make_uint2(0u, 0u);
-            wait_node_loads(n0, n1, n2, n3, n4);
+            wait_node_gather();
             if (alive && !done && has_node) {
+                const uint4 n0 = s_node_stage[5 * tx + 0], n1 = s_node_stage[5 * tx + 1], n2 = s_node_stage[5 * tx + 2];
+                const uint4 n3 = s_node_stage[5 * tx + 3], n4 = s_node_stage[5 * tx + 4];
                 if (COUNT) ++cnt_nodes;
                 const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
                 const uint32_t e_imask = n0.w;
@@ -473,8 +502,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                 }
                 s.cur = make_uint2(n1.x, (hitmask & 0xff000000u) | (e_imask >> 24));
                 tri = make_uint2(n1.y, hitmask & 0x00ffffffu);
-                has_node = false;
             }
+            has_node = false; nidx = 0u;
 
             // COUNT builds walk in the canonical order (every leaf of a node is tested before the next
             // node is chosen, no postponing, no splitting): the counters then equal a CPU walk of the
@@ -490,7 +519,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                 }
             }
 
-            // ---- B. bookkeeping + issue of the next loads (primitive first, then the next node) ----
+            // ---- B. bookkeeping: pending leaf group, the primitive and the node of the next iteration ----
             if (alive && !done && tri.y != 0u) {
                 if (s.ptri.y == 0u) s.ptri = tri;
                 else {
@@ -498,50 +527,31 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                     ++s.sp;
                 }
             }
-            const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
-            // leaf pass: ONE per iteration, one primitive per lane out of its pending leaf group.  It
-            // is skipped (wave-uniform) while few lanes have leaf work and none depends on it.
-            bool has_prim = false, do_pass = false;
-            uint32_t pidx = 0u;
             {
+                // leaf pass: ONE per iteration, one primitive per lane out of its pending leaf group.  It
+                // is skipped (wave-uniform) while few lanes have leaf work and none depends on it.
+                const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
                 const bool has = alive && !done && s.ptri.y != 0u;
                 const uint64_t m = __ballot(has);
                 const uint64_t must = __ballot(has && s.cur.y <= 0x00ffffffu);     // no node work in hand
-                do_pass = m != 0ull && (must != 0ull || (uint32_t)__popcll(m) * 100u >= n_alive * (uint32_t)a.postpone_pct);
-                if (do_pass) {
+                if (m != 0ull && (must != 0ull || (uint32_t)__popcll(m) * 100u >= n_alive * (uint32_t)a.postpone_pct)) {
                     if (has) {
                         const uint32_t k = (uint32_t)__ffs((int)s.ptri.y) - 1u;
                         s.ptri.y &= s.ptri.y - 1u;
                         pidx = s.ptri.x + k;
+                        has_prim = true;
                     }
-                    has_prim = has;
                 }
             }
-            // all stack traffic (LDS, and scratch for the overflow part -- scratch shares vmcnt with
-            // the global loads) happens BEFORE the loads are issued
-            uint32_t nidx = 0u;
-            if (alive && !done) nidx = advance_select();
-            // the loads are unconditional (every lane, index 0 when a lane has nothing to load) and
-            // hand-issued: primitive first, node second (see issue_prim_loads)
-            f32x4 pa, pb, pc;
-            issue_prim_loads(prims + 3 * (size_t)pidx, pa, pb, pc);
-            issue_node_loads(nodes + 5 * (size_t)nidx, n0, n1, n2, n3, n4);
-
-            // ---- C. leaf test (waits for the primitive only) ----
-            wait_prim_loads(pa, pb, pc);
-            if (has_prim) {
-                const bool better = test_prim<HAS_SPHERES>(make_float4(pa.x, pa.y, pa.z, pa.w), make_float4(pb.x, pb.y, pb.z, pb.w),
-                                                           make_float4(pc.x, pc.y, pc.z, pc.w), s, tmin, tmax_ray, a.inst_inv, a.inst_identity);
-                if (ANY_HIT && better) done = true;
-            }
+            if (alive && !done) advance_select();
 
             // ---- finished? ----
             if (alive) {
-                if (!done && !has_node && s.ptri.y == 0u) done = true;
+                if (!done && !has_node && !has_prim && s.ptri.y == 0u) done = true;
                 if (done && !shared) {
                     a.hit_tuvp[s.slot] = make_float4(s.bt, s.bu, s.bv, __uint_as_float(s.bprim));
                     a.hit_inst[s.slot] = s.binst;
-                    alive = false; has_node = false;
+                    alive = false; has_node = false; has_prim = false; nidx = 0u; pidx = 0u;
                 }
             }
             // pieces of split rays finish one lane at a time: merge into the home mailbox, the last one writes
@@ -549,7 +559,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
             while (fin) {
                 const uint32_t l = (uint32_t)__ffsll((long long)fin) - 1u;
                 fin &= fin - 1ull;
-                if ((tx & 63u) == l) {
+                if (tx == l) {
                     const float mt = s_mb_t[home];
                     const uint64_t mid = ((uint64_t)s_mb_inst[home] << 32) | s_mb_prim[home];
                     const uint64_t id = ((uint64_t)s.binst << 32) | s.bprim;
@@ -562,7 +572,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                         a.hit_tuvp[s.slot] = make_float4(s_mb_t[home], s_mb_u[home], s_mb_v[home], __uint_as_float(s_mb_prim[home]));
                         a.hit_inst[s.slot] = s_mb_inst[home];
                     }
-                    alive = false; shared = false; home = tx; has_node = false;
+                    alive = false; shared = false; home = tx; has_node = false; has_prim = false; nidx = 0u; pidx = 0u;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -578,7 +588,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
             cnt_nodes += (uint32_t)__shfl_down((int)cnt_nodes, off);
             cnt_prims += (uint32_t)__shfl_down((int)cnt_prims, off);
         }
-        if ((tx & 63u) == 0u) {
+        if (tx == 0u) {
             atomicAdd(reinterpret_cast<unsigned long long *>(a.count_nodes), (unsigned long long)cnt_nodes);
             atomicAdd(reinterpret_cast<unsigned long long *>(a.count_prims), (unsigned long long)cnt_prims);
         }
