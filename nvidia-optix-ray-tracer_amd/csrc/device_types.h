@@ -47,6 +47,7 @@ struct GenerateArgs {
 struct TraverseArgs {
     const void *nodes;             // Bvh8Node[]
     const void *prims;             // PrimRecord[]
+    uint32_t node_stride, prim_stride;   // bytes between consecutive records (80 / 48 when packed)
     const RayRec *rays;
     const uint32_t *n_rays_ptr;    // 4 device counters whose sum is the queue length, or NULL
     uint32_t n_rays;               // used when n_rays_ptr == NULL
@@ -105,7 +106,7 @@ struct FinalizeArgs {
 // host-callable launchers (defined in kernels.hip)
 void launch_rng_init(RngState *states, uint32_t n, uint64_t salt, const uint32_t *d_jump, hipStream_t s);
 void launch_generate(const GenerateArgs &a, hipStream_t s);
-void launch_traverse(const TraverseArgs &a, bool any_hit, bool count, bool has_spheres, uint32_t grid_blocks, hipStream_t s);
+void launch_traverse(const TraverseArgs &a, bool any_hit, bool count, bool has_spheres, bool dma, uint32_t grid_blocks, hipStream_t s);
 void launch_bin(const BinArgs &a, uint32_t grid_blocks, hipStream_t s);
 void launch_shade(const ShadeArgs &a, int program, uint32_t grid_blocks, hipStream_t s);
 void launch_accumulate(const AccumArgs &a, uint32_t grid_blocks, hipStream_t s);

@@ -42,6 +42,7 @@ struct Tlas {
     float *d_inst_inv = nullptr;
     uint32_t *d_inst_identity = nullptr;
     bool has_spheres = false;
+    uint32_t node_stride = 80, prim_stride = 48;
     uint64_t generation = 0;
 };
 
@@ -96,9 +97,11 @@ struct HrtContext {
     double kernel_ms[HRT_K_COUNT] = {0}; uint64_t kernel_launches[HRT_K_COUNT] = {0};
     float4 *d_linear = nullptr;
     int refill_threshold = 16;
-    int traverse_blocks_per_cu = 12;            // one-wave workgroups of the traverse kernel per CU
+    int traverse_blocks_per_cu = 16;            // one-wave workgroups of the traverse kernel per CU
     int postpone_pct = 25;
     int tail_split = 1;
+    int node_stride = 80, prim_stride = 64;     // bytes between records in HBM (80/48 packed; 128/64 = one cache line each)
+    int lds_gather = 0;                         // 1: cooperative LDS-DMA gathers, 0: per-lane register loads
     int fetch_chunk = 64;
     int substreams = 1;                         // sub-tiles rendered on their own HIP streams so that one's tail overlaps another's bulk
     std::vector<hipStream_t> sub_streams; std::vector<hipEvent_t> sub_done; hipEvent_t ev_begin = nullptr;
@@ -260,15 +263,26 @@ int build_tlas_into(HrtContext *ctx, Tlas &t, const HrtInstance *d_instances, ui
 
     free_tlas_device(t);
     t.n_instances = n;
-    const size_t nb = sizeof(Bvh8Node) * t.bvh.nodes.size();
-    const size_t pb = sizeof(PrimRecord) * std::max<size_t>(t.bvh.prims.size(), 1);
+    t.node_stride = (uint32_t)ctx->node_stride; t.prim_stride = (uint32_t)ctx->prim_stride;
+    const size_t n_nodes = t.bvh.nodes.size(), n_prims = t.bvh.prims.size();
+    const size_t nb = (size_t)t.node_stride * n_nodes;
+    const size_t pb = (size_t)t.prim_stride * std::max<size_t>(n_prims, 1);
     HIP_TRY(ctx, hipMalloc(&t.d_nodes, nb));
     HIP_TRY(ctx, hipMalloc(&t.d_prims, pb));
     HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_inv, sizeof(float) * inv.size()));
     HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_identity, sizeof(uint32_t) * ident.size()));
-    HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, t.bvh.nodes.data(), nb, hipMemcpyHostToDevice, s));
-    if (!t.bvh.prims.empty())
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_prims, t.bvh.prims.data(), sizeof(PrimRecord) * t.bvh.prims.size(), hipMemcpyHostToDevice, s));
+    if (t.node_stride == sizeof(Bvh8Node) && t.prim_stride == sizeof(PrimRecord)) {
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, t.bvh.nodes.data(), nb, hipMemcpyHostToDevice, s));
+        if (n_prims) HIP_TRY(ctx, hipMemcpyAsync(t.d_prims, t.bvh.prims.data(), sizeof(PrimRecord) * n_prims, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+    } else {
+        std::vector<unsigned char> hn(nb, 0), hp(pb, 0);
+        for (size_t i = 0; i < n_nodes; ++i) std::memcpy(&hn[i * t.node_stride], &t.bvh.nodes[i], sizeof(Bvh8Node));
+        for (size_t i = 0; i < n_prims; ++i) std::memcpy(&hp[i * t.prim_stride], &t.bvh.prims[i], sizeof(PrimRecord));
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, hn.data(), nb, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_prims, hp.data(), pb, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+    }
     HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_inv, inv.data(), sizeof(float) * inv.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_identity, ident.data(), sizeof(uint32_t) * ident.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -355,6 +369,9 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
         return fail(nullptr, HRT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(hipGetLastError()));
     if (const char *e = std::getenv("HRT_TRAVERSE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) ctx->traverse_blocks_per_cu = v; }
     if (const char *e = std::getenv("HRT_FETCH_CHUNK")) { const int v = std::atoi(e); if (v >= 8 && v <= 4096) ctx->fetch_chunk = v; }
+    if (const char *e = std::getenv("HRT_NODE_STRIDE")) { const int v = std::atoi(e); if (v >= 80 && v <= 256 && v % 16 == 0) ctx->node_stride = v; }
+    if (const char *e = std::getenv("HRT_PRIM_STRIDE")) { const int v = std::atoi(e); if (v >= 48 && v <= 256 && v % 16 == 0) ctx->prim_stride = v; }
+    if (const char *e = std::getenv("HRT_LDS_GATHER")) ctx->lds_gather = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_TAIL_SPLIT")) ctx->tail_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_SUBSTREAMS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) ctx->substreams = v; }
     if (const char *e = std::getenv("HRT_POSTPONE_PCT")) { const int v = std::atoi(e); if (v >= 0 && v <= 100) ctx->postpone_pct = v; }
@@ -639,7 +656,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
                 const uint32_t *n_ptr = depth == 1 ? nullptr : &sb.stages[depth - 1].bin_count[1];
                 uint32_t *bin_items = w.bin_items + (size_t)sb.j0 * kNumBins;
                 TraverseArgs ta{};
-                ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.rays = w.rays[cur] + sb.j0;
+                ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.node_stride = t->node_stride; ta.prim_stride = t->prim_stride; ta.rays = w.rays[cur] + sb.j0;
                 ta.n_rays_ptr = n_ptr; ta.n_rays = sb.n; ta.fetch_counter = sb.stages[depth].fetch;
                 ta.hit_tuvp = w.hit_tuvp + sb.j0; ta.hit_inst = w.hit_inst + sb.j0;
                 ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
@@ -649,7 +666,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
                 ta.count_prims = any_hit ? &ctx->d_stats->prims_any : &ctx->d_stats->prims_closest;
                 ta.debug = any_hit ? nullptr : ctx->d_stats->debug;
                 { Timer tm(ctx, st, any_hit ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
-                  launch_traverse(ta, any_hit, count, t->has_spheres, sb.grid_trav, st); }
+                  launch_traverse(ta, any_hit, count, t->has_spheres, ctx->lds_gather != 0, sb.grid_trav, st); }
 
                 BinArgs ba{};
                 ba.n_rays_ptr = n_ptr; ba.n_rays = sb.n; ba.hit_inst = w.hit_inst + sb.j0; ba.inst_program = ctx->d_inst_program; ba.depth = depth;
@@ -763,7 +780,7 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
     HIP_TRY(ctx, hipMemsetAsync(fetch, 0, sizeof(uint32_t) * 8 * 32, s));
     launch_pack_rays(reinterpret_cast<const float *>(d_origins), reinterpret_cast<const float *>(d_directions), n_rays, rays, s);
     TraverseArgs ta{};
-    ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.rays = rays; ta.n_rays_ptr = nullptr; ta.n_rays = n_rays;
+    ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.node_stride = t->node_stride; ta.prim_stride = t->prim_stride; ta.rays = rays; ta.n_rays_ptr = nullptr; ta.n_rays = n_rays;
     ta.fetch_counter = fetch; ta.hit_tuvp = tuvp; ta.hit_inst = inst; ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
     ta.tmin = tmin; ta.tmax = tmax; ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fetch_chunk;
     ta.count_nodes = any_hit ? &ctx->d_stats->nodes_any : &ctx->d_stats->nodes_closest;
@@ -771,7 +788,7 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
     ta.debug = any_hit ? nullptr : ctx->d_stats->debug;
     const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (n_rays + 63u) / 64u);
     { Timer tm(ctx, s, any_hit ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
-      launch_traverse(ta, any_hit != 0, (ctx->flags & HRT_CTX_COUNT) != 0, t->has_spheres, grid, s); }
+      launch_traverse(ta, any_hit != 0, (ctx->flags & HRT_CTX_COUNT) != 0, t->has_spheres, ctx->lds_gather != 0, grid, s); }
     launch_unpack_hits(tuvp, inst, n_rays, d_t, d_u, d_v, d_prim, d_inst, s);
     hipError_t e = hipStreamSynchronize(s);
     (void)hipFree(rays); (void)hipFree(tuvp); (void)hipFree(inst); (void)hipFree(fetch);

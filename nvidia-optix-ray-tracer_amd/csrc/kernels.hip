@@ -261,15 +261,40 @@ __device__ __forceinline__ void gather_prim_pieces(uint32_t lds_base, const void
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(p0), "v"(p1), "v"(p2), "s"(lds_base) : "memory", "scc");
 }
+// Per-lane variant (template parameter DMA = false): every lane loads its own node / primitive into
+// registers.  More L1 look-ups per step, but no staging image, so more waves fit per CU.  The
+// destinations are named "+v" in the wait statements so that no use is scheduled above the wait.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void issue_prim_loads(const void *p, f32x4 &a, f32x4 &b, f32x4 &c) {
+    asm volatile("global_load_dwordx4 %0, %3, off\n\t"
+                 "global_load_dwordx4 %1, %3, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:32"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void issue_node_loads(const void *p, u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, u32x4 &e) {
+    asm volatile("global_load_dwordx4 %0, %5, off\n\t"
+                 "global_load_dwordx4 %1, %5, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %5, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %5, off offset:48\n\t"
+                 "global_load_dwordx4 %4, %5, off offset:64"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void wait_prim_loads(f32x4 &a, f32x4 &b, f32x4 &c) {
+    asm volatile("s_waitcnt vmcnt(5)" : "+v"(a), "+v"(b), "+v"(c) :: "memory");
+}
+__device__ __forceinline__ void wait_node_loads(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, u32x4 &e) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) :: "memory");
+}
 __device__ __forceinline__ void wait_prim_gather() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
 __device__ __forceinline__ void wait_node_gather() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <bool ANY_HIT, bool COUNT, bool HAS_SPHERES>
+template <bool ANY_HIT, bool COUNT, bool HAS_SPHERES, bool DMA>
 __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     static_assert(kTraverseBlock == 64, "one wave per workgroup: staging images and mailboxes are per wave");
     __shared__ uint2 s_stack[kLdsStack][kTraverseBlock];
-    __shared__ uint4 s_node_stage[5 * 64];          // 64 node slots x 80 B, filled by LDS-DMA
-    __shared__ uint4 s_prim_stage[3 * 64];          // 64 primitive slots x 48 B
+    __shared__ uint4 s_node_stage[DMA ? 5 * 64 : 1];          // 64 node slots x 80 B, filled by LDS-DMA
+    __shared__ uint4 s_prim_stage[DMA ? 3 * 64 : 1];          // 64 primitive slots x 48 B
     // tail splitting: one mailbox per lane that owns a split ray (indexed by its home lane)
     __shared__ float s_mb_t[kTraverseBlock], s_mb_u[kTraverseBlock], s_mb_v[kTraverseBlock];
     __shared__ uint32_t s_mb_prim[kTraverseBlock], s_mb_inst[kTraverseBlock], s_mb_pending[kTraverseBlock];
@@ -279,7 +304,6 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     const uint32_t n_rays = a.n_rays_ptr ? (a.n_rays_ptr[0] + a.n_rays_ptr[1] + a.n_rays_ptr[2] + a.n_rays_ptr[3]) : a.n_rays;
     const char *__restrict__ node_bytes = reinterpret_cast<const char *>(a.nodes);
     const char *__restrict__ prim_bytes = reinterpret_cast<const char *>(a.prims);
-    const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(a.prims);
     const float tmin = a.tmin, tmax_ray = a.tmax;
     const uint32_t tx = threadIdx.x;                // = lane
 
@@ -433,28 +457,39 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                 }
             }
 
-            // ---- G. gather what every lane needs next: primitives first, nodes second ----
-            {
+            // ---- G. fetch what every lane needs next: primitives first, nodes second ----
+            f32x4 rpa, rpb, rpc;                      // !DMA: the lane's own primitive / node in registers
+            u32x4 rn0, rn1, rn2, rn3, rn4;
+            if (DMA) {
                 const void *pp[3], *np[5];
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
-                    pp[i] = prim_bytes + (size_t)(uint32_t)__shfl((int)pidx, (int)gp_own[i]) * 48u + gp_off[i];
+                    pp[i] = prim_bytes + (size_t)(uint32_t)__shfl((int)pidx, (int)gp_own[i]) * a.prim_stride + gp_off[i];
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
-                    np[i] = node_bytes + (size_t)(uint32_t)__shfl((int)nidx, (int)gn_own[i]) * 80u + gn_off[i];
+                    np[i] = node_bytes + (size_t)(uint32_t)__shfl((int)nidx, (int)gn_own[i]) * a.node_stride + gn_off[i];
                 gather_prim_pieces(prim_lds, pp[0], pp[1], pp[2]);
                 gather_node_pieces(node_lds, np[0], np[1], np[2], np[3], np[4]);
+            } else {
+                issue_prim_loads(prim_bytes + (size_t)pidx * a.prim_stride, rpa, rpb, rpc);
+                issue_node_loads(node_bytes + (size_t)nidx * a.node_stride, rn0, rn1, rn2, rn3, rn4);
             }
 
             bool done = false;
             if (ANY_HIT && alive && shared && s_mb_prim[home] != kMissPrim) done = true;   // another piece already found a hit
 
             // ---- C. leaf test: waits for the primitive pieces only ----
-            wait_prim_gather();
+            if (DMA) wait_prim_gather(); else wait_prim_loads(rpa, rpb, rpc);
             if (!COUNT && alive && !done && has_prim) {
-                const float4 pa = reinterpret_cast<const float4 *>(s_prim_stage)[3 * tx + 0];
-                const float4 pb = reinterpret_cast<const float4 *>(s_prim_stage)[3 * tx + 1];
-                const float4 pc = reinterpret_cast<const float4 *>(s_prim_stage)[3 * tx + 2];
+                float4 pa, pb, pc;
+                if (DMA) {
+                    pa = reinterpret_cast<const float4 *>(s_prim_stage)[3 * tx + 0];
+                    pb = reinterpret_cast<const float4 *>(s_prim_stage)[3 * tx + 1];
+                    pc = reinterpret_cast<const float4 *>(s_prim_stage)[3 * tx + 2];
+                } else {
+                    pa = make_float4(rpa.x, rpa.y, rpa.z, rpa.w); pb = make_float4(rpb.x, rpb.y, rpb.z, rpb.w);
+                    pc = make_float4(rpc.x, rpc.y, rpc.z, rpc.w);
+                }
                 const bool better = test_prim<HAS_SPHERES>(pa, pb, pc, s, tmin, tmax_ray, a.inst_inv, a.inst_identity);
                 if (ANY_HIT && better) done = true;
             }
@@ -462,10 +497,17 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
 
             // ---- A. node phase ----
             uint2 tri = make_uint2(0u, 0u);
-            wait_node_gather();
+            if (DMA) wait_node_gather(); else wait_node_loads(rn0, rn1, rn2, rn3, rn4);
             if (alive && !done && has_node) {
-                const uint4 n0 = s_node_stage[5 * tx + 0], n1 = s_node_stage[5 * tx + 1], n2 = s_node_stage[5 * tx + 2];
-                const uint4 n3 = s_node_stage[5 * tx + 3], n4 = s_node_stage[5 * tx + 4];
+                uint4 n0, n1, n2, n3, n4;
+                if (DMA) {
+                    n0 = s_node_stage[5 * tx + 0]; n1 = s_node_stage[5 * tx + 1]; n2 = s_node_stage[5 * tx + 2];
+                    n3 = s_node_stage[5 * tx + 3]; n4 = s_node_stage[5 * tx + 4];
+                } else {
+                    n0 = make_uint4(rn0.x, rn0.y, rn0.z, rn0.w); n1 = make_uint4(rn1.x, rn1.y, rn1.z, rn1.w);
+                    n2 = make_uint4(rn2.x, rn2.y, rn2.z, rn2.w); n3 = make_uint4(rn3.x, rn3.y, rn3.z, rn3.w);
+                    n4 = make_uint4(rn4.x, rn4.y, rn4.z, rn4.w);
+                }
                 if (COUNT) ++cnt_nodes;
                 const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
                 const uint32_t e_imask = n0.w;
@@ -513,7 +555,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                     const uint32_t k = (uint32_t)__ffs((int)tri.y) - 1u;
                     tri.y &= tri.y - 1u;
                     ++cnt_prims;
-                    const float4 *pp = prims + 3 * (size_t)(tri.x + k);
+                    const float4 *pp = reinterpret_cast<const float4 *>(prim_bytes + (size_t)(tri.x + k) * a.prim_stride);
                     const bool better = test_prim<HAS_SPHERES>(pp[0], pp[1], pp[2], s, tmin, tmax_ray, a.inst_inv, a.inst_identity);
                     if (ANY_HIT && better) done = true;
                 }
@@ -885,19 +927,21 @@ void launch_rng_init(RngState *states, uint32_t n, uint64_t salt, const uint32_t
 void launch_generate(const GenerateArgs &a, hipStream_t s) {
     if (a.n_tile_pixels) hipLaunchKernelGGL(k_generate, dim3(ceil_div(a.n_tile_pixels, 256)), dim3(256), 0, s, a);
 }
-void launch_traverse(const TraverseArgs &a, bool any_hit, bool count, bool has_spheres, uint32_t grid_blocks, hipStream_t s) {
+void launch_traverse(const TraverseArgs &a, bool any_hit, bool count, bool has_spheres, bool dma, uint32_t grid_blocks, hipStream_t s) {
     const dim3 g(grid_blocks), b(kTraverseBlock);
-    const int sel = (any_hit ? 4 : 0) | (count ? 2 : 0) | (has_spheres ? 1 : 0);
+    const int sel = (dma ? 8 : 0) | (any_hit ? 4 : 0) | (count ? 2 : 0) | (has_spheres ? 1 : 0);
+#define HRT_TRAV_CASE(N, A, C, S, D) case N: hipLaunchKernelGGL((k_traverse<A, C, S, D>), g, b, 0, s, a); break;
     switch (sel) {
-        case 0: hipLaunchKernelGGL((k_traverse<false, false, false>), g, b, 0, s, a); break;
-        case 1: hipLaunchKernelGGL((k_traverse<false, false, true>), g, b, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((k_traverse<false, true, false>), g, b, 0, s, a); break;
-        case 3: hipLaunchKernelGGL((k_traverse<false, true, true>), g, b, 0, s, a); break;
-        case 4: hipLaunchKernelGGL((k_traverse<true, false, false>), g, b, 0, s, a); break;
-        case 5: hipLaunchKernelGGL((k_traverse<true, false, true>), g, b, 0, s, a); break;
-        case 6: hipLaunchKernelGGL((k_traverse<true, true, false>), g, b, 0, s, a); break;
-        default: hipLaunchKernelGGL((k_traverse<true, true, true>), g, b, 0, s, a); break;
+        HRT_TRAV_CASE(0, false, false, false, false) HRT_TRAV_CASE(1, false, false, true, false)
+        HRT_TRAV_CASE(2, false, true, false, false)  HRT_TRAV_CASE(3, false, true, true, false)
+        HRT_TRAV_CASE(4, true, false, false, false)  HRT_TRAV_CASE(5, true, false, true, false)
+        HRT_TRAV_CASE(6, true, true, false, false)   HRT_TRAV_CASE(7, true, true, true, false)
+        HRT_TRAV_CASE(8, false, false, false, true)  HRT_TRAV_CASE(9, false, false, true, true)
+        HRT_TRAV_CASE(10, false, true, false, true)  HRT_TRAV_CASE(11, false, true, true, true)
+        HRT_TRAV_CASE(12, true, false, false, true)  HRT_TRAV_CASE(13, true, false, true, true)
+        HRT_TRAV_CASE(14, true, true, false, true)   default: hipLaunchKernelGGL((k_traverse<true, true, true, true>), g, b, 0, s, a); break;
     }
+#undef HRT_TRAV_CASE
 }
 void launch_bin(const BinArgs &a, uint32_t grid_blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_bin_hits, dim3(grid_blocks), dim3(256), 0, s, a);
