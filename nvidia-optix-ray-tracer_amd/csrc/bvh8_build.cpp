@@ -4,7 +4,10 @@
 // :174-208 buildIAS).  OptiX's builder is closed; this one is:
 //   1. binned-SAH BVH2 over padded primitive bounds (16 bins x 3 axes, leaves <= 3 prims),
 //      big subtrees built on worker threads (topology does not depend on thread timing);
-//   2. greedy collapse to 8-wide nodes (always open the inner child with the largest area);
+//   2. optimal SAH collapse to 8-wide nodes by dynamic programming (Ylitie, Karras, Laine 2017,
+//      sec. 4.1): C(n, i) = cheapest way to represent subtree n as a forest of at most i roots,
+//      c_node = 1, c_prim = 0.3, leaves <= 3 primitives.  (A first greedy version -- always open
+//      the largest inner child -- left 64 % of the nodes with only two children.)
 //   3. octant-ordered slot assignment so that (slot ^ (7 - ray_octant)) approximates
 //      front-to-back order during traversal;
 //   4. outward-rounded 8-bit quantisation of the child boxes against the node origin/exponent.
@@ -13,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <thread>
@@ -24,6 +28,7 @@ struct B2 {
     float lo[3], hi[3];
     uint32_t left, right;     // inner
     uint32_t first, count;    // leaf when count > 0
+    uint32_t nprims;          // primitives in the subtree: idx[first, first + nprims)
 };
 
 inline float half_area(const float *lo, const float *hi) {
@@ -64,7 +69,7 @@ struct Builder {
         float clo[3], chi[3];
         bounds_of(b, e, n.lo, n.hi, clo, chi);
         const uint32_t cnt = e - b;
-        n.left = n.right = 0; n.first = b; n.count = 0;
+        n.left = n.right = 0; n.first = b; n.count = 0; n.nprims = cnt;
         if (cnt == 1) { n.count = 1; return; }
 
         constexpr int NB = 16;
@@ -186,7 +191,58 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads) {
 
     for (int a = 0; a < 3; ++a) { out.lo[a] = B.nodes[0].lo[a]; out.hi[a] = B.nodes[0].hi[a]; }
 
-    // ---- collapse to 8-wide, breadth first so that inner children are contiguous ----
+    // ---- optimal collapse: cost tables bottom-up (children always have larger indices than parents) ----
+    const uint32_t nb2 = B.n_nodes.load();
+    float kCNode = 1.0f, kCPrim = 0.3f; const float kInf = std::numeric_limits<float>::infinity();
+    if (const char *e = std::getenv("HRT_BVH_CPRIM")) kCPrim = (float)std::atof(e);     // tuning experiments
+    if (const char *e = std::getenv("HRT_BVH_CNODE")) kCNode = (float)std::atof(e);
+    struct Cost { float c[8]; uint8_t leaf1; uint8_t use_dist[8]; uint8_t split[9]; };   // c[i], i = 1..7; split[j], j = 2..8
+    std::vector<Cost> cost(nb2);
+    for (uint32_t ni = nb2; ni-- > 0;) {
+        const B2 &bn = B.nodes[ni];
+        Cost &cn = cost[ni];
+        std::memset(&cn, 0, sizeof cn);
+        const float area = half_area(bn.lo, bn.hi);
+        const float c_leaf = bn.nprims <= kMaxLeafPrims ? area * kCPrim * (float)bn.nprims : kInf;
+        if (bn.count > 0) {                      // BVH2 leaf
+            for (int i = 1; i <= 7; ++i) cn.c[i] = c_leaf;
+            cn.leaf1 = 1;
+            continue;
+        }
+        const Cost &cl = cost[bn.left], &cr = cost[bn.right];
+        float dist[9];
+        for (int j = 2; j <= 8; ++j) {
+            float best = kInf; int bk = 1;
+            for (int k = 1; k < j; ++k) {
+                const float v = cl.c[std::min(k, 7)] + cr.c[std::min(j - k, 7)];
+                if (v < best) { best = v; bk = k; }
+            }
+            dist[j] = best; cn.split[j] = (uint8_t)bk;
+        }
+        const float c_internal = dist[8] + area * kCNode;
+        cn.leaf1 = c_leaf <= c_internal ? 1 : 0;
+        cn.c[1] = std::min(c_leaf, c_internal);
+        for (int i = 2; i <= 7; ++i) {
+            if (dist[i] < cn.c[i - 1]) { cn.c[i] = dist[i]; cn.use_dist[i] = 1; }
+            else { cn.c[i] = cn.c[i - 1]; cn.use_dist[i] = 0; }
+        }
+    }
+    // roots of the forest that represents subtree n with a budget of j roots (as chosen by the tables)
+    struct Collector {
+        const Builder &B; const std::vector<Cost> &cost; uint32_t out[8]; int n = 0;
+        void forest(uint32_t x, int i) {            // at most i roots for subtree x
+            while (i > 1 && !cost[x].use_dist[i]) --i;
+            if (i == 1 || B.nodes[x].count > 0) { out[n++] = x; return; }
+            distribute(x, i);
+        }
+        void distribute(uint32_t x, int j) {        // subtree x opened: j roots over its two children
+            const int k = cost[x].split[j];
+            forest(B.nodes[x].left, std::min(k, 7));
+            forest(B.nodes[x].right, std::min(j - k, 7));
+        }
+    };
+
+    // ---- emit 8-wide nodes breadth first so that inner children are contiguous ----
     struct Item { uint32_t b2; uint32_t depth; };
     std::vector<Item> queue;
     queue.reserve(n);
@@ -194,7 +250,6 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads) {
     out.prims.reserve(n);
     out.prim_bounds.reserve(6 * (size_t)n);
 
-    // root: if the BVH2 root is itself a leaf, wrap it into a node with one leaf child
     queue.push_back({0u, 0u});
     out.nodes.emplace_back();
     size_t head = 0;
@@ -206,20 +261,16 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads) {
         out.max_depth = std::max(out.max_depth, it.depth);
 
         uint32_t ch[8]; int nch = 0;
-        if (bn.count > 0) { ch[nch++] = it.b2; }
-        else {
-            ch[nch++] = bn.left; ch[nch++] = bn.right;
-            while (nch < 8) {
-                int pick = -1; float pa = -1.0f;
-                for (int k = 0; k < nch; ++k) {
-                    const B2 &c = B.nodes[ch[k]];
-                    if (c.count > 0) continue;
-                    const float ar = half_area(c.lo, c.hi);
-                    if (ar > pa) { pa = ar; pick = k; }
-                }
-                if (pick < 0) break;
-                const B2 &c = B.nodes[ch[pick]];
-                ch[pick] = c.left; ch[nch++] = c.right;
+        bool ch_leaf[8];
+        if (bn.count > 0 || (it.b2 == 0 && bn.nprims <= kMaxLeafPrims)) {
+            ch[nch] = it.b2; ch_leaf[nch] = true; ++nch;         // the whole scene fits one leaf: wrap it
+        } else {
+            Collector col{B, cost};
+            col.distribute(it.b2, 8);
+            for (int k = 0; k < col.n; ++k) {
+                ch[nch] = col.out[k];
+                ch_leaf[nch] = B.nodes[col.out[k]].count > 0 || cost[col.out[k]].leaf1;
+                ++nch;
             }
         }
 
@@ -283,15 +334,15 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads) {
                 while (qh < 255 && nd.p[a] + (float)qh * fs < c.hi[a]) ++qh;
                 nd.qlo[a][s] = (uint8_t)ql; nd.qhi[a][s] = (uint8_t)qh;
             }
-            if (c.count > 0) {
-                nd.meta[s] = (uint8_t)((unary_count(c.count) << 5) | prim_off);
-                for (uint32_t i = 0; i < c.count; ++i) {
+            if (ch_leaf[k]) {
+                nd.meta[s] = (uint8_t)((unary_count(c.nprims) << 5) | prim_off);
+                for (uint32_t i = 0; i < c.nprims; ++i) {
                     const uint32_t p = B.idx[c.first + i];
                     out.prims.push_back(prims[p].rec);
                     for (int a = 0; a < 3; ++a) out.prim_bounds.push_back(prims[p].lo[a]);
                     for (int a = 0; a < 3; ++a) out.prim_bounds.push_back(prims[p].hi[a]);
                 }
-                prim_off += c.count;
+                prim_off += c.nprims;
             } else {
                 nd.meta[s] = (uint8_t)(0x20u | (24u + (uint32_t)s));
                 nd.imask |= (uint8_t)(1u << s);
