@@ -2,7 +2,7 @@
 //
 // Stands in for optixAccelBuild (reference: src/Global/RendererImpl.cu:30-88 buildASImpl,
 // :174-208 buildIAS).  OptiX's builder is closed; this one is:
-//   1. binned-SAH BVH2 over padded primitive bounds (16 bins x 3 axes, leaves <= 3 prims),
+//   1. binned-SAH BVH2 over padded primitive bounds (16 bins x 3 axes) down to single primitives,
 //      big subtrees built on worker threads (topology does not depend on thread timing);
 //   2. optimal SAH collapse to 8-wide nodes by dynamic programming (Ylitie, Karras, Laine 2017,
 //      sec. 4.1): C(n, i) = cheapest way to represent subtree n as a forest of at most i roots,
@@ -43,6 +43,7 @@ struct Builder {
     std::vector<B2> nodes;
     std::atomic<uint32_t> n_nodes{0};
     int max_par_depth = 0;
+    bool split_to_single = true;      // build the BVH2 down to one primitive per leaf and let the collapse form the leaves (+7 %)
 
     explicit Builder(const std::vector<BuildPrim> &p) : in(p) {}
 
@@ -110,7 +111,7 @@ struct Builder {
             }
         }
 
-        if (cnt <= kMaxLeafPrims) {
+        if (cnt <= kMaxLeafPrims && !split_to_single) {
             // leaf unless splitting is clearly cheaper (c_prim = 0.3, c_inner = 0.5)
             const float area = half_area(n.lo, n.hi);
             const float split_cost = best_axis >= 0 && area > 0.0f ? 0.3f * best_cost / area + 0.5f
@@ -186,6 +187,7 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads) {
     int hw = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
     if (hw < 1) hw = 1;
     B.max_par_depth = 0;
+    if (const char *e = std::getenv("HRT_BVH2_SINGLE")) B.split_to_single = std::atoi(e) != 0;
     while ((1 << B.max_par_depth) < hw && B.max_par_depth < 6) B.max_par_depth++;
     B.build(0, 0, n, 0);
 
@@ -193,7 +195,7 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads) {
 
     // ---- optimal collapse: cost tables bottom-up (children always have larger indices than parents) ----
     const uint32_t nb2 = B.n_nodes.load();
-    float kCNode = 1.0f, kCPrim = 0.3f; const float kInf = std::numeric_limits<float>::infinity();
+    float kCNode = 1.0f, kCPrim = 0.45f;    // measured on MI355X (C4): 0.3 -> 1674, 0.45 -> 1691, 0.6 -> 1691, 1.0 -> 1684 Mrays/s const float kInf = std::numeric_limits<float>::infinity();
     if (const char *e = std::getenv("HRT_BVH_CPRIM")) kCPrim = (float)std::atof(e);     // tuning experiments
     if (const char *e = std::getenv("HRT_BVH_CNODE")) kCNode = (float)std::atof(e);
     struct Cost { float c[8]; uint8_t leaf1; uint8_t use_dist[8]; uint8_t split[9]; };   // c[i], i = 1..7; split[j], j = 2..8
