@@ -195,7 +195,8 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads) {
 
     // ---- optimal collapse: cost tables bottom-up (children always have larger indices than parents) ----
     const uint32_t nb2 = B.n_nodes.load();
-    float kCNode = 1.0f, kCPrim = 0.45f;    // measured on MI355X (C4): 0.3 -> 1674, 0.45 -> 1691, 0.6 -> 1691, 1.0 -> 1684 Mrays/s const float kInf = std::numeric_limits<float>::infinity();
+    // c_prim measured on MI355X (C4): 0.3 -> 1674, 0.45 -> 1691, 0.6 -> 1691, 1.0 -> 1684 Mrays/s
+    float kCNode = 1.0f, kCPrim = 0.45f; const float kInf = std::numeric_limits<float>::infinity();
     if (const char *e = std::getenv("HRT_BVH_CPRIM")) kCPrim = (float)std::atof(e);     // tuning experiments
     if (const char *e = std::getenv("HRT_BVH_CNODE")) kCNode = (float)std::atof(e);
     struct Cost { float c[8]; uint8_t leaf1; uint8_t use_dist[8]; uint8_t split[9]; };   // c[i], i = 1..7; split[j], j = 2..8
