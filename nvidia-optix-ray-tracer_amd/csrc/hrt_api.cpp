@@ -103,6 +103,7 @@ struct HrtContext {
     int node_stride = 80, prim_stride = 64;     // bytes between records in HBM (80/48 packed; 128/64 = one cache line each)
     int lds_gather = 0;                         // 1: cooperative LDS-DMA gathers, 0: per-lane register loads
     int fetch_chunk = 64;
+    int substream_min_pixels = 32768;
     int substreams = 1;                         // sub-tiles rendered on their own HIP streams so that one's tail overlaps another's bulk
     std::vector<hipStream_t> sub_streams; std::vector<hipEvent_t> sub_done; hipEvent_t ev_begin = nullptr;
 };
@@ -373,6 +374,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_PRIM_STRIDE")) { const int v = std::atoi(e); if (v >= 48 && v <= 256 && v % 16 == 0) ctx->prim_stride = v; }
     if (const char *e = std::getenv("HRT_LDS_GATHER")) ctx->lds_gather = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_TAIL_SPLIT")) ctx->tail_split = std::atoi(e) != 0;
+    if (const char *e = std::getenv("HRT_SUBSTREAM_MIN_PIXELS")) { const int v = std::atoi(e); if (v >= 1024) ctx->substream_min_pixels = v; }
     if (const char *e = std::getenv("HRT_SUBSTREAMS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) ctx->substreams = v; }
     if (const char *e = std::getenv("HRT_POSTPONE_PCT")) { const int v = std::atoi(e); if (v >= 0 && v <= 100) ctx->postpone_pct = v; }
     if (const char *e = std::getenv("HRT_REFILL_THRESHOLD")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->refill_threshold = v; }
@@ -618,7 +620,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
     //      launch ends with a tail (the longest rays, ~0.3 ms) during which most CUs idle; with
     //      2-3 independent sub-tiles in flight one sub-tile's tail overlaps another's bulk. ----
     uint32_t S = (uint32_t)ctx->substreams;
-    while (S > 1 && n / S < 131072u) --S;
+    while (S > 1 && n / S < (uint32_t)ctx->substream_min_pixels) --S;
     if (S > 1) {
         while (ctx->sub_streams.size() < S) {
             hipStream_t st; HIP_TRY(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); ctx->sub_streams.push_back(st);
