@@ -135,20 +135,26 @@ def main():
     elapsed = float(tt.item())
     total_rays = float(rays[0].item())
 
-    # ---- per-ray node / primitive counts of the closest-hit kernel: one extra untimed sample pass ----
+    # ---- per-ray node / primitive counts (canonical walk order): one extra untimed pass ----
     r.set_flags(hrt.CTX_COUNT)
     r.reset_stats()
-    r.render(1, tile=tile, sync=True)
+    r.render(2, tile=tile, sync=True)
     sc = r.stats()
     nodes_per_ray = sc.node_visits_closest / max(sc.rays_closest, 1)
     prims_per_ray = sc.prim_tests_closest / max(sc.rays_closest, 1)
     bytes_per_ray = RAY_BYTES + NODE_BYTES * nodes_per_ray + PRIM_BYTES * prims_per_ray + HIT_BYTES
+    any_nodes = (sc.node_visits - sc.node_visits_closest) / max(sc.rays_any, 1)
+    any_prims = (sc.prim_tests - sc.prim_tests_closest) / max(sc.rays_any, 1)
+    bytes_per_any_ray = RAY_BYTES + NODE_BYTES * any_nodes + PRIM_BYTES * any_prims + HIT_BYTES
+
     if rank == 0:
-        trav_ms = st.kernel_ms[hrt.K_TRAVERSE]
-        trav_launches = max(int(st.kernel_launches[hrt.K_TRAVERSE]), 1)
+        # every traverse launch of the timed region (closest-hit rays, and the depth-5 any-hit rays that ride along)
+        trav_ms = st.kernel_ms[hrt.K_TRAVERSE] + st.kernel_ms[hrt.K_TRAVERSE_ANY]
+        trav_launches = max(int(st.kernel_launches[hrt.K_TRAVERSE] + st.kernel_launches[hrt.K_TRAVERSE_ANY]), 1)
         avg_launch_ms = trav_ms / trav_launches
-        rays_per_launch = st.rays_closest / trav_launches
-        achieved = bytes_per_ray * rays_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        rays_per_launch = st.rays / trav_launches
+        bytes_per_launch = (bytes_per_ray * st.rays_closest + bytes_per_any_ray * st.rays_any) / trav_launches
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         traffic = None
         tf = ROOT / "profiles" / "traverse_traffic.json"
         if tf.exists():
@@ -171,10 +177,11 @@ def main():
                                    f"{W}x{H}, {spp} spp, depth {5}, tile-split x{world} (8-row stripes, BVH replicated)",
                        "rays_per_step": int(total_rays / max(args.steps, 1)), "rays_per_path": round(st.rays / max(st.paths, 1), 4),
                        "bvh_nodes": int(st.bvh_nodes), "bvh_bytes": int(st.bvh_bytes), "bvh_build_s": round(build_s, 2)},
-            "roofline": {"bound": "hbm", "kernel": "k_traverse (closest hit)", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_traverse", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 3),
-                         "prims_per_ray": round(prims_per_ray, 3), "avg_launch_ms": round(avg_launch_ms, 4),
+                         "prims_per_ray": round(prims_per_ray, 3), "bytes_per_any_hit_ray": round(bytes_per_any_ray, 1),
+                         "bytes_per_launch": round(bytes_per_launch, 0), "avg_launch_ms": round(avg_launch_ms, 4),
                          "rays_per_launch": round(rays_per_launch, 1), "launches": trav_launches},
             "kernel_ms": {hrt.KERNEL_NAMES[k]: round(st.kernel_ms[k], 3) for k in range(hrt.K_COUNT)},
         }

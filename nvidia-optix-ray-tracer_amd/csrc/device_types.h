@@ -44,25 +44,30 @@ struct GenerateArgs {
     float center[3], U[3], V[3], W[3];
 };
 
+// one input queue of a traverse launch and where its hit records go
+struct TraverseSeg {
+    const RayRec *rays;            // NULL: segment unused
+    const uint32_t *n_ptr;         // 4 device counters whose sum is the queue length, or NULL
+    uint32_t n;                    // used when n_ptr == NULL
+    uint32_t any_hit;              // 1: the rays only need hit / no hit (depth >= rayTraceDepth)
+    float4 *hit_tuvp;              // t, u, v, primitive index (bits); t = tmax on miss
+    uint32_t *hit_inst;            // instance index, kMissPrim on miss
+    uint64_t *count_nodes, *count_prims;   // COUNT builds
+};
+
 struct TraverseArgs {
     const void *nodes;             // Bvh8Node[]
     const void *prims;             // PrimRecord[]
     uint32_t node_stride, prim_stride;   // bytes between consecutive records (80 / 48 when packed)
-    const RayRec *rays;
-    const uint32_t *n_rays_ptr;    // 4 device counters whose sum is the queue length, or NULL
-    uint32_t n_rays;               // used when n_rays_ptr == NULL
-    uint32_t *fetch_counter;       // zeroed before the launch
-    float4 *hit_tuvp;              // t, u, v, primitive index (bits); t = tmax on miss
-    uint32_t *hit_inst;            // instance index, kMissPrim on miss
+    TraverseSeg seg[2];
+    uint32_t *fetch_counter;       // 8 slice counters on 128-byte lines, zeroed before the launch
     const float *inst_inv;         // 12 floats per instance: world->object (spheres)
     const uint32_t *inst_identity;
     float tmin, tmax;
     int refill_threshold;          // refill when at least this many lanes are idle
     uint32_t fetch_chunk;          // rays per slice a wave takes from the queue
     int tail_split;                // split long rays across idle lanes once the queue is drained
-    int postpone_pct;              // leaf work is postponed while fewer than this % of the alive lanes have any
-    uint64_t *count_nodes, *count_prims;
-    uint64_t *debug;               // COUNT only: [0] wave iterations, [1] wave leaf passes, [2] sum of alive lanes per iteration
+    int postpone_pct;              // the leaf pass is skipped while fewer than this % of the alive lanes have leaf work and none needs it
 };
 
 struct BinArgs {
@@ -91,10 +96,9 @@ struct AccumArgs {
     const RayRec *rays_in; const uint32_t *hit_inst;
     const HitGroup *hitgroups;
     const uint32_t *chain;
-    float4 *accum;
+    float4 *result;                // per tile pixel: linear radiance of this sample
     float bg[3];
     uint32_t depth;
-    uint32_t first_sample;
 };
 
 struct FinalizeArgs {
@@ -106,7 +110,8 @@ struct FinalizeArgs {
 // host-callable launchers (defined in kernels.hip)
 void launch_rng_init(RngState *states, uint32_t n, uint64_t salt, const uint32_t *d_jump, hipStream_t s);
 void launch_generate(const GenerateArgs &a, hipStream_t s);
-void launch_traverse(const TraverseArgs &a, bool any_hit, bool count, bool has_spheres, bool dma, uint32_t grid_blocks, hipStream_t s);
+void launch_traverse(const TraverseArgs &a, bool count, bool has_spheres, bool dma, uint32_t grid_blocks, hipStream_t s);
+void launch_sum(float4 *accum, const float4 *result, uint32_t n, uint32_t first_sample, hipStream_t s);
 void launch_bin(const BinArgs &a, uint32_t grid_blocks, hipStream_t s);
 void launch_shade(const ShadeArgs &a, int program, uint32_t grid_blocks, hipStream_t s);
 void launch_accumulate(const AccumArgs &a, uint32_t grid_blocks, hipStream_t s);

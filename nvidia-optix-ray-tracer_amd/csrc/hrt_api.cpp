@@ -52,15 +52,21 @@ static_assert(sizeof(StageCounters) == 128 + 8 * 128, "stage counters layout");
 
 struct DeviceStats { uint64_t rays_closest, rays_any, nodes_closest, prims_closest, nodes_any, prims_any; uint64_t debug[4]; };
 
+// Everything one sample needs besides the per-pixel state.  Two sets (sample parity): the stages of
+// two consecutive samples overlap in time (hrt_render_launch), never more.
+struct SampleSet {
+    RayRec *rays[2] = {nullptr, nullptr};  // depth d reads rays[(d-1)&1], shade writes rays[d&1]
+    float4 *hit_tuvp = nullptr; uint32_t *hit_inst = nullptr;
+    uint32_t *bin_items = nullptr;          // kNumBins x n ray indices
+    uint32_t *chain = nullptr;              // 4 instance indices per tile pixel
+    float4 *result = nullptr;               // the sample's linear radiance per tile pixel
+    StageCounters *stages = nullptr;        // [sub-tile][kRayTraceDepth + 1]
+};
 struct Workspace {
     uint32_t capacity = 0, rows_capacity = 0;
-    RayRec *rays[2] = {nullptr, nullptr};
-    float4 *hit_tuvp = nullptr; uint32_t *hit_inst = nullptr;
-    uint32_t *bin_items = nullptr;
-    uint32_t *chain = nullptr;
+    SampleSet set[2];
     float4 *accum = nullptr;
     uint32_t *rows = nullptr;
-    StageCounters *stages = nullptr;       // [kRayTraceDepth + 1]
 };
 
 struct TimedSpan { int kind; hipEvent_t a, b; };
@@ -291,18 +297,27 @@ int build_tlas_into(HrtContext *ctx, Tlas &t, const HrtInstance *d_instances, ui
     return HRT_OK;
 }
 
+constexpr int kMaxSubTiles = 8;
+
 int ensure_workspace(HrtContext *ctx, uint32_t n, uint32_t height) {
     Workspace &w = ctx->ws;
     if (n > w.capacity) {
-        if (w.rays[0]) { (void)hipFree(w.rays[0]); (void)hipFree(w.rays[1]); (void)hipFree(w.hit_tuvp); (void)hipFree(w.hit_inst);
-                         (void)hipFree(w.bin_items); (void)hipFree(w.chain); (void)hipFree(w.accum); }
-        w.capacity = 0;
-        HIP_TRY(ctx, hipMalloc((void **)&w.rays[0], sizeof(RayRec) * (size_t)n));
-        HIP_TRY(ctx, hipMalloc((void **)&w.rays[1], sizeof(RayRec) * (size_t)n));
-        HIP_TRY(ctx, hipMalloc((void **)&w.hit_tuvp, sizeof(float4) * (size_t)n));
-        HIP_TRY(ctx, hipMalloc((void **)&w.hit_inst, sizeof(uint32_t) * (size_t)n));
-        HIP_TRY(ctx, hipMalloc((void **)&w.bin_items, sizeof(uint32_t) * (size_t)n * kNumBins));
-        HIP_TRY(ctx, hipMalloc((void **)&w.chain, sizeof(uint32_t) * 4 * (size_t)n));
+        for (SampleSet &st : w.set) {
+            void *ptrs[] = {st.rays[0], st.rays[1], st.hit_tuvp, st.hit_inst, st.bin_items, st.chain, st.result};
+            for (void *p : ptrs) if (p) (void)hipFree(p);
+            st = SampleSet{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st.stages};
+        }
+        if (w.accum) (void)hipFree(w.accum);
+        w.accum = nullptr; w.capacity = 0;
+        for (SampleSet &st : w.set) {
+            HIP_TRY(ctx, hipMalloc((void **)&st.rays[0], sizeof(RayRec) * (size_t)n));
+            HIP_TRY(ctx, hipMalloc((void **)&st.rays[1], sizeof(RayRec) * (size_t)n));
+            HIP_TRY(ctx, hipMalloc((void **)&st.hit_tuvp, sizeof(float4) * (size_t)n));
+            HIP_TRY(ctx, hipMalloc((void **)&st.hit_inst, sizeof(uint32_t) * (size_t)n));
+            HIP_TRY(ctx, hipMalloc((void **)&st.bin_items, sizeof(uint32_t) * (size_t)n * kNumBins));
+            HIP_TRY(ctx, hipMalloc((void **)&st.chain, sizeof(uint32_t) * 4 * (size_t)n));
+            HIP_TRY(ctx, hipMalloc((void **)&st.result, sizeof(float4) * (size_t)n));
+        }
         HIP_TRY(ctx, hipMalloc((void **)&w.accum, sizeof(float4) * (size_t)n));
         w.capacity = n;
     }
@@ -312,7 +327,8 @@ int ensure_workspace(HrtContext *ctx, uint32_t n, uint32_t height) {
         HIP_TRY(ctx, hipMalloc((void **)&w.rows, sizeof(uint32_t) * (size_t)height));
         w.rows_capacity = height;
     }
-    if (!w.stages) HIP_TRY(ctx, hipMalloc((void **)&w.stages, sizeof(StageCounters) * (kRayTraceDepth + 1) * 8));
+    for (SampleSet &st : w.set)
+        if (!st.stages) HIP_TRY(ctx, hipMalloc((void **)&st.stages, sizeof(StageCounters) * (kRayTraceDepth + 1) * kMaxSubTiles));
     return HRT_OK;
 }
 
@@ -397,8 +413,11 @@ int hrt_ctx_destroy(HrtContext *ctx) {
     (void)hipDeviceSynchronize();
     for (auto &kv : ctx->tlas) free_tlas_device(*kv.second);
     Workspace &w = ctx->ws;
-    void *ptrs[] = {w.rays[0], w.rays[1], w.hit_tuvp, w.hit_inst, w.bin_items, w.chain, w.accum, w.rows, w.stages,
-                    ctx->d_jump, ctx->d_stats, ctx->d_hitgroups, ctx->d_inst_program};
+    for (SampleSet &st : w.set) {
+        void *sp[] = {st.rays[0], st.rays[1], st.hit_tuvp, st.hit_inst, st.bin_items, st.chain, st.result, st.stages};
+        for (void *p : sp) if (p) (void)hipFree(p);
+    }
+    void *ptrs[] = {w.accum, w.rows, ctx->d_jump, ctx->d_stats, ctx->d_hitgroups, ctx->d_inst_program};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->sub_done) (void)hipEventDestroy(e);
@@ -630,72 +649,110 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, s));
         for (uint32_t k = 0; k < S; ++k) HIP_TRY(ctx, hipStreamWaitEvent(ctx->sub_streams[k], ctx->ev_begin, 0));
     }
-    struct Sub { uint32_t j0, n; hipStream_t st; StageCounters *stages; uint32_t grid_wide, grid_trav; };
+    struct Sub { uint32_t j0, n; hipStream_t st; uint32_t index; uint32_t grid_wide, grid_trav; };
+    if (S > (uint32_t)kMaxSubTiles) S = kMaxSubTiles;
     std::vector<Sub> subs(S);
     for (uint32_t k = 0; k < S; ++k) {
         const uint32_t j0 = (uint32_t)((uint64_t)n * k / S), j1 = (uint32_t)((uint64_t)n * (k + 1) / S);
-        subs[k].j0 = j0; subs[k].n = j1 - j0; subs[k].st = S > 1 ? ctx->sub_streams[k] : s;
-        subs[k].stages = w.stages + (size_t)k * (kRayTraceDepth + 1);
+        subs[k].j0 = j0; subs[k].n = j1 - j0; subs[k].st = S > 1 ? ctx->sub_streams[k] : s; subs[k].index = k;
         subs[k].grid_wide = std::min<uint32_t>((uint32_t)ctx->n_cu * 8u, (subs[k].n + 255u) / 256u);
-        subs[k].grid_trav = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (subs[k].n + 63u) / 64u);
+        subs[k].grid_trav = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (2u * subs[k].n + 63u) / 64u);
     }
 
+    // ---- schedule.  Class (s, d) = the rays of sample s at depth d.  Samples are sequential per pixel
+    //      (one persistent RNG stream), but two things are off that chain: the primary rays of sample
+    //      s+1 draw no random numbers, and the depth-5 rays of sample s only decide black / background.
+    //      They ride along with the launches of the chain:
+    //          T{(s,2),(s-1,5)}   T{(s,3)}   T{(s,4),(s+1,1)}
+    //      so a sample costs three traversal launches instead of five, and the under-filled depth-5
+    //      launch disappears.  Shading order (RNG) and the order of the per-sample sums stay sequential. ----
+    auto stages_of = [&](uint32_t sample, const Sub &sb) { return w.set[sample & 1u].stages + (size_t)sb.index * (kRayTraceDepth + 1); };
+    auto seg_of = [&](uint32_t sample, uint32_t depth, const Sub &sb) {
+        SampleSet &st = w.set[sample & 1u];
+        TraverseSeg g{};
+        g.rays = st.rays[(depth - 1u) & 1u] + sb.j0;
+        g.n_ptr = depth == 1 ? nullptr : &stages_of(sample, sb)[depth - 1].bin_count[1];
+        g.n = sb.n;
+        g.any_hit = depth >= kRayTraceDepth ? 1u : 0u;      // a hit at the depth limit is black whatever it is (Shader.cu:102-107)
+        g.hit_tuvp = st.hit_tuvp + sb.j0; g.hit_inst = st.hit_inst + sb.j0;
+        g.count_nodes = g.any_hit ? &ctx->d_stats->nodes_any : &ctx->d_stats->nodes_closest;
+        g.count_prims = g.any_hit ? &ctx->d_stats->prims_any : &ctx->d_stats->prims_closest;
+        return g;
+    };
+    auto do_generate = [&](uint32_t sample, const Sub &sb) -> int {
+        HIP_TRY(ctx, hipMemsetAsync(stages_of(sample, sb), 0, sizeof(StageCounters) * (kRayTraceDepth + 1), sb.st));
+        GenerateArgs ga{};
+        ga.rays = w.set[sample & 1u].rays[0] + sb.j0; ga.rows = w.rows; ga.first_pixel = sb.j0; ga.n_tile_pixels = sb.n;
+        ga.width = rg->width; ga.height = rg->height;
+        std::memcpy(ga.center, &rg->cameraCenter, 12); std::memcpy(ga.U, &rg->cameraU, 12);
+        std::memcpy(ga.V, &rg->cameraV, 12); std::memcpy(ga.W, &rg->cameraW, 12);
+        Timer tm(ctx, sb.st, HRT_K_GENERATE); launch_generate(ga, sb.st);
+        return HRT_OK;
+    };
+    // one traverse launch over class (sa, da) and, optionally, class (sb_, db)
+    auto do_traverse = [&](const Sub &sb, uint32_t sa, uint32_t da, bool second, uint32_t sb_, uint32_t db) {
+        TraverseArgs ta{};
+        ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.node_stride = t->node_stride; ta.prim_stride = t->prim_stride;
+        ta.seg[0] = seg_of(sa, da, sb);
+        if (second) ta.seg[1] = seg_of(sb_, db, sb);
+        ta.fetch_counter = stages_of(sa, sb)[da].fetch;
+        ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
+        ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;      // Shader.cu:232, :266
+        ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fetch_chunk;
+        Timer tm(ctx, sb.st, (da >= kRayTraceDepth && !second) ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
+        launch_traverse(ta, count, t->has_spheres, ctx->lds_gather != 0, sb.grid_trav, sb.st);
+    };
+    // everything that follows the traversal of class (sample, depth): binning, shading, path ends
+    auto do_after = [&](const Sub &sb, uint32_t sample, uint32_t depth) {
+        SampleSet &st = w.set[sample & 1u];
+        StageCounters *stg = stages_of(sample, sb);
+        hipStream_t strm = sb.st;
+        uint32_t *bin_items = st.bin_items + (size_t)sb.j0 * kNumBins;
+        const RayRec *rays_in = st.rays[(depth - 1u) & 1u] + sb.j0;
+        BinArgs ba{};
+        ba.n_rays_ptr = depth == 1 ? nullptr : &stg[depth - 1].bin_count[1]; ba.n_rays = sb.n;
+        ba.hit_inst = st.hit_inst + sb.j0; ba.inst_program = ctx->d_inst_program; ba.depth = depth;
+        ba.bin_count = stg[depth].bin_count; ba.bin_items = bin_items; ba.bin_stride = sb.n;
+        ba.total_rays = depth >= kRayTraceDepth ? &ctx->d_stats->rays_any : &ctx->d_stats->rays_closest;
+        { Timer tm(ctx, strm, HRT_K_BIN); launch_bin(ba, sb.grid_wide, strm); }
+        if (depth < kRayTraceDepth) {
+            ShadeArgs sa{};
+            sa.bin_count = stg[depth].bin_count; sa.bin_items = bin_items; sa.bin_stride = sb.n;
+            sa.rays_in = rays_in; sa.rays_out = st.rays[depth & 1u] + sb.j0;
+            sa.hit_tuvp = st.hit_tuvp + sb.j0; sa.hit_inst = st.hit_inst + sb.j0; sa.hitgroups = ctx->d_hitgroups;
+            sa.states = reinterpret_cast<RngState *>(h_params->stateArray);
+            sa.chain = st.chain; sa.depth = depth;
+            for (int p = 0; p < (int)kNumPrograms; ++p)
+                if (ctx->program_present[p]) { Timer tm(ctx, strm, HRT_K_SHADE); launch_shade(sa, p, sb.grid_wide, strm); }
+        }
+        AccumArgs aa{};
+        aa.bin_count = stg[depth].bin_count; aa.bin_items = bin_items; aa.rays_in = rays_in; aa.hit_inst = st.hit_inst + sb.j0;
+        aa.hitgroups = ctx->d_hitgroups; aa.chain = st.chain; aa.result = st.result;
+        aa.bg[0] = ctx->miss.backgroundColor.x; aa.bg[1] = ctx->miss.backgroundColor.y; aa.bg[2] = ctx->miss.backgroundColor.z;
+        aa.depth = depth;
+        { Timer tm(ctx, strm, HRT_K_ACCUMULATE); launch_accumulate(aa, sb.grid_wide, strm); }
+        if (depth >= kRayTraceDepth) {       // the sample is complete: add it, in sample order
+            Timer tm(ctx, strm, HRT_K_ACCUMULATE);
+            launch_sum(w.accum + sb.j0, st.result + sb.j0, sb.n, sample == 0 ? 1u : 0u, strm);
+        }
+    };
+
+    for (const Sub &sb : subs) { rc = do_generate(0, sb); if (rc != HRT_OK) return rc; }
+    for (const Sub &sb : subs) do_traverse(sb, 0, 1, false, 0, 0);
     for (uint32_t sample = 0; sample < spp; ++sample) {
-        for (const Sub &sb : subs) {
-            HIP_TRY(ctx, hipMemsetAsync(sb.stages, 0, sizeof(StageCounters) * (kRayTraceDepth + 1), sb.st));
-            GenerateArgs ga{};
-            ga.rays = w.rays[0] + sb.j0; ga.rows = w.rows; ga.first_pixel = sb.j0; ga.n_tile_pixels = sb.n;
-            ga.width = rg->width; ga.height = rg->height;
-            std::memcpy(ga.center, &rg->cameraCenter, 12); std::memcpy(ga.U, &rg->cameraU, 12);
-            std::memcpy(ga.V, &rg->cameraV, 12); std::memcpy(ga.W, &rg->cameraW, 12);
-            Timer tm(ctx, sb.st, HRT_K_GENERATE); launch_generate(ga, sb.st);
-        }
-        int cur = 0;
-        for (uint32_t depth = 1; depth <= kRayTraceDepth; ++depth) {
-            const bool any_hit = depth >= kRayTraceDepth;      // a hit at the depth limit is black whatever it is (Shader.cu:102-107)
-            for (const Sub &sb : subs) {
-                hipStream_t st = sb.st;
-                const uint32_t *n_ptr = depth == 1 ? nullptr : &sb.stages[depth - 1].bin_count[1];
-                uint32_t *bin_items = w.bin_items + (size_t)sb.j0 * kNumBins;
-                TraverseArgs ta{};
-                ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.node_stride = t->node_stride; ta.prim_stride = t->prim_stride; ta.rays = w.rays[cur] + sb.j0;
-                ta.n_rays_ptr = n_ptr; ta.n_rays = sb.n; ta.fetch_counter = sb.stages[depth].fetch;
-                ta.hit_tuvp = w.hit_tuvp + sb.j0; ta.hit_inst = w.hit_inst + sb.j0;
-                ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
-                ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;      // Shader.cu:232, :266
-                ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fetch_chunk;
-                ta.count_nodes = any_hit ? &ctx->d_stats->nodes_any : &ctx->d_stats->nodes_closest;
-                ta.count_prims = any_hit ? &ctx->d_stats->prims_any : &ctx->d_stats->prims_closest;
-                ta.debug = any_hit ? nullptr : ctx->d_stats->debug;
-                { Timer tm(ctx, st, any_hit ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
-                  launch_traverse(ta, any_hit, count, t->has_spheres, ctx->lds_gather != 0, sb.grid_trav, st); }
-
-                BinArgs ba{};
-                ba.n_rays_ptr = n_ptr; ba.n_rays = sb.n; ba.hit_inst = w.hit_inst + sb.j0; ba.inst_program = ctx->d_inst_program; ba.depth = depth;
-                ba.bin_count = sb.stages[depth].bin_count; ba.bin_items = bin_items; ba.bin_stride = sb.n;
-                ba.total_rays = any_hit ? &ctx->d_stats->rays_any : &ctx->d_stats->rays_closest;
-                { Timer tm(ctx, st, HRT_K_BIN); launch_bin(ba, sb.grid_wide, st); }
-
-                if (depth < kRayTraceDepth) {
-                    ShadeArgs sa{};
-                    sa.bin_count = sb.stages[depth].bin_count; sa.bin_items = bin_items; sa.bin_stride = sb.n;
-                    sa.rays_in = w.rays[cur] + sb.j0; sa.rays_out = w.rays[cur ^ 1] + sb.j0;
-                    sa.hit_tuvp = w.hit_tuvp + sb.j0; sa.hit_inst = w.hit_inst + sb.j0; sa.hitgroups = ctx->d_hitgroups;
-                    sa.states = reinterpret_cast<RngState *>(h_params->stateArray);
-                    sa.chain = w.chain; sa.depth = depth;
-                    for (int p = 0; p < (int)kNumPrograms; ++p)
-                        if (ctx->program_present[p]) { Timer tm(ctx, st, HRT_K_SHADE); launch_shade(sa, p, sb.grid_wide, st); }
-                }
-                AccumArgs aa{};
-                aa.bin_count = sb.stages[depth].bin_count; aa.bin_items = bin_items; aa.rays_in = w.rays[cur] + sb.j0; aa.hit_inst = w.hit_inst + sb.j0;
-                aa.hitgroups = ctx->d_hitgroups; aa.chain = w.chain; aa.accum = w.accum;
-                aa.bg[0] = ctx->miss.backgroundColor.x; aa.bg[1] = ctx->miss.backgroundColor.y; aa.bg[2] = ctx->miss.backgroundColor.z;
-                aa.depth = depth; aa.first_sample = sample == 0 ? 1u : 0u;
-                { Timer tm(ctx, st, HRT_K_ACCUMULATE); launch_accumulate(aa, sb.grid_wide, st); }
-            }
-            cur ^= 1;
-        }
+        const bool prev = sample > 0, next = sample + 1 < spp;
+        for (const Sub &sb : subs) do_after(sb, sample, 1);
+        for (const Sub &sb : subs) do_traverse(sb, sample, 2, prev, sample - 1, kRayTraceDepth);
+        if (prev) for (const Sub &sb : subs) do_after(sb, sample - 1, kRayTraceDepth);
+        for (const Sub &sb : subs) do_after(sb, sample, 2);
+        for (const Sub &sb : subs) do_traverse(sb, sample, 3, false, 0, 0);
+        for (const Sub &sb : subs) do_after(sb, sample, 3);
+        if (next) for (const Sub &sb : subs) { rc = do_generate(sample + 1, sb); if (rc != HRT_OK) return rc; }
+        for (const Sub &sb : subs) do_traverse(sb, sample, 4, next, sample + 1, 1);
+        for (const Sub &sb : subs) do_after(sb, sample, 4);
     }
+    for (const Sub &sb : subs) do_traverse(sb, spp - 1, kRayTraceDepth, false, 0, 0);
+    for (const Sub &sb : subs) do_after(sb, spp - 1, kRayTraceDepth);
     if (S > 1) {
         for (uint32_t k = 0; k < S; ++k) {
             HIP_TRY(ctx, hipEventRecord(ctx->sub_done[k], ctx->sub_streams[k]));
@@ -782,15 +839,17 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
     HIP_TRY(ctx, hipMemsetAsync(fetch, 0, sizeof(uint32_t) * 8 * 32, s));
     launch_pack_rays(reinterpret_cast<const float *>(d_origins), reinterpret_cast<const float *>(d_directions), n_rays, rays, s);
     TraverseArgs ta{};
-    ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.node_stride = t->node_stride; ta.prim_stride = t->prim_stride; ta.rays = rays; ta.n_rays_ptr = nullptr; ta.n_rays = n_rays;
-    ta.fetch_counter = fetch; ta.hit_tuvp = tuvp; ta.hit_inst = inst; ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
-    ta.tmin = tmin; ta.tmax = tmax; ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fetch_chunk;
-    ta.count_nodes = any_hit ? &ctx->d_stats->nodes_any : &ctx->d_stats->nodes_closest;
-    ta.count_prims = any_hit ? &ctx->d_stats->prims_any : &ctx->d_stats->prims_closest;
-    ta.debug = any_hit ? nullptr : ctx->d_stats->debug;
+    ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.node_stride = t->node_stride; ta.prim_stride = t->prim_stride;
+    ta.seg[0].rays = rays; ta.seg[0].n_ptr = nullptr; ta.seg[0].n = n_rays; ta.seg[0].any_hit = any_hit ? 1u : 0u;
+    ta.seg[0].hit_tuvp = tuvp; ta.seg[0].hit_inst = inst;
+    ta.seg[0].count_nodes = any_hit ? &ctx->d_stats->nodes_any : &ctx->d_stats->nodes_closest;
+    ta.seg[0].count_prims = any_hit ? &ctx->d_stats->prims_any : &ctx->d_stats->prims_closest;
+    ta.fetch_counter = fetch; ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
+    ta.tmin = tmin; ta.tmax = tmax; ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct;
+    ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fetch_chunk;
     const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (n_rays + 63u) / 64u);
     { Timer tm(ctx, s, any_hit ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
-      launch_traverse(ta, any_hit != 0, (ctx->flags & HRT_CTX_COUNT) != 0, t->has_spheres, ctx->lds_gather != 0, grid, s); }
+      launch_traverse(ta, (ctx->flags & HRT_CTX_COUNT) != 0, t->has_spheres, ctx->lds_gather != 0, grid, s); }
     launch_unpack_hits(tuvp, inst, n_rays, d_t, d_u, d_v, d_prim, d_inst, s);
     hipError_t e = hipStreamSynchronize(s);
     (void)hipFree(rays); (void)hipFree(tuvp); (void)hipFree(inst); (void)hipFree(fetch);

@@ -289,7 +289,7 @@ __device__ __forceinline__ void wait_node_loads(u32x4 &a, u32x4 &b, u32x4 &c, u3
 __device__ __forceinline__ void wait_prim_gather() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
 __device__ __forceinline__ void wait_node_gather() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <bool ANY_HIT, bool COUNT, bool HAS_SPHERES, bool DMA>
+template <bool COUNT, bool HAS_SPHERES, bool DMA>
 __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     static_assert(kTraverseBlock == 64, "one wave per workgroup: staging images and mailboxes are per wave");
     __shared__ uint2 s_stack[kLdsStack][kTraverseBlock];
@@ -301,7 +301,11 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     __shared__ uint32_t s_pair[kTraverseBlock];
     uint2 spill[kSpillStack];
 
-    const uint32_t n_rays = a.n_rays_ptr ? (a.n_rays_ptr[0] + a.n_rays_ptr[1] + a.n_rays_ptr[2] + a.n_rays_ptr[3]) : a.n_rays;
+    // up to two queue segments per launch (e.g. the depth-4 rays of sample s and the primary rays of
+    // sample s+1): ray i < n_a comes from segment 0, the others from segment 1
+    const uint32_t n_a = a.seg[0].n_ptr ? (a.seg[0].n_ptr[0] + a.seg[0].n_ptr[1] + a.seg[0].n_ptr[2] + a.seg[0].n_ptr[3]) : a.seg[0].n;
+    const uint32_t n_b = a.seg[1].rays ? (a.seg[1].n_ptr ? (a.seg[1].n_ptr[0] + a.seg[1].n_ptr[1] + a.seg[1].n_ptr[2] + a.seg[1].n_ptr[3]) : a.seg[1].n) : 0u;
+    const uint32_t n_rays = n_a + n_b;
     const char *__restrict__ node_bytes = reinterpret_cast<const char *>(a.nodes);
     const char *__restrict__ prim_bytes = reinterpret_cast<const char *>(a.prims);
     const float tmin = a.tmin, tmax_ray = a.tmax;
@@ -321,7 +325,9 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     bool exhausted = false;                 // wave-uniform
     bool shared = false;                    // this lane works on a ray that has been split across lanes
     uint32_t home = tx;                     // lane whose mailbox collects the split ray's result
-    uint32_t cnt_nodes = 0, cnt_prims = 0;
+    uint32_t cnt_nodes = 0, cnt_prims = 0, cnt_nodes_b = 0, cnt_prims_b = 0;
+    bool any = false;                       // this lane's ray only needs to know whether anything is hit
+    bool in_b = false;                      // ... and belongs to segment 1
 
     // what the next iteration gathers for this lane
     bool has_node = false, has_prim = false;
@@ -387,7 +393,9 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                 const uint32_t mine = wbeg + rank;
                 wbeg += take;
                 if (!alive && rank < take) {
-                    const RayRec r = a.rays[mine];
+                    in_b = mine >= n_a;
+                    any = (in_b ? a.seg[1].any_hit : a.seg[0].any_hit) != 0u;
+                    const RayRec r = in_b ? a.seg[1].rays[mine - n_a] : a.seg[0].rays[mine];
                     s.ox = r.o.x; s.oy = r.o.y; s.oz = r.o.z;
                     s.dx = r.d.x; s.dy = r.d.y; s.dz = r.d.z;
                     s.idx = safe_rcp_dir(s.dx); s.idy = safe_rcp_dir(s.dy); s.idz = safe_rcp_dir(s.dz);
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                     s.cur = make_uint2(0u, 0x80000000u);
                     s.ptri = make_uint2(0u, 0u);
                     s.sp = 0; s.base = 0;
-                    s.slot = mine;
+                    s.slot = in_b ? mine - n_a : mine;
                     alive = true; has_prim = false; pidx = 0u;
                     advance_select();                   // the root becomes this lane's next node
                 }
@@ -442,6 +450,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                     const uint32_t r_bp = (uint32_t)__shfl((int)s.bprim, src), r_bi = (uint32_t)__shfl((int)s.binst, src);
                     const uint32_t r_oct = (uint32_t)__shfl((int)s.oct_inv4, src), r_slot = (uint32_t)__shfl((int)s.slot, src);
                     const uint32_t r_home = (uint32_t)__shfl((int)home, src);
+                    const uint32_t r_flags = (uint32_t)__shfl((int)((any ? 1u : 0u) | (in_b ? 2u : 0u)), src);
                     const uint32_t r_gx = (uint32_t)__shfl((int)give.x, src), r_gy = (uint32_t)__shfl((int)give.y, src);
                     if (is_recv) {
                         s.ox = r_ox; s.oy = r_oy; s.oz = r_oz; s.dx = r_dx; s.dy = r_dy; s.dz = r_dz;
@@ -452,6 +461,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                         else { s.cur = make_uint2(0u, 0u); s.ptri = make_uint2(r_gx, r_gy); }
                         s.sp = 0; s.base = 0;
                         home = r_home; shared = true; alive = true; has_prim = false; pidx = 0u;
+                        any = (r_flags & 1u) != 0u; in_b = (r_flags & 2u) != 0u;
                         advance_select();
                     }
                 }
@@ -476,7 +486,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
             }
 
             bool done = false;
-            if (ANY_HIT && alive && shared && s_mb_prim[home] != kMissPrim) done = true;   // another piece already found a hit
+            if (any && alive && shared && s_mb_prim[home] != kMissPrim) done = true;   // another piece already found a hit
 
             // ---- C. leaf test: waits for the primitive pieces only ----
             if (DMA) wait_prim_gather(); else wait_prim_loads(rpa, rpb, rpc);
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                     pc = make_float4(rpc.x, rpc.y, rpc.z, rpc.w);
                 }
                 const bool better = test_prim<HAS_SPHERES>(pa, pb, pc, s, tmin, tmax_ray, a.inst_inv, a.inst_identity);
-                if (ANY_HIT && better) done = true;
+                if (any && better) done = true;
             }
             has_prim = false; pidx = 0u;
 
@@ -508,7 +518,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                     n2 = make_uint4(rn2.x, rn2.y, rn2.z, rn2.w); n3 = make_uint4(rn3.x, rn3.y, rn3.z, rn3.w);
                     n4 = make_uint4(rn4.x, rn4.y, rn4.z, rn4.w);
                 }
-                if (COUNT) ++cnt_nodes;
+                if (COUNT) { if (in_b) ++cnt_nodes_b; else ++cnt_nodes; }
                 const float px = __uint_as_float(n0.x), py = __uint_as_float(n0.y), pz = __uint_as_float(n0.z);
                 const uint32_t e_imask = n0.w;
                 const float aix = __uint_as_float((e_imask & 0xffu) << 23) * s.idx;
@@ -554,10 +564,10 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                 while (alive && !done && tri.y != 0u) {
                     const uint32_t k = (uint32_t)__ffs((int)tri.y) - 1u;
                     tri.y &= tri.y - 1u;
-                    ++cnt_prims;
+                    if (in_b) ++cnt_prims_b; else ++cnt_prims;
                     const float4 *pp = reinterpret_cast<const float4 *>(prim_bytes + (size_t)(tri.x + k) * a.prim_stride);
                     const bool better = test_prim<HAS_SPHERES>(pp[0], pp[1], pp[2], s, tmin, tmax_ray, a.inst_inv, a.inst_identity);
-                    if (ANY_HIT && better) done = true;
+                    if (any && better) done = true;
                 }
             }
 
@@ -591,8 +601,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
             if (alive) {
                 if (!done && !has_node && !has_prim && s.ptri.y == 0u) done = true;
                 if (done && !shared) {
-                    a.hit_tuvp[s.slot] = make_float4(s.bt, s.bu, s.bv, __uint_as_float(s.bprim));
-                    a.hit_inst[s.slot] = s.binst;
+                    (in_b ? a.seg[1].hit_tuvp : a.seg[0].hit_tuvp)[s.slot] = make_float4(s.bt, s.bu, s.bv, __uint_as_float(s.bprim));
+                    (in_b ? a.seg[1].hit_inst : a.seg[0].hit_inst)[s.slot] = s.binst;
                     alive = false; has_node = false; has_prim = false; nidx = 0u; pidx = 0u;
                 }
             }
@@ -605,14 +615,14 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                     const float mt = s_mb_t[home];
                     const uint64_t mid = ((uint64_t)s_mb_inst[home] << 32) | s_mb_prim[home];
                     const uint64_t id = ((uint64_t)s.binst << 32) | s.bprim;
-                    const bool better = ANY_HIT ? (s.bprim != kMissPrim && s_mb_prim[home] == kMissPrim)
+                    const bool better = any ? (s.bprim != kMissPrim && s_mb_prim[home] == kMissPrim)
                                                 : (s.bt < mt || (s.bt == mt && id < mid));
                     if (better) { s_mb_t[home] = s.bt; s_mb_u[home] = s.bu; s_mb_v[home] = s.bv; s_mb_prim[home] = s.bprim; s_mb_inst[home] = s.binst; }
                     const uint32_t pend = s_mb_pending[home] - 1u;
                     s_mb_pending[home] = pend;
                     if (pend == 0u) {
-                        a.hit_tuvp[s.slot] = make_float4(s_mb_t[home], s_mb_u[home], s_mb_v[home], __uint_as_float(s_mb_prim[home]));
-                        a.hit_inst[s.slot] = s_mb_inst[home];
+                        (in_b ? a.seg[1].hit_tuvp : a.seg[0].hit_tuvp)[s.slot] = make_float4(s_mb_t[home], s_mb_u[home], s_mb_v[home], __uint_as_float(s_mb_prim[home]));
+                        (in_b ? a.seg[1].hit_inst : a.seg[0].hit_inst)[s.slot] = s_mb_inst[home];
                     }
                     alive = false; shared = false; home = tx; has_node = false; has_prim = false; nidx = 0u; pidx = 0u;
                 }
@@ -629,10 +639,16 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
         for (int off = 32; off > 0; off >>= 1) {
             cnt_nodes += (uint32_t)__shfl_down((int)cnt_nodes, off);
             cnt_prims += (uint32_t)__shfl_down((int)cnt_prims, off);
+            cnt_nodes_b += (uint32_t)__shfl_down((int)cnt_nodes_b, off);
+            cnt_prims_b += (uint32_t)__shfl_down((int)cnt_prims_b, off);
         }
         if (tx == 0u) {
-            atomicAdd(reinterpret_cast<unsigned long long *>(a.count_nodes), (unsigned long long)cnt_nodes);
-            atomicAdd(reinterpret_cast<unsigned long long *>(a.count_prims), (unsigned long long)cnt_prims);
+            atomicAdd(reinterpret_cast<unsigned long long *>(a.seg[0].count_nodes), (unsigned long long)cnt_nodes);
+            atomicAdd(reinterpret_cast<unsigned long long *>(a.seg[0].count_prims), (unsigned long long)cnt_prims);
+            if (a.seg[1].rays) {
+                atomicAdd(reinterpret_cast<unsigned long long *>(a.seg[1].count_nodes), (unsigned long long)cnt_nodes_b);
+                atomicAdd(reinterpret_cast<unsigned long long *>(a.seg[1].count_prims), (unsigned long long)cnt_prims_b);
+            }
         }
     }
 }
@@ -816,11 +832,19 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumArgs a) {
             const HitGroup hg = a.hitgroups[chain[k]];
             rx *= hg.albedo[0]; ry *= hg.albedo[1]; rz *= hg.albedo[2];
         }
-        float4 acc;
-        if (a.first_sample) acc = make_float4(rx, ry, rz, 0.0f);
-        else { acc = a.accum[local]; acc.x += rx; acc.y += ry; acc.z += rz; }
-        a.accum[local] = acc;
+        // every pixel ends exactly once per sample: a plain store.  k_sum adds the samples in sample order.
+        a.result[local] = make_float4(rx, ry, rz, 0.0f);
     }
+}
+
+// accum (+)= result, once per sample and strictly in sample order (bit-exact mean): the stages of two
+// consecutive samples overlap in time, their terminations must not be added in stage order.
+__global__ __launch_bounds__(256) void k_sum(float4 *accum, const float4 *result, uint32_t n, uint32_t first_sample) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 r = result[i];
+    if (first_sample) accum[i] = make_float4(r.x, r.y, r.z, 0.0f);
+    else { float4 acc = accum[i]; acc.x += r.x; acc.y += r.y; acc.z += r.z; accum[i] = acc; }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -927,21 +951,19 @@ void launch_rng_init(RngState *states, uint32_t n, uint64_t salt, const uint32_t
 void launch_generate(const GenerateArgs &a, hipStream_t s) {
     if (a.n_tile_pixels) hipLaunchKernelGGL(k_generate, dim3(ceil_div(a.n_tile_pixels, 256)), dim3(256), 0, s, a);
 }
-void launch_traverse(const TraverseArgs &a, bool any_hit, bool count, bool has_spheres, bool dma, uint32_t grid_blocks, hipStream_t s) {
+void launch_traverse(const TraverseArgs &a, bool count, bool has_spheres, bool dma, uint32_t grid_blocks, hipStream_t s) {
     const dim3 g(grid_blocks), b(kTraverseBlock);
-    const int sel = (dma ? 8 : 0) | (any_hit ? 4 : 0) | (count ? 2 : 0) | (has_spheres ? 1 : 0);
-#define HRT_TRAV_CASE(N, A, C, S, D) case N: hipLaunchKernelGGL((k_traverse<A, C, S, D>), g, b, 0, s, a); break;
+    const int sel = (dma ? 4 : 0) | (count ? 2 : 0) | (has_spheres ? 1 : 0);
     switch (sel) {
-        HRT_TRAV_CASE(0, false, false, false, false) HRT_TRAV_CASE(1, false, false, true, false)
-        HRT_TRAV_CASE(2, false, true, false, false)  HRT_TRAV_CASE(3, false, true, true, false)
-        HRT_TRAV_CASE(4, true, false, false, false)  HRT_TRAV_CASE(5, true, false, true, false)
-        HRT_TRAV_CASE(6, true, true, false, false)   HRT_TRAV_CASE(7, true, true, true, false)
-        HRT_TRAV_CASE(8, false, false, false, true)  HRT_TRAV_CASE(9, false, false, true, true)
-        HRT_TRAV_CASE(10, false, true, false, true)  HRT_TRAV_CASE(11, false, true, true, true)
-        HRT_TRAV_CASE(12, true, false, false, true)  HRT_TRAV_CASE(13, true, false, true, true)
-        HRT_TRAV_CASE(14, true, true, false, true)   default: hipLaunchKernelGGL((k_traverse<true, true, true, true>), g, b, 0, s, a); break;
+        case 0: hipLaunchKernelGGL((k_traverse<false, false, false>), g, b, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((k_traverse<false, true, false>), g, b, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_traverse<true, false, false>), g, b, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((k_traverse<true, true, false>), g, b, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((k_traverse<false, false, true>), g, b, 0, s, a); break;
+        case 5: hipLaunchKernelGGL((k_traverse<false, true, true>), g, b, 0, s, a); break;
+        case 6: hipLaunchKernelGGL((k_traverse<true, false, true>), g, b, 0, s, a); break;
+        default: hipLaunchKernelGGL((k_traverse<true, true, true>), g, b, 0, s, a); break;
     }
-#undef HRT_TRAV_CASE
 }
 void launch_bin(const BinArgs &a, uint32_t grid_blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_bin_hits, dim3(grid_blocks), dim3(256), 0, s, a);
@@ -957,6 +979,9 @@ void launch_shade(const ShadeArgs &a, int program, uint32_t grid_blocks, hipStre
 }
 void launch_accumulate(const AccumArgs &a, uint32_t grid_blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_accumulate, dim3(grid_blocks), dim3(256), 0, s, a);
+}
+void launch_sum(float4 *accum, const float4 *result, uint32_t n, uint32_t first_sample, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_sum, dim3(ceil_div(n, 256)), dim3(256), 0, s, accum, result, n, first_sample);
 }
 void launch_finalize(const FinalizeArgs &a, hipStream_t s) {
     if (a.n_tile_pixels) hipLaunchKernelGGL(k_finalize, dim3(ceil_div(a.n_tile_pixels, 256)), dim3(256), 0, s, a);
