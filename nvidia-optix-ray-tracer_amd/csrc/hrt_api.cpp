@@ -110,7 +110,7 @@ struct HrtContext {
     int lds_gather = 0;                         // 1: cooperative LDS-DMA gathers, 0: per-lane register loads
     int fetch_chunk = 64;
     int substream_min_pixels = 32768;
-    int substreams = 1;                         // sub-tiles rendered on their own HIP streams so that one's tail overlaps another's bulk
+    int substreams = 0;                         // sub-tiles rendered on their own HIP streams so that one's tail overlaps another's bulk
     std::vector<hipStream_t> sub_streams; std::vector<hipEvent_t> sub_done; hipEvent_t ev_begin = nullptr;
 };
 
@@ -391,7 +391,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_LDS_GATHER")) ctx->lds_gather = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_TAIL_SPLIT")) ctx->tail_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_SUBSTREAM_MIN_PIXELS")) { const int v = std::atoi(e); if (v >= 1024) ctx->substream_min_pixels = v; }
-    if (const char *e = std::getenv("HRT_SUBSTREAMS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) ctx->substreams = v; }
+    if (const char *e = std::getenv("HRT_SUBSTREAMS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) ctx->substreams = v; }
     if (const char *e = std::getenv("HRT_POSTPONE_PCT")) { const int v = std::atoi(e); if (v >= 0 && v <= 100) ctx->postpone_pct = v; }
     if (const char *e = std::getenv("HRT_REFILL_THRESHOLD")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->refill_threshold = v; }
     *out_ctx = ctx.release();
@@ -638,7 +638,10 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
     // ---- sub-tiles: contiguous ranges of the tile's pixels, each on its own stream.  A traverse
     //      launch ends with a tail (the longest rays, ~0.3 ms) during which most CUs idle; with
     //      2-3 independent sub-tiles in flight one sub-tile's tail overlaps another's bulk. ----
-    uint32_t S = (uint32_t)ctx->substreams;
+    // 0 = automatic: a full frame keeps one stream (clean per-kernel timing, the GPU is full anyway);
+    // the smaller tiles of the multi-GPU split are latency-bound per stage and gain from 2-3 sub-tiles
+    // in flight (measured on the 1/8 tile: 41.4 -> 37.6 ms per 32 spp with 3).
+    uint32_t S = ctx->substreams > 0 ? (uint32_t)ctx->substreams : (n >= 1200000u ? 1u : (n >= 600000u ? 2u : 3u));
     while (S > 1 && n / S < (uint32_t)ctx->substream_min_pixels) --S;
     if (S > 1) {
         while (ctx->sub_streams.size() < S) {
