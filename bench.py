@@ -100,6 +100,8 @@ def main():
     tile = hrt.tile_for_rank(H, rank, world) if world > 1 else None
 
     def step():
+        if world > 1:
+            r.color.zero_()                                       # rows of the other ranks must be zero for the sum
         r.render(spp, tile=tile, sync=False)
         if world > 1:
             hrt.reduce_tiles(r.color, dst=0)                      # per-tile radiance -> rank 0 (x + 0 is exact)
@@ -111,15 +113,11 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        if world > 1:
-            r.color.zero_()
         step()
     fence()
     r.reset_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        if world > 1 and rank != 0:
-            pass
         step()
     fence()
     elapsed = time.perf_counter() - t0
@@ -157,7 +155,7 @@ def main():
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         traffic = None
         tf = ROOT / "profiles" / "traverse_traffic.json"
-        if tf.exists():
+        if tf.exists() and args.config == "C4" and world == 1:      # the PMC passes were taken on this workload
             try:
                 traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
             except Exception:
