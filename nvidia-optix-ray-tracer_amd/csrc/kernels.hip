@@ -118,6 +118,87 @@ __global__ __launch_bounds__(256) void k_rng_init(RngState *states, uint32_t n, 
 }
 
 // ---------------------------------------------------------------------------------------
+// shading arithmetic shared by the wavefront kernels (k_generate / k_shade / k_accumulate) and the
+// fused path mode of k_traverse: one definition, hence one rounding behaviour
+// ---------------------------------------------------------------------------------------
+// pinhole ray through the centre of pixel (ix, iy): shader/Shader.cu:249-261
+__device__ __forceinline__ V3 primary_direction(uint32_t ix, uint32_t iy, uint32_t width, uint32_t height,
+                                                const float *Uc, const float *Vc, const float *Wc) {
+    const float ndcx = (((float)ix + 0.5f) / (float)width) * 2.0f - 1.0f;          // :250
+    const float ndcy = (((float)iy + 0.5f) / (float)height) * 2.0f - 1.0f;         // :251
+    const V3 U = mk3(Uc[0], Uc[1], Uc[2]), V = mk3(Vc[0], Vc[1], Vc[2]), W = mk3(Wc[0], Wc[1], Wc[2]);
+    const float aspect = (float)width / (float)height;                            // :260
+    return normalize3(add3(add3(muls3(U, ndcx * aspect), muls3(V, ndcy)), W));    // :261
+}
+
+// randomSpaceVector, include/Global/DeviceFunctions.cuh:570-582 (length = 1)
+__device__ __forceinline__ V3 random_space_vector(Xorwow &rng) {
+    V3 ret; float lengthSquare;
+    do {
+        ret.x = -1.0f + 2.0f * xorwow_uniform(rng);      // randomDouble(state, -1, 1) :220-222
+        ret.y = -1.0f + 2.0f * xorwow_uniform(rng);
+        ret.z = -1.0f + 2.0f * xorwow_uniform(rng);
+        lengthSquare = len2_3(ret);
+    } while (lengthSquare < kFloatZero * kFloatZero);
+    ret = normalize3(ret);
+    return muls3(ret, 1.0f);
+}
+
+// closesthitImpl for one (geometry, material) program, shader/Shader.cu:111-213: hit point and the
+// direction of the next ray.  rng is touched only when the program draws (rough, or metal with fuzz > 0).
+template <bool kSphere, bool kRough>
+__device__ __forceinline__ void scatter(const HitGroup &hg, V3 rayOrigin, V3 rayDirection, float t, float u, float v,
+                                        uint32_t primitiveIndex, Xorwow &rng, V3 &hitPoint, V3 &reflectDirection) {
+    hitPoint = add3(rayOrigin, muls3(rayDirection, t));                   // :114
+    V3 normalVector;
+    if (kSphere) {                                                        // :122-136
+        const float *cp = reinterpret_cast<const float *>(hg.ptr0) + 3 * (size_t)primitiveIndex;
+        const V3 sphereCenter = mk3(cp[0], cp[1], cp[2]);
+        const float sphereRadius = reinterpret_cast<const float *>(hg.ptr1)[primitiveIndex];
+        const V3 outwardNormal = divs3(sub3(hitPoint, sphereCenter), sphereRadius);
+        const bool hitFrontFace = dot3(rayDirection, outwardNormal) < 0.0f;
+        normalVector = hitFrontFace ? outwardNormal : neg3(outwardNormal);
+    } else {                                                              // :137-155
+        const float *np = reinterpret_cast<const float *>(hg.ptr0) + 9 * (size_t)primitiveIndex;
+        const V3 n1 = mk3(np[0], np[1], np[2]), n2 = mk3(np[3], np[4], np[5]), n3 = mk3(np[6], np[7], np[8]);
+        const float w = 1.0f - u - v;
+        const V3 _normal = add3(add3(muls3(n1, w), muls3(n2, u)), muls3(n3, v));
+        const bool hitFrontFace = dot3(rayDirection, _normal) < 0.0f;
+        normalVector = hitFrontFace ? _normal : neg3(_normal);
+    }
+    if (kRough) {                                                         // :169-179
+        reflectDirection = add3(normalVector, random_space_vector(rng));
+        if (fabsf(len2_3(reflectDirection) - kFloatZero * kFloatZero) < kFloatZero) reflectDirection = normalVector;
+    } else {                                                              // :180-192
+        const V3 vv = rayDirection, nn = normalVector;
+        reflectDirection = normalize3(sub3(vv, muls3(nn, 2.0f * dot3(vv, nn))));
+        if (hg.fuzz > 0.0f) reflectDirection = add3(reflectDirection, muls3(random_space_vector(rng), hg.fuzz));
+    }
+    // :202-213
+    if (!finite3(reflectDirection) || len2_3(reflectDirection) <= kFloatZero * kFloatZero) {
+        reflectDirection = normalVector;
+        if (len2_3(reflectDirection) <= kFloatZero * kFloatZero || !finite3(reflectDirection))
+            reflectDirection = mk3(0.0f, 0.0f, 1.0f);
+    }
+    // the depth-1 AOV write (:216-227) is overwritten by the terminating program (quirk Q3): nothing to keep
+}
+__device__ __forceinline__ bool program_draws(int program, const HitGroup &hg) {
+    return program == kProgramSphereRough || program == kProgramTriangleRough || hg.fuzz > 0.0f;
+}
+
+// a path that ends at `depth`: miss colour (Shader.cu:276-287) or black at the depth limit (:102-107),
+// then the albedo products of the unwinding recursion (:236-238), innermost bounce first
+__device__ __forceinline__ V3 fold_chain(bool miss, const float *bg, const uint32_t *chain, uint32_t depth,
+                                         const HitGroup *__restrict__ hitgroups) {
+    V3 r = miss ? mk3(bg[0], bg[1], bg[2]) : mk3(0.0f, 0.0f, 0.0f);
+    for (int k = (int)depth - 2; k >= 0; --k) {
+        const HitGroup hg = hitgroups[chain[k]];
+        r.x *= hg.albedo[0]; r.y *= hg.albedo[1]; r.z *= hg.albedo[2];
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------
 // generate: __raygen__raygenProgram up to the trace call, shader/Shader.cu:246-267
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_generate(GenerateArgs a) {
@@ -127,11 +208,7 @@ __global__ __launch_bounds__(256) void k_generate(GenerateArgs a) {
     const uint32_t row = j / a.width;
     const uint32_t ix = j - row * a.width;
     const uint32_t iy = a.rows[row];
-    const float ndcx = (((float)ix + 0.5f) / (float)a.width) * 2.0f - 1.0f;        // :250
-    const float ndcy = (((float)iy + 0.5f) / (float)a.height) * 2.0f - 1.0f;       // :251
-    const V3 U = mk3(a.U[0], a.U[1], a.U[2]), V = mk3(a.V[0], a.V[1], a.V[2]), W = mk3(a.W[0], a.W[1], a.W[2]);
-    const float aspect = (float)a.width / (float)a.height;                        // :260
-    const V3 dir = normalize3(add3(add3(muls3(U, ndcx * aspect), muls3(V, ndcy)), W));   // :261
+    const V3 dir = primary_direction(ix, iy, a.width, a.height, a.U, a.V, a.W);
     RayRec r;
     r.o = make_float4(a.center[0], a.center[1], a.center[2], __uint_as_float(j));
     r.d = make_float4(dir.x, dir.y, dir.z, __uint_as_float(iy * a.width + ix));
@@ -728,19 +805,6 @@ __global__ __launch_bounds__(256) void k_bin_hits(BinArgs a) {
 // ---------------------------------------------------------------------------------------
 // shade: closesthitImpl for one (geometry, material) program, shader/Shader.cu:108-233
 // ---------------------------------------------------------------------------------------
-// randomSpaceVector, include/Global/DeviceFunctions.cuh:570-582 (length = 1)
-__device__ __forceinline__ V3 random_space_vector(Xorwow &rng) {
-    V3 ret; float lengthSquare;
-    do {
-        ret.x = -1.0f + 2.0f * xorwow_uniform(rng);      // randomDouble(state, -1, 1) :220-222
-        ret.y = -1.0f + 2.0f * xorwow_uniform(rng);
-        ret.z = -1.0f + 2.0f * xorwow_uniform(rng);
-        lengthSquare = len2_3(ret);
-    } while (lengthSquare < kFloatZero * kFloatZero);
-    ret = normalize3(ret);
-    return muls3(ret, 1.0f);
-}
-
 template <int PROGRAM>
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     constexpr bool kSphere = PROGRAM == kProgramSphereRough || PROGRAM == kProgramSphereMetal;
@@ -758,52 +822,15 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
         const uint32_t local = __float_as_uint(ray.o.w), tid = __float_as_uint(ray.d.w);
         const HitGroup hg = a.hitgroups[inst];               // SBT record of the instance, :108
 
-        const float t = hit.x;                                // optixGetRayTmax :111
         const V3 rayOrigin = mk3(ray.o.x, ray.o.y, ray.o.z), rayDirection = mk3(ray.d.x, ray.d.y, ray.d.z);
-        const V3 hitPoint = add3(rayOrigin, muls3(rayDirection, t));      // :114
-        const uint32_t primitiveIndex = __float_as_uint(hit.w);           // :117
-
-        V3 normalVector;
-        if (kSphere) {                                                    // :122-136
-            const float *cp = reinterpret_cast<const float *>(hg.ptr0) + 3 * (size_t)primitiveIndex;
-            const V3 sphereCenter = mk3(cp[0], cp[1], cp[2]);
-            const float sphereRadius = reinterpret_cast<const float *>(hg.ptr1)[primitiveIndex];
-            const V3 outwardNormal = divs3(sub3(hitPoint, sphereCenter), sphereRadius);
-            const bool hitFrontFace = dot3(rayDirection, outwardNormal) < 0.0f;
-            normalVector = hitFrontFace ? outwardNormal : neg3(outwardNormal);
-        } else {                                                          // :137-155
-            const float *np = reinterpret_cast<const float *>(hg.ptr0) + 9 * (size_t)primitiveIndex;
-            const V3 n1 = mk3(np[0], np[1], np[2]), n2 = mk3(np[3], np[4], np[5]), n3 = mk3(np[6], np[7], np[8]);
-            const float u = hit.y, v = hit.z;
-            const float w = 1.0f - u - v;
-            const V3 _normal = add3(add3(muls3(n1, w), muls3(n2, u)), muls3(n3, v));
-            const bool hitFrontFace = dot3(rayDirection, _normal) < 0.0f;
-            normalVector = hitFrontFace ? _normal : neg3(_normal);
-        }
-
-        V3 reflectDirection;
         RngState *state = a.states + tid;                                  // params.stateArray + tid
-        if (kRough) {                                                     // :169-179
-            Xorwow rng = rng_load(state);
-            reflectDirection = add3(normalVector, random_space_vector(rng));
-            rng_store(state, rng);
-            if (fabsf(len2_3(reflectDirection) - kFloatZero * kFloatZero) < kFloatZero) reflectDirection = normalVector;
-        } else {                                                          // :180-192
-            const V3 v = rayDirection, nn = normalVector;
-            reflectDirection = normalize3(sub3(v, muls3(nn, 2.0f * dot3(v, nn))));
-            if (hg.fuzz > 0.0f) {
-                Xorwow rng = rng_load(state);
-                reflectDirection = add3(reflectDirection, muls3(random_space_vector(rng), hg.fuzz));
-                rng_store(state, rng);
-            }
-        }
-        // :202-213
-        if (!finite3(reflectDirection) || len2_3(reflectDirection) <= kFloatZero * kFloatZero) {
-            reflectDirection = normalVector;
-            if (len2_3(reflectDirection) <= kFloatZero * kFloatZero || !finite3(reflectDirection))
-                reflectDirection = mk3(0.0f, 0.0f, 1.0f);
-        }
-        // the depth-1 AOV write (:216-227) is overwritten by the terminating program (quirk Q3): nothing to store
+        const bool draws = program_draws(PROGRAM, hg);
+        Xorwow rng{};
+        if (draws) rng = rng_load(state);
+        V3 hitPoint, reflectDirection;
+        scatter<kSphere, kRough>(hg, rayOrigin, rayDirection, hit.x /* optixGetRayTmax :111 */, hit.y, hit.z,
+                                 __float_as_uint(hit.w) /* optixGetPrimitiveIndex :117 */, rng, hitPoint, reflectDirection);
+        if (draws) rng_store(state, rng);
 
         a.chain[(size_t)local * 4 + (a.depth - 1u)] = inst;               // albedo applied on the way back, :236-238
         RayRec nr;                                                        // recursive rayTrace, :230-233
@@ -825,13 +852,10 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumArgs a) {
         const uint32_t i = a.bin_items[q];
         const uint32_t local = __float_as_uint(a.rays_in[i].o.w);
         const bool miss = a.hit_inst[i] == kMissPrim;
-        float rx = miss ? a.bg[0] : 0.0f, ry = miss ? a.bg[1] : 0.0f, rz = miss ? a.bg[2] : 0.0f;
         const uint4 ch = reinterpret_cast<const uint4 *>(a.chain)[local];
         const uint32_t chain[4] = {ch.x, ch.y, ch.z, ch.w};
-        for (int k = (int)a.depth - 2; k >= 0; --k) {
-            const HitGroup hg = a.hitgroups[chain[k]];
-            rx *= hg.albedo[0]; ry *= hg.albedo[1]; rz *= hg.albedo[2];
-        }
+        const V3 r = fold_chain(miss, a.bg, chain, a.depth, a.hitgroups);
+        const float rx = r.x, ry = r.y, rz = r.z;
         // every pixel ends exactly once per sample: a plain store.  k_sum adds the samples in sample order.
         a.result[local] = make_float4(rx, ry, rz, 0.0f);
     }
