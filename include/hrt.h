@@ -109,7 +109,7 @@ int  hrt_to_rgba8(HrtContext *ctx, const HrtFloat4 *d_src, HrtUchar4 *d_dst,
 
 /* ---- measurement (no reference counterpart: the reference has no timers) ------------- */
 enum { HRT_K_GENERATE = 0, HRT_K_TRAVERSE, HRT_K_TRAVERSE_ANY, HRT_K_BIN, HRT_K_SHADE,
-       HRT_K_ACCUMULATE, HRT_K_FINALIZE, HRT_K_COUNT };
+       HRT_K_ACCUMULATE, HRT_K_FINALIZE, HRT_K_PATHS /* fused path mode */, HRT_K_COUNT };
 
 typedef struct HrtStats {
     uint64_t rays;                         /* trace calls since the last reset (1..5 per pixel-sample) */

@@ -59,8 +59,8 @@ class Tile(C.Structure):
                 ("stripe_period", C.c_uint32), ("stripe_phase", C.c_uint32)]
 
 
-K_GENERATE, K_TRAVERSE, K_TRAVERSE_ANY, K_BIN, K_SHADE, K_ACCUMULATE, K_FINALIZE, K_COUNT = range(8)
-KERNEL_NAMES = ["generate", "traverse", "traverse_any", "bin", "shade", "accumulate", "finalize"]
+K_GENERATE, K_TRAVERSE, K_TRAVERSE_ANY, K_BIN, K_SHADE, K_ACCUMULATE, K_FINALIZE, K_PATHS, K_COUNT = range(9)
+KERNEL_NAMES = ["generate", "traverse", "traverse_any", "bin", "shade", "accumulate", "finalize", "paths"]
 
 
 class Stats(C.Structure):

@@ -55,6 +55,16 @@ struct TraverseSeg {
     uint64_t *count_nodes, *count_prims;   // COUNT builds
 };
 
+// fused path mode (k_traverse<..., FUSED>): what generate / shade / accumulate need, in one launch
+struct PathArgs {
+    const uint32_t *rows; uint32_t first_pixel, n_tile_pixels, width, height, spp;
+    float center[3], U[3], V[3], W[3], bg[3];
+    RngState *states;
+    const HitGroup *hitgroups; const uint32_t *inst_program;
+    float4 *accum;                 // per tile pixel: sum of the samples' linear radiance
+    uint64_t *rays_closest, *rays_any;
+};
+
 struct TraverseArgs {
     const void *nodes;             // Bvh8Node[]
     const void *prims;             // PrimRecord[]
@@ -68,6 +78,7 @@ struct TraverseArgs {
     uint32_t fetch_chunk;          // rays per slice a wave takes from the queue
     int tail_split;                // split long rays across idle lanes once the queue is drained
     int postpone_pct;              // the leaf pass is skipped while fewer than this % of the alive lanes have leaf work and none needs it
+    PathArgs path;                 // FUSED only
 };
 
 struct BinArgs {
@@ -111,6 +122,7 @@ struct FinalizeArgs {
 void launch_rng_init(RngState *states, uint32_t n, uint64_t salt, const uint32_t *d_jump, hipStream_t s);
 void launch_generate(const GenerateArgs &a, hipStream_t s);
 void launch_traverse(const TraverseArgs &a, bool count, bool has_spheres, bool dma, uint32_t grid_blocks, hipStream_t s);
+void launch_paths(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s);
 void launch_sum(float4 *accum, const float4 *result, uint32_t n, uint32_t first_sample, hipStream_t s);
 void launch_bin(const BinArgs &a, uint32_t grid_blocks, hipStream_t s);
 void launch_shade(const ShadeArgs &a, int program, uint32_t grid_blocks, hipStream_t s);

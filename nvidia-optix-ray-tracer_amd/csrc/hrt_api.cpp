@@ -107,6 +107,8 @@ struct HrtContext {
     int postpone_pct = 25;
     int tail_split = 1;
     int node_stride = 80, prim_stride = 64;     // bytes between records in HBM (80/48 packed; 128/64 = one cache line each)
+    int fused = 0;                              // 1: fused persistent path mode, 0: wavefront kernels, -1: by tile size
+    int fused_max_pixels = 700000;
     int lds_gather = 0;                         // 1: cooperative LDS-DMA gathers, 0: per-lane register loads
     int fetch_chunk = 64;
     int substream_min_pixels = 32768;
@@ -388,6 +390,8 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_FETCH_CHUNK")) { const int v = std::atoi(e); if (v >= 8 && v <= 4096) ctx->fetch_chunk = v; }
     if (const char *e = std::getenv("HRT_NODE_STRIDE")) { const int v = std::atoi(e); if (v >= 80 && v <= 256 && v % 16 == 0) ctx->node_stride = v; }
     if (const char *e = std::getenv("HRT_PRIM_STRIDE")) { const int v = std::atoi(e); if (v >= 48 && v <= 256 && v % 16 == 0) ctx->prim_stride = v; }
+    if (const char *e = std::getenv("HRT_FUSED")) ctx->fused = std::atoi(e);
+    if (const char *e = std::getenv("HRT_FUSED_MAX_PIXELS")) { const int v = std::atoi(e); if (v > 0) ctx->fused_max_pixels = v; }
     if (const char *e = std::getenv("HRT_LDS_GATHER")) ctx->lds_gather = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_TAIL_SPLIT")) ctx->tail_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_SUBSTREAM_MIN_PIXELS")) { const int v = std::atoi(e); if (v >= 1024) ctx->substream_min_pixels = v; }
@@ -634,6 +638,39 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
     }
 
     const bool count = (ctx->flags & HRT_CTX_COUNT) != 0;
+
+    // ---- fused path mode: ONE launch, every lane owns a pixel and runs all its samples (generate,
+    //      traverse, shade, accumulate in place).  No stage barriers: the choice for small tiles. ----
+    const bool use_fused = !count && (ctx->fused > 0 || (ctx->fused < 0 && n <= (uint32_t)ctx->fused_max_pixels));
+    if (use_fused) {
+        StageCounters *stg = w.set[0].stages;
+        HIP_TRY(ctx, hipMemsetAsync(stg, 0, sizeof(StageCounters), s));
+        TraverseArgs ta{};
+        ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.node_stride = t->node_stride; ta.prim_stride = t->prim_stride;
+        ta.fetch_counter = stg[0].fetch;
+        ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
+        ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;
+        ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.tail_split = 0; ta.fetch_chunk = (uint32_t)ctx->fetch_chunk;
+        PathArgs &pa = ta.path;
+        pa.rows = w.rows; pa.first_pixel = 0; pa.n_tile_pixels = n; pa.width = rg->width; pa.height = rg->height; pa.spp = spp;
+        std::memcpy(pa.center, &rg->cameraCenter, 12); std::memcpy(pa.U, &rg->cameraU, 12);
+        std::memcpy(pa.V, &rg->cameraV, 12); std::memcpy(pa.W, &rg->cameraW, 12);
+        pa.bg[0] = ctx->miss.backgroundColor.x; pa.bg[1] = ctx->miss.backgroundColor.y; pa.bg[2] = ctx->miss.backgroundColor.z;
+        pa.states = reinterpret_cast<RngState *>(h_params->stateArray);
+        pa.hitgroups = ctx->d_hitgroups; pa.inst_program = ctx->d_inst_program; pa.accum = w.accum;
+        pa.rays_closest = &ctx->d_stats->rays_closest; pa.rays_any = &ctx->d_stats->rays_any;
+        const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (n + 63u) / 64u);
+        { Timer tm(ctx, s, HRT_K_PATHS); launch_paths(ta, t->has_spheres, grid, s); }
+        FinalizeArgs fa{};
+        fa.accum = w.accum; fa.rows = w.rows; fa.n_tile_pixels = n; fa.width = rg->width; fa.spp = spp;
+        fa.color = reinterpret_cast<float4 *>(rg->colorBuffer); fa.albedo = reinterpret_cast<float4 *>(rg->albedoBuffer);
+        fa.normal = reinterpret_cast<float4 *>(rg->normalBuffer); fa.linear = ctx->d_linear;
+        { Timer tm(ctx, s, HRT_K_FINALIZE); launch_finalize(fa, s); }
+        HIP_TRY(ctx, hipGetLastError());
+        ctx->paths += (uint64_t)n * spp;
+        ctx->last_tlas = h_params->handle;
+        return HRT_OK;
+    }
 
     // ---- sub-tiles: contiguous ranges of the tile's pixels, each on its own stream.  A traverse
     //      launch ends with a tail (the longest rays, ~0.3 ms) during which most CUs idle; with

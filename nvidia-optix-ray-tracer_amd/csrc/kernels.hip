@@ -366,7 +366,7 @@ __device__ __forceinline__ void wait_node_loads(u32x4 &a, u32x4 &b, u32x4 &c, u3
 __device__ __forceinline__ void wait_prim_gather() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
 __device__ __forceinline__ void wait_node_gather() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <bool COUNT, bool HAS_SPHERES, bool DMA>
+template <bool COUNT, bool HAS_SPHERES, bool DMA, bool FUSED>
 __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     static_assert(kTraverseBlock == 64, "one wave per workgroup: staging images and mailboxes are per wave");
     __shared__ uint2 s_stack[kLdsStack][kTraverseBlock];
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     // sample s+1): ray i < n_a comes from segment 0, the others from segment 1
     const uint32_t n_a = a.seg[0].n_ptr ? (a.seg[0].n_ptr[0] + a.seg[0].n_ptr[1] + a.seg[0].n_ptr[2] + a.seg[0].n_ptr[3]) : a.seg[0].n;
     const uint32_t n_b = a.seg[1].rays ? (a.seg[1].n_ptr ? (a.seg[1].n_ptr[0] + a.seg[1].n_ptr[1] + a.seg[1].n_ptr[2] + a.seg[1].n_ptr[3]) : a.seg[1].n) : 0u;
-    const uint32_t n_rays = n_a + n_b;
+    const uint32_t n_rays = FUSED ? a.path.n_tile_pixels : n_a + n_b;     // fused: the queue is the tile's pixel list
     const char *__restrict__ node_bytes = reinterpret_cast<const char *>(a.nodes);
     const char *__restrict__ prim_bytes = reinterpret_cast<const char *>(a.prims);
     const float tmin = a.tmin, tmax_ray = a.tmax;
@@ -405,6 +405,16 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     uint32_t cnt_nodes = 0, cnt_prims = 0, cnt_nodes_b = 0, cnt_prims_b = 0;
     bool any = false;                       // this lane's ray only needs to know whether anything is hit
     bool in_b = false;                      // ... and belongs to segment 1
+
+    // FUSED (path mode): the lane owns a pixel and carries its path state; a finished ray is shaded in
+    // place and the next ray (bounce, next sample, next pixel) starts in the same lane -- no queues, no
+    // per-stage launches, no stage barriers.  Used for small tiles where per-stage latency dominates.
+    bool have_pixel = false, waiting = false;
+    uint32_t px_local = 0u, px_tid = 0u, px_sample = 0u, px_depth = 1u;
+    uint32_t px_chain[4] = {0u, 0u, 0u, 0u};
+    float px_ax = 0.0f, px_ay = 0.0f, px_az = 0.0f;
+    Xorwow px_rng{};
+    uint32_t px_rays_closest = 0u, px_rays_any = 0u;
 
     // what the next iteration gathers for this lane
     bool has_node = false, has_prim = false;
@@ -446,9 +456,97 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     uint32_t kstart = 0;
 
     for (;;) {
-        // ---- refill idle lanes from the wave's slice ----
         const uint64_t idle = __ballot(!alive);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (FUSED) {
+            // ---- regenerate: shade finished rays in place, start the next sample / pixel ----
+            if (n_idle >= (uint32_t)a.refill_threshold || idle == ~0ull) {
+                auto start_ray = [&](V3 o, V3 d) {
+                    s.ox = o.x; s.oy = o.y; s.oz = o.z; s.dx = d.x; s.dy = d.y; s.dz = d.z;
+                    s.idx = safe_rcp_dir(s.dx); s.idy = safe_rcp_dir(s.dy); s.idz = safe_rcp_dir(s.dz);
+                    const uint32_t oct = (s.dx < 0.0f ? 4u : 0u) | (s.dy < 0.0f ? 2u : 0u) | (s.dz < 0.0f ? 1u : 0u);
+                    s.oct_inv4 = (7u - oct) * 0x01010101u;
+                    s.bt = tmax_ray; s.bu = 0.0f; s.bv = 0.0f; s.bprim = kMissPrim; s.binst = kMissPrim;
+                    s.cur = make_uint2(0u, 0x80000000u);
+                    s.ptri = make_uint2(0u, 0u);
+                    s.sp = 0; s.base = 0;
+                    any = px_depth >= kRayTraceDepth;      // a hit at the depth limit is black whatever it is
+                    if (any) ++px_rays_any; else ++px_rays_closest;
+                    alive = true; has_prim = false; pidx = 0u;
+                    advance_select();
+                };
+                bool want_primary = false;
+                if (!alive && waiting) {
+                    waiting = false;
+                    const bool miss = s.bprim == kMissPrim;
+                    if (miss || px_depth >= kRayTraceDepth) {
+                        const V3 r = fold_chain(miss, a.path.bg, px_chain, px_depth, a.path.hitgroups);
+                        if (px_sample == 0u) { px_ax = r.x; px_ay = r.y; px_az = r.z; }
+                        else { px_ax += r.x; px_ay += r.y; px_az += r.z; }
+                        ++px_sample;
+                        if (px_sample >= a.path.spp) {
+                            a.path.accum[px_local] = make_float4(px_ax, px_ay, px_az, 0.0f);
+                            rng_store(a.path.states + px_tid, px_rng);
+                            have_pixel = false;
+                        } else want_primary = true;
+                    } else {
+                        const uint32_t inst = s.binst;
+                        const HitGroup hg = a.path.hitgroups[inst];
+                        const uint32_t program = a.path.inst_program[inst];
+                        const V3 ro = mk3(s.ox, s.oy, s.oz), rd = mk3(s.dx, s.dy, s.dz);
+                        V3 hp, nd;
+                        if (program == (uint32_t)kProgramTriangleRough) scatter<false, true>(hg, ro, rd, s.bt, s.bu, s.bv, s.bprim, px_rng, hp, nd);
+                        else if (program == (uint32_t)kProgramTriangleMetal) scatter<false, false>(hg, ro, rd, s.bt, s.bu, s.bv, s.bprim, px_rng, hp, nd);
+                        else if (program == (uint32_t)kProgramSphereRough) scatter<true, true>(hg, ro, rd, s.bt, s.bu, s.bv, s.bprim, px_rng, hp, nd);
+                        else scatter<true, false>(hg, ro, rd, s.bt, s.bu, s.bv, s.bprim, px_rng, hp, nd);
+                        px_chain[px_depth - 1u] = inst;
+                        ++px_depth;
+                        start_ray(hp, nd);
+                    }
+                }
+                // lanes without a pixel take the next ones of the wave's slice of the tile
+                const uint64_t need = __ballot(!alive && !have_pixel && !want_primary);
+                if (need != 0ull && !exhausted) {
+                    if (wbeg >= wend) {
+                        for (uint32_t k = kstart; k < kFetchShards && wbeg >= wend; ++k) {
+                            const uint32_t shard = (home_shard + k) & (kFetchShards - 1);
+                            uint32_t c = 0;
+                            if (tx == 0u) c = atomicAdd(a.fetch_counter + shard * kFetchShardStride, 1u);
+                            c = (uint32_t)__shfl((int)c, 0);
+                            const uint64_t beg = ((uint64_t)c * kFetchShards + shard) * (uint64_t)a.fetch_chunk;
+                            if (beg < (uint64_t)n_rays) {
+                                wbeg = (uint32_t)beg;
+                                wend = (uint32_t)(beg + a.fetch_chunk < (uint64_t)n_rays ? beg + a.fetch_chunk : (uint64_t)n_rays);
+                            } else kstart = k + 1;
+                        }
+                        if (wbeg >= wend) exhausted = true;
+                    }
+                    if (!exhausted) {
+                        const uint32_t n_need = (uint32_t)__popcll(need);
+                        const uint32_t take = n_need < wend - wbeg ? n_need : wend - wbeg;
+                        const uint32_t rank = lane_prefix(need);
+                        const uint32_t mine = wbeg + rank;
+                        wbeg += take;
+                        if (!alive && !have_pixel && !want_primary && rank < take) {
+                            const uint32_t j = a.path.first_pixel + mine;
+                            const uint32_t row = j / a.path.width;
+                            const uint32_t ix = j - row * a.path.width;
+                            const uint32_t iy = a.path.rows[row];
+                            px_local = j; px_tid = iy * a.path.width + ix;
+                            px_sample = 0u; px_rng = rng_load(a.path.states + px_tid);
+                            have_pixel = true; want_primary = true;
+                        }
+                    }
+                }
+                if (!alive && want_primary) {
+                    const uint32_t iy = px_tid / a.path.width, ix = px_tid - iy * a.path.width;
+                    px_depth = 1u;
+                    start_ray(mk3(a.path.center[0], a.path.center[1], a.path.center[2]),
+                              primary_direction(ix, iy, a.path.width, a.path.height, a.path.U, a.path.V, a.path.W));
+                }
+            }
+        } else
+        // ---- refill idle lanes from the wave's slice ----
         if (!exhausted && (n_idle >= (uint32_t)a.refill_threshold || idle == ~0ull)) {
             if (wbeg >= wend) {
                 for (uint32_t k = kstart; k < kFetchShards && wbeg >= wend; ++k) {
@@ -488,7 +586,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                 }
             }
         }
-        if (__ballot(alive) == 0ull) break;     // queue drained and every lane finished
+        if (__ballot(alive) == 0ull) break;     // queue drained and every lane finished (fused: nothing waits after a full regeneration)
 
         // ---- traverse until enough lanes have finished to make a refill worthwhile ----
         for (;;) {
@@ -496,7 +594,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
             //      gives the BOTTOM entry of its stack (the largest pending subtree) to an idle lane
             //      of the same wave, which continues with a copy of the ray and of the best hit so
             //      far; results are merged through an LDS mailbox when the pieces finish. ----
-            if (!COUNT && a.tail_split && exhausted) {
+            if (!COUNT && !FUSED && a.tail_split && exhausted) {
                 const uint64_t idle2 = __ballot(!alive);
                 const uint64_t donors = __ballot(alive && s.sp > s.base);
                 const uint32_t n_idle2 = (uint32_t)__popcll(idle2), n_don = (uint32_t)__popcll(donors);
@@ -677,7 +775,9 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
             // ---- finished? ----
             if (alive) {
                 if (!done && !has_node && !has_prim && s.ptri.y == 0u) done = true;
-                if (done && !shared) {
+                if (FUSED && done) {
+                    alive = false; waiting = true; has_node = false; has_prim = false; nidx = 0u; pidx = 0u;   // shaded at the next regeneration
+                } else if (done && !shared) {
                     (in_b ? a.seg[1].hit_tuvp : a.seg[0].hit_tuvp)[s.slot] = make_float4(s.bt, s.bu, s.bv, __uint_as_float(s.bprim));
                     (in_b ? a.seg[1].hit_inst : a.seg[0].hit_inst)[s.slot] = s.binst;
                     alive = false; has_node = false; has_prim = false; nidx = 0u; pidx = 0u;
@@ -708,7 +808,17 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
             }
             const uint64_t act = __ballot(alive);
             if (act == 0ull) break;
-            if (!exhausted && (64u - (uint32_t)__popcll(act)) >= (uint32_t)a.refill_threshold) break;
+            if ((FUSED || !exhausted) && (64u - (uint32_t)__popcll(act)) >= (uint32_t)a.refill_threshold) break;
+        }
+    }
+    if (FUSED) {
+        for (int off = 32; off > 0; off >>= 1) {
+            px_rays_closest += (uint32_t)__shfl_down((int)px_rays_closest, off);
+            px_rays_any += (uint32_t)__shfl_down((int)px_rays_any, off);
+        }
+        if (tx == 0u) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(a.path.rays_closest), (unsigned long long)px_rays_closest);
+            atomicAdd(reinterpret_cast<unsigned long long *>(a.path.rays_any), (unsigned long long)px_rays_any);
         }
     }
     if (COUNT) {
@@ -979,15 +1089,21 @@ void launch_traverse(const TraverseArgs &a, bool count, bool has_spheres, bool d
     const dim3 g(grid_blocks), b(kTraverseBlock);
     const int sel = (dma ? 4 : 0) | (count ? 2 : 0) | (has_spheres ? 1 : 0);
     switch (sel) {
-        case 0: hipLaunchKernelGGL((k_traverse<false, false, false>), g, b, 0, s, a); break;
-        case 1: hipLaunchKernelGGL((k_traverse<false, true, false>), g, b, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((k_traverse<true, false, false>), g, b, 0, s, a); break;
-        case 3: hipLaunchKernelGGL((k_traverse<true, true, false>), g, b, 0, s, a); break;
-        case 4: hipLaunchKernelGGL((k_traverse<false, false, true>), g, b, 0, s, a); break;
-        case 5: hipLaunchKernelGGL((k_traverse<false, true, true>), g, b, 0, s, a); break;
-        case 6: hipLaunchKernelGGL((k_traverse<true, false, true>), g, b, 0, s, a); break;
-        default: hipLaunchKernelGGL((k_traverse<true, true, true>), g, b, 0, s, a); break;
+        case 0: hipLaunchKernelGGL((k_traverse<false, false, false, false>), g, b, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((k_traverse<false, true, false, false>), g, b, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_traverse<true, false, false, false>), g, b, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((k_traverse<true, true, false, false>), g, b, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((k_traverse<false, false, true, false>), g, b, 0, s, a); break;
+        case 5: hipLaunchKernelGGL((k_traverse<false, true, true, false>), g, b, 0, s, a); break;
+        case 6: hipLaunchKernelGGL((k_traverse<true, false, true, false>), g, b, 0, s, a); break;
+        default: hipLaunchKernelGGL((k_traverse<true, true, true, false>), g, b, 0, s, a); break;
     }
+}
+// fused path mode: one launch renders every sample of every pixel of the tile
+void launch_paths(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s) {
+    const dim3 g(grid_blocks), b(kTraverseBlock);
+    if (has_spheres) hipLaunchKernelGGL((k_traverse<false, true, false, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_traverse<false, false, false, true>), g, b, 0, s, a);
 }
 void launch_bin(const BinArgs &a, uint32_t grid_blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_bin_hits, dim3(grid_blocks), dim3(256), 0, s, a);
