@@ -146,12 +146,24 @@ def main():
     bytes_per_any_ray = RAY_BYTES + NODE_BYTES * any_nodes + PRIM_BYTES * any_prims + HIT_BYTES
 
     if rank == 0:
-        # every traverse launch of the timed region (closest-hit rays, and the depth-5 any-hit rays that ride along)
-        trav_ms = st.kernel_ms[hrt.K_TRAVERSE] + st.kernel_ms[hrt.K_TRAVERSE_ANY]
-        trav_launches = max(int(st.kernel_launches[hrt.K_TRAVERSE] + st.kernel_launches[hrt.K_TRAVERSE_ANY]), 1)
+        fused = st.kernel_launches[hrt.K_PATHS] > 0
+        if fused:
+            # fused path mode: ONE launch per step renders every sample of every pixel; rays live in registers, so
+            # the algorithmic traffic is the BVH bytes a ray has to read (no ray / hit records)
+            trav_ms = st.kernel_ms[hrt.K_PATHS]
+            trav_launches = max(int(st.kernel_launches[hrt.K_PATHS]), 1)
+            b_closest = NODE_BYTES * nodes_per_ray + PRIM_BYTES * prims_per_ray
+            b_any = NODE_BYTES * any_nodes + PRIM_BYTES * any_prims
+            kernel_name = "k_traverse<FUSED> (persistent path mode: generate + traverse + shade + accumulate)"
+        else:
+            # wavefront mode: every traverse launch of the timed region (closest-hit rays and the depth-5 any-hit rays)
+            trav_ms = st.kernel_ms[hrt.K_TRAVERSE] + st.kernel_ms[hrt.K_TRAVERSE_ANY]
+            trav_launches = max(int(st.kernel_launches[hrt.K_TRAVERSE] + st.kernel_launches[hrt.K_TRAVERSE_ANY]), 1)
+            b_closest, b_any = bytes_per_ray, bytes_per_any_ray
+            kernel_name = "k_traverse"
         avg_launch_ms = trav_ms / trav_launches
         rays_per_launch = st.rays / trav_launches
-        bytes_per_launch = (bytes_per_ray * st.rays_closest + bytes_per_any_ray * st.rays_any) / trav_launches
+        bytes_per_launch = (b_closest * st.rays_closest + b_any * st.rays_any) / trav_launches
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
         traffic = None
         tf = ROOT / "profiles" / "traverse_traffic.json"
@@ -175,10 +187,10 @@ def main():
                                    f"{W}x{H}, {spp} spp, depth {5}, tile-split x{world} (8-row stripes, BVH replicated)",
                        "rays_per_step": int(total_rays / max(args.steps, 1)), "rays_per_path": round(st.rays / max(st.paths, 1), 4),
                        "bvh_nodes": int(st.bvh_nodes), "bvh_bytes": int(st.bvh_bytes), "bvh_build_s": round(build_s, 2)},
-            "roofline": {"bound": "hbm", "kernel": "k_traverse", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 3),
-                         "prims_per_ray": round(prims_per_ray, 3), "bytes_per_any_hit_ray": round(bytes_per_any_ray, 1),
+                         "bytes_per_ray": round(b_closest, 1), "nodes_per_ray": round(nodes_per_ray, 3),
+                         "prims_per_ray": round(prims_per_ray, 3), "bytes_per_any_hit_ray": round(b_any, 1),
                          "bytes_per_launch": round(bytes_per_launch, 0), "avg_launch_ms": round(avg_launch_ms, 4),
                          "rays_per_launch": round(rays_per_launch, 1), "launches": trav_launches},
             "kernel_ms": {hrt.KERNEL_NAMES[k]: round(st.kernel_ms[k], 3) for k in range(hrt.K_COUNT)},

@@ -107,7 +107,7 @@ struct HrtContext {
     int postpone_pct = 25;
     int tail_split = 1;
     int node_stride = 80, prim_stride = 64;     // bytes between records in HBM (80/48 packed; 128/64 = one cache line each)
-    int fused = 0;                              // 1: fused persistent path mode, 0: wavefront kernels, -1: by tile size
+    int fused = 1;                              // 1: fused persistent path mode (default), 0: wavefront kernels, -1: fused only for small tiles
     int fused_max_pixels = 700000;
     int lds_gather = 0;                         // 1: cooperative LDS-DMA gathers, 0: per-lane register loads
     int fetch_chunk = 64;

@@ -269,10 +269,12 @@ def test_errors_are_loud(hrt, renderer):
 
 MODES = {
     "default": {},
-    "fused-paths": {"HRT_FUSED": "1"},
-    "lds-dma-gather": {"HRT_LDS_GATHER": "1"},
-    "substreams": {"HRT_SUBSTREAMS": "3", "HRT_SUBSTREAM_MIN_PIXELS": "1024"},
-    "no-tail-split-small-slices": {"HRT_TAIL_SPLIT": "0", "HRT_FETCH_CHUNK": "16", "HRT_REFILL_THRESHOLD": "4"},
+    "wavefront": {"HRT_FUSED": "0"},
+    "wavefront-by-tile-size": {"HRT_FUSED": "-1", "HRT_FUSED_MAX_PIXELS": "16000"},
+    "wavefront-lds-dma-gather": {"HRT_FUSED": "0", "HRT_LDS_GATHER": "1"},
+    "wavefront-substreams": {"HRT_FUSED": "0", "HRT_SUBSTREAMS": "3", "HRT_SUBSTREAM_MIN_PIXELS": "1024"},
+    "wavefront-no-tail-split-small-slices": {"HRT_FUSED": "0", "HRT_TAIL_SPLIT": "0", "HRT_FETCH_CHUNK": "16", "HRT_REFILL_THRESHOLD": "4"},
+    "fused-small-slices": {"HRT_FETCH_CHUNK": "16", "HRT_REFILL_THRESHOLD": "4", "HRT_TRAVERSE_BLOCKS_PER_CU": "3"},
     "aligned-records": {"HRT_NODE_STRIDE": "128", "HRT_PRIM_STRIDE": "64"},
 }
 
@@ -315,8 +317,7 @@ def test_fused_mode_tiles(hrt, oracle, gpu_available, monkeypatch):
     """Fused path mode on stripe tiles: union == full frame, rows outside the tile untouched."""
     if not gpu_available:
         pytest.skip("no GPU")
-    monkeypatch.setenv("HRT_FUSED", "1")
-    r = hrt.Renderer(0, 0)
+    r = hrt.Renderer(0, 0)                      # fused path mode is the default of the production build
     try:
         scene = hrt.scenes.mixed_test_scene(1500, 30, 3, 80, 50, 2)
         r.load_scene(scene)
