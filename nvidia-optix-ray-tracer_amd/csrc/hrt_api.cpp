@@ -102,7 +102,8 @@ struct HrtContext {
     std::vector<TimedSpan> spans; std::vector<hipEvent_t> event_pool; size_t events_used = 0;
     double kernel_ms[HRT_K_COUNT] = {0}; uint64_t kernel_launches[HRT_K_COUNT] = {0};
     float4 *d_linear = nullptr;
-    int refill_threshold = 16;
+    int refill_threshold = 16;                  // wavefront mode; fused mode: fused_refill_threshold
+    int fused_refill_threshold = 24, fused_fetch_chunk = 16;   // measured optimum of the fused path mode (profiles/r01_sweep_fused_*.txt)
     int traverse_blocks_per_cu = 16;            // one-wave workgroups of the traverse kernel per CU
     int postpone_pct = 25;
     int tail_split = 1;
@@ -387,7 +388,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
         hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)) != hipSuccess)
         return fail(nullptr, HRT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(hipGetLastError()));
     if (const char *e = std::getenv("HRT_TRAVERSE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) ctx->traverse_blocks_per_cu = v; }
-    if (const char *e = std::getenv("HRT_FETCH_CHUNK")) { const int v = std::atoi(e); if (v >= 8 && v <= 4096) ctx->fetch_chunk = v; }
+    if (const char *e = std::getenv("HRT_FETCH_CHUNK")) { const int v = std::atoi(e); if (v >= 8 && v <= 4096) { ctx->fetch_chunk = v; ctx->fused_fetch_chunk = v; } }
     if (const char *e = std::getenv("HRT_NODE_STRIDE")) { const int v = std::atoi(e); if (v >= 80 && v <= 256 && v % 16 == 0) ctx->node_stride = v; }
     if (const char *e = std::getenv("HRT_PRIM_STRIDE")) { const int v = std::atoi(e); if (v >= 48 && v <= 256 && v % 16 == 0) ctx->prim_stride = v; }
     if (const char *e = std::getenv("HRT_FUSED")) ctx->fused = std::atoi(e);
@@ -397,7 +398,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_SUBSTREAM_MIN_PIXELS")) { const int v = std::atoi(e); if (v >= 1024) ctx->substream_min_pixels = v; }
     if (const char *e = std::getenv("HRT_SUBSTREAMS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) ctx->substreams = v; }
     if (const char *e = std::getenv("HRT_POSTPONE_PCT")) { const int v = std::atoi(e); if (v >= 0 && v <= 100) ctx->postpone_pct = v; }
-    if (const char *e = std::getenv("HRT_REFILL_THRESHOLD")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->refill_threshold = v; }
+    if (const char *e = std::getenv("HRT_REFILL_THRESHOLD")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) { ctx->refill_threshold = v; ctx->fused_refill_threshold = v; } }
     *out_ctx = ctx.release();
     return HRT_OK;
 }
@@ -650,7 +651,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         ta.fetch_counter = stg[0].fetch;
         ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
         ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;
-        ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.tail_split = 0; ta.fetch_chunk = (uint32_t)ctx->fetch_chunk;
+        ta.refill_threshold = ctx->fused_refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.tail_split = 0; ta.fetch_chunk = (uint32_t)ctx->fused_fetch_chunk;
         PathArgs &pa = ta.path;
         pa.rows = w.rows; pa.first_pixel = 0; pa.n_tile_pixels = n; pa.width = rg->width; pa.height = rg->height; pa.spp = spp;
         std::memcpy(pa.center, &rg->cameraCenter, 12); std::memcpy(pa.U, &rg->cameraU, 12);
