@@ -37,7 +37,8 @@ int main(int argc, char **argv) {
         normals[3 * i] = normals[3 * i + 1] = normals[3 * i + 2] = n;
     }
 
-    HrtContext *ctx = createContext(0, true);
+    HrtContext *ctx = createContext(0, false);
+    hrtCheckError(ctx, hrt_ctx_set_flags(ctx, HRT_CTX_TIMING));      // production kernels, HIP-event timing
     RendererTriangle tri{0, 0, nullptr, nullptr, n_tri};
     hipCheck(hipMalloc((void **)&tri.dev_vertices, verts.size() * sizeof(HrtFloat3)));
     hipCheck(hipMalloc((void **)&tri.dev_normals, normals.size() * sizeof(HrtFloat3)));
@@ -84,10 +85,11 @@ int main(int argc, char **argv) {
     HrtStats st{};
     hrtCheckError(ctx, hrt_stats_get(ctx, &st));
     const double ms = std::chrono::duration<double, std::milli>(t3 - t2).count();
-    std::printf("build %.1f ms | %u tris %ux%u %u spp: %.2f ms, %.1f Mrays/s, %.2f rays/path, %.1f nodes/ray, %.1f prims/ray\n",
+    std::printf("build %.1f ms | %u tris %ux%u %u spp: %.2f ms, %.1f Mrays/s, %.2f rays/path\n",
                 std::chrono::duration<double, std::milli>(t1 - t0).count(), n_tri, W, H, spp, ms, st.rays / ms * 1e-3,
-                (double)st.rays / st.paths, (double)st.node_visits / st.rays, (double)st.prim_tests / st.rays);
-    for (int k = 0; k < HRT_K_COUNT; ++k) std::printf("  kernel %d: %.3f ms in %llu launches\n", k, st.kernel_ms[k], (unsigned long long)st.kernel_launches[k]);
+                (double)st.rays / st.paths);
+    for (int k = 0; k < HRT_K_COUNT; ++k)
+        if (st.kernel_launches[k]) std::printf("  kernel class %d: %.3f ms in %llu launches\n", k, st.kernel_ms[k], (unsigned long long)st.kernel_launches[k]);
 
     hrtCheckError(ctx, hrt_to_rgba8(ctx, color, rgba, W, H, nullptr));
     std::vector<HrtUchar4> host((size_t)W * H);
