@@ -21,15 +21,19 @@ $(LIBDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/device_types.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/hrt_api.o: $(CSRC)/hrt_api.cpp $(CSRC)/device_types.h $(CSRC)/bvh8.h include/hrt.h include/hrt_params.h
+$(LIBDIR)/refit.o: $(CSRC)/refit.hip $(CSRC)/device_types.h $(CSRC)/bvh8_geom.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/bvh8_build.o: $(CSRC)/bvh8_build.cpp $(CSRC)/bvh8.h
+$(LIBDIR)/hrt_api.o: $(CSRC)/hrt_api.cpp $(CSRC)/device_types.h $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.h include/hrt.h include/hrt_params.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/bvh8_build.o: $(CSRC)/bvh8_build.cpp $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.h
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
-$(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/hrt_api.o $(LIBDIR)/bvh8_build.o
+$(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/refit.o $(LIBDIR)/hrt_api.o $(LIBDIR)/bvh8_build.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -pthread
 
 oracle:

@@ -109,7 +109,7 @@ int  hrt_to_rgba8(HrtContext *ctx, const HrtFloat4 *d_src, HrtUchar4 *d_dst,
 
 /* ---- measurement (no reference counterpart: the reference has no timers) ------------- */
 enum { HRT_K_GENERATE = 0, HRT_K_TRAVERSE, HRT_K_TRAVERSE_ANY, HRT_K_BIN, HRT_K_SHADE,
-       HRT_K_ACCUMULATE, HRT_K_FINALIZE, HRT_K_PATHS /* fused path mode */, HRT_K_COUNT };
+       HRT_K_ACCUMULATE, HRT_K_FINALIZE, HRT_K_PATHS /* fused path mode */, HRT_K_REFIT /* hrt_tlas_update */, HRT_K_COUNT };
 
 typedef struct HrtStats {
     uint64_t rays;                         /* trace calls since the last reset (1..5 per pixel-sample) */
@@ -123,6 +123,7 @@ typedef struct HrtStats {
     uint64_t bvh_bytes;
     uint64_t debug[4];                     /* HRT_CTX_COUNT, closest-hit kernel: wave iterations, wave leaf passes,
                                               sum of alive lanes over iterations, reserved                     */
+    uint64_t tlas_refits, tlas_rebuilds;   /* hrt_tlas_update calls served by the device refit / builds + rebuilds    */
 } HrtStats;
 
 int  hrt_stats_reset(HrtContext *ctx);
@@ -151,7 +152,8 @@ typedef struct HrtBvhBlob {
     float    bounds[6];
 } HrtBvhBlob;
 int  hrt_host_build_bvh8(const float *h_triangles, uint32_t n_triangles, HrtBvhBlob *out);
-/* Copy the flattened world-space BVH of a TLAS back to the host (same blob format). */
+/* Copy the flattened world-space BVH of a TLAS, as it is in device memory now (after any refit), back to
+ * the host (same blob format). */
 int  hrt_tlas_download(HrtContext *ctx, HrtTraversable tlas, HrtBvhBlob *out);
 void hrt_host_free(HrtBvhBlob *blob);
 

@@ -59,8 +59,8 @@ class Tile(C.Structure):
                 ("stripe_period", C.c_uint32), ("stripe_phase", C.c_uint32)]
 
 
-K_GENERATE, K_TRAVERSE, K_TRAVERSE_ANY, K_BIN, K_SHADE, K_ACCUMULATE, K_FINALIZE, K_PATHS, K_COUNT = range(9)
-KERNEL_NAMES = ["generate", "traverse", "traverse_any", "bin", "shade", "accumulate", "finalize", "paths"]
+K_GENERATE, K_TRAVERSE, K_TRAVERSE_ANY, K_BIN, K_SHADE, K_ACCUMULATE, K_FINALIZE, K_PATHS, K_REFIT, K_COUNT = range(10)
+KERNEL_NAMES = ["generate", "traverse", "traverse_any", "bin", "shade", "accumulate", "finalize", "paths", "refit"]
 
 
 class Stats(C.Structure):
@@ -69,7 +69,8 @@ class Stats(C.Structure):
                 ("node_visits_closest", C.c_uint64), ("prim_tests_closest", C.c_uint64),
                 ("kernel_ms", C.c_double * K_COUNT), ("kernel_launches", C.c_uint64 * K_COUNT),
                 ("bvh_nodes", C.c_uint64), ("bvh_triangles", C.c_uint64), ("bvh_spheres", C.c_uint64),
-                ("bvh_bytes", C.c_uint64), ("debug", C.c_uint64 * 4)]
+                ("bvh_bytes", C.c_uint64), ("debug", C.c_uint64 * 4),
+                ("tlas_refits", C.c_uint64), ("tlas_rebuilds", C.c_uint64)]
 
 
 class BvhBlob(C.Structure):

@@ -57,11 +57,17 @@ struct Bvh8 {
     uint32_t n_triangles = 0, n_spheres = 0;
     uint32_t max_depth = 0;
     std::vector<float>      prim_bounds;   // 6 floats per primitive, leaf order (host-side checks only)
+    // refit support: nodes are emitted breadth first, so level l is nodes [level_begin[l], level_begin[l+1])
+    std::vector<uint32_t>   level_begin;
+    std::vector<float>      node_box;      // 6 floats per node: union of the padded primitive boxes below it
+    float pad = 0.0f;                      // what was added around every primitive box
+    double area_sum = 0.0;                 // sum of the nodes' half areas (refit quality baseline)
 };
 
 // Deterministic host build (binned SAH BVH2 -> greedy collapse to 8-wide -> octant slot
 // assignment -> outward-rounded 8-bit quantisation).  threads <= 0: hardware concurrency.
-void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads = 0);
+// scene_scale > 0 overrides the largest |coordinate| the padding is derived from.
+void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads = 0, float scene_scale = 0.0f);
 
 // Structural self-check used by the CPU tests: every primitive's bounds lie inside the
 // dequantised box of every ancestor slot.  Returns an empty string when consistent.

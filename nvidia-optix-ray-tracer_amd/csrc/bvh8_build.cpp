@@ -12,6 +12,7 @@
 //      front-to-back order during traversal;
 //   4. outward-rounded 8-bit quantisation of the child boxes against the node origin/exponent.
 #include "bvh8.h"
+#include "bvh8_geom.h"
 
 #include <algorithm>
 #include <atomic>
@@ -153,7 +154,7 @@ inline uint8_t unary_count(uint32_t n) { return (uint8_t)((1u << n) - 1u); }
 
 }  // namespace
 
-void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads) {
+void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, float scene_scale) {
     out = Bvh8();
     const uint32_t n = (uint32_t)prims.size();
     for (const auto &p : prims) { if (p.rec.kind == kPrimKindSphere) out.n_spheres++; else out.n_triangles++; }
@@ -163,6 +164,8 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads) {
         root.e[0] = root.e[1] = root.e[2] = 127;
         for (int a = 0; a < 3; ++a) for (int s = 0; s < 8; ++s) { root.qlo[a][s] = 255; root.qhi[a][s] = 0; }
         out.nodes.push_back(root);
+        out.level_begin = {0u, 1u};
+        out.node_box.assign(6, 0.0f);
         return;
     }
 
@@ -173,7 +176,9 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads) {
         for (int a = 0; a < 3; ++a) smax = std::max(smax, std::max(std::fabs(prims[i].lo[a]), std::fabs(prims[i].hi[a])));
     // Padding keeps the quantised slab test conservative w.r.t. the canonical intersector's
     // own rounding (DESIGN.md "conservative boxes"): 4e-6 of the scene scale.
+    if (scene_scale > 0.0f) smax = std::max(1.0f, scene_scale);
     const float pad = 4e-6f * smax;
+    out.pad = pad;
     for (uint32_t i = 0; i < n; ++i) {
         B.idx[i] = i;
         for (int a = 0; a < 3; ++a) {
@@ -310,11 +315,14 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads) {
         Bvh8Node nd; std::memset(&nd, 0, sizeof nd);
         for (int a = 0; a < 3; ++a) {
             nd.p[a] = bn.lo[a];
-            const float ext = bn.hi[a] - bn.lo[a];
-            int e = ext > 0.0f ? (int)std::ceil(std::log2((double)ext / 255.0)) : -126;
-            e = std::min(std::max(e, -126), 127);
-            while (e < 127 && std::ldexp(255.0, e) < (double)ext) ++e;
-            nd.e[a] = (uint8_t)(e + 127);
+            nd.e[a] = node_exponent(bn.hi[a] - bn.lo[a]);
+        }
+        if (out.level_begin.size() <= it.depth) out.level_begin.push_back(self);
+        for (int a = 0; a < 3; ++a) out.node_box.push_back(bn.lo[a]);
+        for (int a = 0; a < 3; ++a) out.node_box.push_back(bn.hi[a]);
+        {
+            const double ex = (double)bn.hi[0] - bn.lo[0], ey = (double)bn.hi[1] - bn.lo[1], ez = (double)bn.hi[2] - bn.lo[2];
+            out.area_sum += ex * ey + ey * ez + ez * ex;
         }
         nd.child_base = (uint32_t)queue.size();
         nd.prim_base = (uint32_t)out.prims.size();
@@ -327,16 +335,7 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads) {
                 continue;
             }
             const B2 &c = B.nodes[ch[k]];
-            for (int a = 0; a < 3; ++a) {
-                const double sc = std::ldexp(1.0, (int)nd.e[a] - 127);
-                int ql = (int)std::floor(((double)c.lo[a] - (double)nd.p[a]) / sc);
-                int qh = (int)std::ceil(((double)c.hi[a] - (double)nd.p[a]) / sc);
-                ql = std::min(std::max(ql, 0), 255); qh = std::min(std::max(qh, 0), 255);
-                const float fs = (float)sc;
-                while (ql > 0 && nd.p[a] + (float)ql * fs > c.lo[a]) --ql;       // float decode must stay outside
-                while (qh < 255 && nd.p[a] + (float)qh * fs < c.hi[a]) ++qh;
-                nd.qlo[a][s] = (uint8_t)ql; nd.qhi[a][s] = (uint8_t)qh;
-            }
+            for (int a = 0; a < 3; ++a) quantise_axis(nd.p[a], nd.e[a], c.lo[a], c.hi[a], &nd.qlo[a][s], &nd.qhi[a][s]);
             if (ch_leaf[k]) {
                 nd.meta[s] = (uint8_t)((unary_count(c.nprims) << 5) | prim_off);
                 for (uint32_t i = 0; i < c.nprims; ++i) {
@@ -355,6 +354,7 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads) {
         }
         out.nodes[self] = nd;
     }
+    out.level_begin.push_back((uint32_t)out.nodes.size());
 }
 
 // Walk the packed tree and check containment of every primitive in every ancestor slot box.

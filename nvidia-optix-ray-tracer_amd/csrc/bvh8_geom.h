@@ -1,0 +1,95 @@
+// bvh8_geom.h -- the arithmetic the host builder and the device refit must agree on, bit for bit:
+// instance transform of a point, world-space primitive records and bounds, and the quantisation of
+// child boxes against a node's origin / exponents.  Compiled with -ffp-contract=off on both sides, so
+// a refit under unchanged transforms reproduces the built tree byte for byte (tests/test_gpu_parity.py).
+//
+// Replaces (together with the refit kernel) what optixAccelBuild(OPTIX_BUILD_OPERATION_UPDATE) does for
+// the reference's per-frame updateIAS (src/Global/RendererImpl.cu:210-242).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HRT_HD __host__ __device__ inline
+#else
+#define HRT_HD inline
+#endif
+
+namespace hrt {
+
+// 3x4 row-major affine transform of a point, fixed operation order (the oracle applies the same one)
+HRT_HD void xf_point(const float *m, const float *p, float *o) {
+    o[0] = ((m[0] * p[0] + m[1] * p[1]) + m[2] * p[2]) + m[3];
+    o[1] = ((m[4] * p[0] + m[5] * p[1]) + m[6] * p[2]) + m[7];
+    o[2] = ((m[8] * p[0] + m[9] * p[1]) + m[10] * p[2]) + m[11];
+}
+
+// World-space triangle record (v0, e1 = v1 - v0, e2 = v2 - v0) and bounds from 9 object-space floats.
+HRT_HD void triangle_world(const float *src9, const float *m, bool identity, float *v0, float *e1, float *e2, float *lo, float *hi) {
+    float v[3][3];
+    for (int k = 0; k < 3; ++k) {
+        const float *s = src9 + 3 * k;
+        if (identity) { v[k][0] = s[0]; v[k][1] = s[1]; v[k][2] = s[2]; } else xf_point(m, s, v[k]);
+    }
+    for (int a = 0; a < 3; ++a) {
+        v0[a] = v[0][a]; e1[a] = v[1][a] - v[0][a]; e2[a] = v[2][a] - v[0][a];
+        lo[a] = fminf(v[0][a], fminf(v[1][a], v[2][a]));
+        hi[a] = fmaxf(v[0][a], fmaxf(v[1][a], v[2][a]));
+    }
+}
+
+// World-space bounds of an object-space sphere under an affine instance transform: the transformed
+// corners of its object-space box (exact for the rotations / scales the reference composes).
+HRT_HD void sphere_world_bounds(const float *c, float r, const float *m, bool identity, float *lo, float *hi) {
+    const float rr = fabsf(r);
+    for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+    for (int k = 0; k < 8; ++k) {
+        const float q[3] = {c[0] + ((k & 1) ? rr : -rr), c[1] + ((k & 2) ? rr : -rr), c[2] + ((k & 4) ? rr : -rr)};
+        float w[3];
+        if (identity) { w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; } else xf_point(m, q, w);
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], w[a]); hi[a] = fmaxf(hi[a], w[a]); }
+    }
+}
+
+HRT_HD bool finite_box(const float *lo, const float *hi) {
+    bool ok = true;
+    for (int a = 0; a < 3; ++a) ok = ok && (fabsf(lo[a]) <= 3.0e38f) && (fabsf(hi[a]) <= 3.0e38f);
+    return ok;
+}
+
+// Smallest exponent e (biased by 127, within [1, 254]) with 255 * 2^(e-127) >= ext, from the bits of ext.
+HRT_HD uint8_t node_exponent(float ext) {
+    if (!(ext > 0.0f)) return 1;
+    uint32_t bits; memcpy(&bits, &ext, 4);
+    const int E = (int)((bits >> 23) & 0xffu);
+    const uint32_t M = bits & 0x7fffffu;
+    if (E == 0) return 1;                                  // subnormal extent
+    if (E == 255) return 254;                              // inf / nan: callers never build on those
+    // ext = (1 + M/2^23) * 2^(E-127); 255 * 2^-8 covers mantissas up to 255/128
+    int e = (M <= 0x7f0000u) ? (E - 127) - 7 : (E - 127) - 6;
+    if (e < -126) e = -126;
+    if (e > 127) e = 127;
+    return (uint8_t)(e + 127);
+}
+
+HRT_HD float exponent_scale(uint8_t e) {
+    const uint32_t bits = (uint32_t)e << 23; float f; memcpy(&f, &bits, 4); return f;
+}
+
+// Outward-rounded 8-bit coordinates of [clo, chi] on the grid p + q * 2^(e-127); the float decode
+// p + (float)q * scale stays outside the box.
+HRT_HD void quantise_axis(float p, uint8_t e, float clo, float chi, uint8_t *qlo, uint8_t *qhi) {
+    const float fs = exponent_scale(e);
+    const double sc = (double)fs;
+    double dl = floor(((double)clo - (double)p) / sc), dh = ceil(((double)chi - (double)p) / sc);
+    dl = (dl >= 0.0) ? (dl > 255.0 ? 255.0 : dl) : 0.0;          // NaN -> widest
+    dh = (dh <= 255.0) ? (dh < 0.0 ? 0.0 : dh) : 255.0;
+    int ql = (int)dl, qh = (int)dh;
+    while (ql > 0 && p + (float)ql * fs > clo) --ql;
+    while (qh < 255 && p + (float)qh * fs < chi) ++qh;
+    *qlo = (uint8_t)ql; *qhi = (uint8_t)qh;
+}
+
+}  // namespace hrt

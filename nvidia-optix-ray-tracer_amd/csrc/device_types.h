@@ -57,7 +57,9 @@ struct TraverseSeg {
 
 // fused path mode (k_traverse<..., FUSED>): what generate / shade / accumulate need, in one launch
 struct PathArgs {
-    const uint32_t *rows; uint32_t first_pixel, n_tile_pixels, width, height, spp;
+    const uint32_t *rows; uint32_t first_pixel, n_tile_pixels, width, height;
+    uint32_t spp;                  // samples taken by THIS launch
+    uint32_t continue_sum;         // 1: accum already holds the sum of earlier samples of this render
     float center[3], U[3], V[3], W[3], bg[3];
     RngState *states;
     const HitGroup *hitgroups; const uint32_t *inst_program;
@@ -117,6 +119,20 @@ struct FinalizeArgs {
     uint32_t n_tile_pixels, width, spp;
     float4 *color, *albedo, *normal, *linear;
 };
+
+// one level of the bottom-up refit (refit.hip)
+struct RefitArgs {
+    unsigned char *nodes; uint32_t node_stride;
+    unsigned char *prims; uint32_t prim_stride;
+    float *node_box;               // 6 floats per node: padded bounds of everything below it
+    uint32_t first_node, n_nodes;  // the level
+    const float *inst_xf;          // 12 floats per instance: object -> world
+    const uint32_t *inst_identity;
+    const void *const *inst_src;   // per instance: object-space triangle vertices (9 floats per triangle) of its BLAS
+    float pad;
+    float *area_sum;               // sum of the nodes' half areas (tree quality after the refit), may be NULL
+};
+void launch_refit_level(const RefitArgs &a, hipStream_t s);
 
 // host-callable launchers (defined in kernels.hip)
 void launch_rng_init(RngState *states, uint32_t n, uint64_t salt, const uint32_t *d_jump, hipStream_t s);

@@ -4,6 +4,7 @@
 // HIP kernel launch, and context creation fails when no gfx950 device is present.
 #include "../../include/hrt.h"
 #include "bvh8.h"
+#include "bvh8_geom.h"
 #include "device_types.h"
 
 #include <hip/hip_runtime.h>
@@ -31,6 +32,10 @@ struct Blas {
     std::vector<float> verts;        // triangles: 9 floats each (object space)
     std::vector<float> centers;      // spheres: 3 floats each
     std::vector<float> radii;
+    float *d_verts = nullptr;        // device copy of verts: the refit re-derives the world-space records from it
+                                     // (the caller may free its vertex buffer after the build, RendererMesh.cu:116)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};   // object-space bounds
+    ~Blas() { if (d_verts) (void)hipFree(d_verts); }
 };
 
 struct Tlas {
@@ -44,6 +49,15 @@ struct Tlas {
     bool has_spheres = false;
     uint32_t node_stride = 80, prim_stride = 48;
     uint64_t generation = 0;
+    // refit (hrt_tlas_update): what must stay the same, and the device tables the refit kernel reads
+    std::vector<std::shared_ptr<Blas>> blas_refs;       // keeps the source geometry alive
+    std::vector<uint64_t> sig_handle; std::vector<uint32_t> sig_visibility;
+    std::vector<float> h_xf, h_inv; std::vector<uint32_t> h_ident;   // staging of the per-instance uploads
+    float *d_node_box = nullptr, *d_inst_xf = nullptr, *d_area = nullptr;
+    const void **d_inst_src = nullptr;
+    float *h_area = nullptr;                             // pinned: area sum of the last refit
+    hipEvent_t area_ready = nullptr; bool area_pending = false;
+    uint64_t refits = 0, rebuilds = 0;
 };
 
 // per-depth counters, zeroed once per sample: bin sizes + 8 slice counters on 128-byte lines of their own
@@ -79,7 +93,7 @@ struct HrtContext {
     int n_cu = 256;
     std::string error;
     std::mutex mu;
-    std::unordered_map<uint64_t, std::unique_ptr<Blas>> blas;
+    std::unordered_map<uint64_t, std::shared_ptr<Blas>> blas;
     std::unordered_map<uint64_t, std::unique_ptr<Tlas>> tlas;
     uint64_t next_handle = 0x1000;
     // materials
@@ -110,9 +124,13 @@ struct HrtContext {
     int node_stride = 80, prim_stride = 64;     // bytes between records in HBM (80/48 packed; 128/64 = one cache line each)
     int fused = 1;                              // 1: fused persistent path mode (default), 0: wavefront kernels, -1: fused only for small tiles
     int fused_max_pixels = 700000;
+    int fused_max_spp = 512;                    // samples per fused launch
     int lds_gather = 0;                         // 1: cooperative LDS-DMA gathers, 0: per-lane register loads
     int fetch_chunk = 64;
     int substream_min_pixels = 32768;
+    int refit = 1;                              // hrt_tlas_update: 1 = device refit when only transforms changed, 0 = always rebuild
+    float refit_rebuild_ratio = 2.0f;           // rebuild when the refitted tree's node area sum exceeds this x the built tree's
+    uint64_t tlas_refits = 0, tlas_rebuilds = 0;
     int substreams = 0;                         // sub-tiles rendered on their own HIP streams so that one's tail overlaps another's bulk
     std::vector<hipStream_t> sub_streams; std::vector<hipEvent_t> sub_done; hipEvent_t ev_begin = nullptr;
 };
@@ -172,11 +190,6 @@ bool is_identity(const float *m) {
     static const float id[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     return std::memcmp(m, id, sizeof id) == 0;
 }
-inline void xf_point(const float *m, const float *p, float *o) {
-    o[0] = ((m[0] * p[0] + m[1] * p[1]) + m[2] * p[2]) + m[3];
-    o[1] = ((m[4] * p[0] + m[5] * p[1]) + m[6] * p[2]) + m[7];
-    o[2] = ((m[8] * p[0] + m[9] * p[1]) + m[10] * p[2]) + m[11];
-}
 void invert_affine(const float *m, float *o) {
     const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
     const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
@@ -196,91 +209,113 @@ void free_tlas_device(Tlas &t) {
     if (t.d_prims) (void)hipFree(t.d_prims);
     if (t.d_inst_inv) (void)hipFree(t.d_inst_inv);
     if (t.d_inst_identity) (void)hipFree(t.d_inst_identity);
+    if (t.d_node_box) (void)hipFree(t.d_node_box);
+    if (t.d_inst_xf) (void)hipFree(t.d_inst_xf);
+    if (t.d_area) (void)hipFree(t.d_area);
+    if (t.d_inst_src) (void)hipFree((void *)t.d_inst_src);
     t.d_nodes = t.d_prims = nullptr; t.d_inst_inv = nullptr; t.d_inst_identity = nullptr;
+    t.d_node_box = t.d_inst_xf = t.d_area = nullptr; t.d_inst_src = nullptr;
+    t.area_pending = false;
+}
+void free_tlas_host(Tlas &t) {
+    if (t.h_area) (void)hipHostFree(t.h_area);
+    if (t.area_ready) (void)hipEventDestroy(t.area_ready);
+    t.h_area = nullptr; t.area_ready = nullptr;
 }
 
-// Flatten the instances into world space, build the BVH8 on the host, upload it.
-int build_tlas_into(HrtContext *ctx, Tlas &t, const HrtInstance *d_instances, uint32_t n, hipStream_t s) {
-    std::vector<HrtInstance> inst(n);
-    if (n) {
-        HIP_TRY(ctx, hipMemcpyAsync(inst.data(), d_instances, sizeof(HrtInstance) * (size_t)n, hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
+// Per-instance tables of a set of instances: object->world, world->object, identity flags, and the
+// largest |coordinate| of the transformed BLAS boxes (what the padding of the tree is derived from).
+float instance_tables(const std::vector<HrtInstance> &inst, const std::vector<std::shared_ptr<Blas>> &blas,
+                      std::vector<float> &xf, std::vector<float> &inv, std::vector<uint32_t> &ident) {
+    const size_t n = inst.size();
+    xf.assign(12 * std::max<size_t>(n, 1), 0.0f); inv.assign(12 * std::max<size_t>(n, 1), 0.0f); ident.assign(std::max<size_t>(n, 1), 1u);
+    float smax = 1.0f;
+    for (size_t i = 0; i < n; ++i) {
+        const float *m = inst[i].transform;
+        std::memcpy(&xf[12 * i], m, 12 * sizeof(float));
+        const bool id = is_identity(m);
+        ident[i] = id ? 1u : 0u;
+        invert_affine(m, &inv[12 * i]);
+        const Blas &b = *blas[i];
+        if ((inst[i].visibilityMask & 1u) == 0 || !(b.lo[0] <= b.hi[0])) continue;
+        for (int c = 0; c < 8; ++c) {
+            const float q[3] = {(c & 1) ? b.hi[0] : b.lo[0], (c & 2) ? b.hi[1] : b.lo[1], (c & 4) ? b.hi[2] : b.lo[2]};
+            float w[3];
+            if (id) { w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; } else xf_point(m, q, w);
+            for (int a = 0; a < 3; ++a) if (std::isfinite(w[a])) smax = std::max(smax, std::fabs(w[a]));
+        }
     }
-    std::vector<BuildPrim> prims;
-    std::vector<float> inv(12 * (size_t)std::max(n, 1u));
-    std::vector<uint32_t> ident(std::max(n, 1u), 1u);
-    t.sbt_offset.assign(n, 0); t.kind.assign(n, 0); t.has_spheres = false;
+    return smax;
+}
+
+// Flatten the instances into world space, build the BVH8 on the host, upload it together with the
+// tables the device refit needs (hrt_tlas_update).
+int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s) {
+    const uint32_t n = (uint32_t)inst.size();
+    std::vector<std::shared_ptr<Blas>> refs(n);
     size_t total = 0;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         for (uint32_t i = 0; i < n; ++i) {
             auto it = ctx->blas.find(inst[i].traversableHandle);
             if (it == ctx->blas.end()) return fail(ctx, HRT_ERR_INVALID, "instance %u: unknown BLAS handle 0x%llx", i, (unsigned long long)inst[i].traversableHandle);
+            refs[i] = it->second;
             total += it->second->n_prims;
         }
     }
+    const float scene_scale = instance_tables(inst, refs, t.h_xf, t.h_inv, t.h_ident);
+    t.sbt_offset.assign(n, 0); t.kind.assign(n, 0); t.has_spheres = false;
+    t.sig_handle.assign(n, 0); t.sig_visibility.assign(n, 0);
+    std::vector<BuildPrim> prims;
     prims.reserve(total);
     for (uint32_t i = 0; i < n; ++i) {
-        const Blas *b;
-        { std::lock_guard<std::mutex> lk(ctx->mu); b = ctx->blas.find(inst[i].traversableHandle)->second.get(); }
+        const Blas *b = refs[i].get();
         const float *m = inst[i].transform;
-        const bool id = is_identity(m);
-        ident[i] = id ? 1u : 0u;
-        invert_affine(m, &inv[12 * (size_t)i]);
+        const bool id = t.h_ident[i] != 0u;
         t.sbt_offset[i] = inst[i].sbtOffset;
         t.kind[i] = b->kind;
+        t.sig_handle[i] = inst[i].traversableHandle; t.sig_visibility[i] = inst[i].visibilityMask & 1u;
         if ((inst[i].visibilityMask & 1u) == 0) continue;       // the reference traces with mask 1 (Shader.cu:71)
         for (uint32_t p = 0; p < b->n_prims; ++p) {
             BuildPrim bp; std::memset(&bp, 0, sizeof bp);
             if (b->kind == kPrimKindTriangle) {
-                float v[3][3];
-                for (int k = 0; k < 3; ++k) {
-                    const float *src = &b->verts[9 * (size_t)p + 3 * k];
-                    if (id) { v[k][0] = src[0]; v[k][1] = src[1]; v[k][2] = src[2]; } else xf_point(m, src, v[k]);
-                }
-                for (int a = 0; a < 3; ++a) {
-                    bp.rec.a[a] = v[0][a]; bp.rec.b[a] = v[1][a] - v[0][a]; bp.rec.c[a] = v[2][a] - v[0][a];
-                    bp.lo[a] = std::fmin(v[0][a], std::fmin(v[1][a], v[2][a]));
-                    bp.hi[a] = std::fmax(v[0][a], std::fmax(v[1][a], v[2][a]));
-                }
+                triangle_world(&b->verts[9 * (size_t)p], m, id, bp.rec.a, bp.rec.b, bp.rec.c, bp.lo, bp.hi);
                 bp.rec.prim = p; bp.rec.inst = i; bp.rec.kind = kPrimKindTriangle;
-                // NaN / Inf geometry never hits anything; keep it out of the tree
-                bool ok = true;
-                for (int a = 0; a < 3; ++a) ok = ok && std::isfinite(bp.lo[a]) && std::isfinite(bp.hi[a]);
-                if (!ok) continue;
             } else {
                 t.has_spheres = true;
                 const float *c = &b->centers[3 * (size_t)p];
-                const float r = b->radii[p], rr = std::fabs(r);
                 bp.rec.a[0] = c[0]; bp.rec.a[1] = c[1]; bp.rec.a[2] = c[2]; bp.rec.prim = p;
-                bp.rec.b[0] = r; bp.rec.inst = i; bp.rec.kind = kPrimKindSphere;
-                for (int a = 0; a < 3; ++a) { bp.lo[a] = INFINITY; bp.hi[a] = -INFINITY; }
-                for (int cidx = 0; cidx < 8; ++cidx) {
-                    float q[3] = {c[0] + ((cidx & 1) ? rr : -rr), c[1] + ((cidx & 2) ? rr : -rr), c[2] + ((cidx & 4) ? rr : -rr)}, w[3];
-                    if (id) { w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; } else xf_point(m, q, w);
-                    for (int a = 0; a < 3; ++a) { bp.lo[a] = std::fmin(bp.lo[a], w[a]); bp.hi[a] = std::fmax(bp.hi[a], w[a]); }
-                }
-                bool ok = true;
-                for (int a = 0; a < 3; ++a) ok = ok && std::isfinite(bp.lo[a]) && std::isfinite(bp.hi[a]);
-                if (!ok) continue;
+                bp.rec.b[0] = b->radii[p]; bp.rec.inst = i; bp.rec.kind = kPrimKindSphere;
+                sphere_world_bounds(c, b->radii[p], m, id, bp.lo, bp.hi);
             }
+            // NaN / Inf geometry never hits anything; keep it out of the tree
+            if (!finite_box(bp.lo, bp.hi)) continue;
             prims.push_back(bp);
         }
     }
-    build_bvh8(prims, t.bvh, 0);
+    build_bvh8(prims, t.bvh, 0, scene_scale);
     if (2 * t.bvh.max_depth + 2 > (uint32_t)(8 + 56))
         return fail(ctx, HRT_ERR_INVALID, "BVH depth %u exceeds the traversal stack", t.bvh.max_depth);
 
     free_tlas_device(t);
     t.n_instances = n;
+    t.blas_refs = std::move(refs);
     t.node_stride = (uint32_t)ctx->node_stride; t.prim_stride = (uint32_t)ctx->prim_stride;
     const size_t n_nodes = t.bvh.nodes.size(), n_prims = t.bvh.prims.size();
     const size_t nb = (size_t)t.node_stride * n_nodes;
     const size_t pb = (size_t)t.prim_stride * std::max<size_t>(n_prims, 1);
+    std::vector<const void *> src(std::max(n, 1u), nullptr);
+    for (uint32_t i = 0; i < n; ++i) src[i] = t.blas_refs[i]->d_verts;
     HIP_TRY(ctx, hipMalloc(&t.d_nodes, nb));
     HIP_TRY(ctx, hipMalloc(&t.d_prims, pb));
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_inv, sizeof(float) * inv.size()));
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_identity, sizeof(uint32_t) * ident.size()));
+    HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_inv, sizeof(float) * t.h_inv.size()));
+    HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_xf, sizeof(float) * t.h_xf.size()));
+    HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_identity, sizeof(uint32_t) * t.h_ident.size()));
+    HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_src, sizeof(void *) * src.size()));
+    HIP_TRY(ctx, hipMalloc((void **)&t.d_node_box, sizeof(float) * std::max<size_t>(t.bvh.node_box.size(), 6)));
+    HIP_TRY(ctx, hipMalloc((void **)&t.d_area, sizeof(float)));
+    if (!t.h_area) HIP_TRY(ctx, hipHostMalloc((void **)&t.h_area, sizeof(float), hipHostMallocDefault));
+    if (!t.area_ready) HIP_TRY(ctx, hipEventCreateWithFlags(&t.area_ready, hipEventDisableTiming));
     if (t.node_stride == sizeof(Bvh8Node) && t.prim_stride == sizeof(PrimRecord)) {
         HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, t.bvh.nodes.data(), nb, hipMemcpyHostToDevice, s));
         if (n_prims) HIP_TRY(ctx, hipMemcpyAsync(t.d_prims, t.bvh.prims.data(), sizeof(PrimRecord) * n_prims, hipMemcpyHostToDevice, s));
@@ -293,10 +328,24 @@ int build_tlas_into(HrtContext *ctx, Tlas &t, const HrtInstance *d_instances, ui
         HIP_TRY(ctx, hipMemcpyAsync(t.d_prims, hp.data(), pb, hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
     }
-    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_inv, inv.data(), sizeof(float) * inv.size(), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_identity, ident.data(), sizeof(uint32_t) * ident.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_inv, t.h_inv.data(), sizeof(float) * t.h_inv.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_xf, t.h_xf.data(), sizeof(float) * t.h_xf.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_identity, t.h_ident.data(), sizeof(uint32_t) * t.h_ident.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync((void *)t.d_inst_src, src.data(), sizeof(void *) * src.size(), hipMemcpyHostToDevice, s));
+    if (!t.bvh.node_box.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_node_box, t.bvh.node_box.data(), sizeof(float) * t.bvh.node_box.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     t.generation++;
+    t.rebuilds++; ctx->tlas_rebuilds++;
+    return HRT_OK;
+}
+
+int download_instances(HrtContext *ctx, const HrtInstance *d_instances, uint32_t n, hipStream_t s, std::vector<HrtInstance> &inst) {
+    inst.resize(n);
+    if (n) {
+        HIP_TRY(ctx, hipMemcpyAsync(inst.data(), d_instances, sizeof(HrtInstance) * (size_t)n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+    }
     return HRT_OK;
 }
 
@@ -308,7 +357,7 @@ int ensure_workspace(HrtContext *ctx, uint32_t n, uint32_t height) {
         for (SampleSet &st : w.set) {
             void *ptrs[] = {st.rays[0], st.rays[1], st.hit_tuvp, st.hit_inst, st.bin_items, st.chain, st.result};
             for (void *p : ptrs) if (p) (void)hipFree(p);
-            st = SampleSet{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st.stages};
+            st = SampleSet{{nullptr, nullptr}, nullptr, nullptr, nullptr, nullptr, nullptr, st.stages};
         }
         if (w.accum) (void)hipFree(w.accum);
         w.accum = nullptr; w.capacity = 0;
@@ -358,6 +407,36 @@ void drain_spans(HrtContext *ctx) {
     ctx->events_used = 0;
 }
 
+// Device refit of a built tree under new instance transforms: upload the per-instance tables, then one
+// k_refit_level launch per tree level, deepest first.  Asynchronous on s.
+int refit_tlas(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s) {
+    const float scene_scale = instance_tables(inst, t.blas_refs, t.h_xf, t.h_inv, t.h_ident);
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_inv, t.h_inv.data(), sizeof(float) * t.h_inv.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_xf, t.h_xf.data(), sizeof(float) * t.h_xf.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_identity, t.h_ident.data(), sizeof(uint32_t) * t.h_ident.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemsetAsync(t.d_area, 0, sizeof(float), s));
+    RefitArgs ra{};
+    ra.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); ra.node_stride = t.node_stride;
+    ra.prims = reinterpret_cast<unsigned char *>(t.d_prims); ra.prim_stride = t.prim_stride;
+    ra.node_box = t.d_node_box; ra.inst_xf = t.d_inst_xf; ra.inst_identity = t.d_inst_identity; ra.inst_src = t.d_inst_src;
+    ra.pad = 4e-6f * std::max(1.0f, scene_scale);
+    ra.area_sum = t.d_area;
+    {
+        Timer tm(ctx, s, HRT_K_REFIT);
+        const std::vector<uint32_t> &lv = t.bvh.level_begin;
+        for (size_t l = lv.size() - 1; l-- > 0;) {
+            ra.first_node = lv[l]; ra.n_nodes = lv[l + 1] - lv[l];
+            launch_refit_level(ra, s);
+        }
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(t.h_area, t.d_area, sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipEventRecord(t.area_ready, s));
+    t.area_pending = true;
+    t.refits++; ctx->tlas_refits++;
+    return HRT_OK;
+}
+
 }  // namespace
 
 // ======================================================================================
@@ -392,6 +471,9 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_NODE_STRIDE")) { const int v = std::atoi(e); if (v >= 80 && v <= 256 && v % 16 == 0) ctx->node_stride = v; }
     if (const char *e = std::getenv("HRT_PRIM_STRIDE")) { const int v = std::atoi(e); if (v >= 48 && v <= 256 && v % 16 == 0) ctx->prim_stride = v; }
     if (const char *e = std::getenv("HRT_FUSED")) ctx->fused = std::atoi(e);
+    if (const char *e = std::getenv("HRT_REFIT")) ctx->refit = std::atoi(e) != 0;
+    if (const char *e = std::getenv("HRT_REFIT_REBUILD_RATIO")) { const double v = std::atof(e); if (v >= 1.0) ctx->refit_rebuild_ratio = (float)v; }
+    if (const char *e = std::getenv("HRT_FUSED_MAX_SPP")) { const int v = std::atoi(e); if (v >= 1) ctx->fused_max_spp = v; }
     if (const char *e = std::getenv("HRT_FUSED_MAX_PIXELS")) { const int v = std::atoi(e); if (v > 0) ctx->fused_max_pixels = v; }
     if (const char *e = std::getenv("HRT_LDS_GATHER")) ctx->lds_gather = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_TAIL_SPLIT")) ctx->tail_split = std::atoi(e) != 0;
@@ -416,7 +498,7 @@ int hrt_ctx_destroy(HrtContext *ctx) {
     if (!ctx) return HRT_ERR_INVALID;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    for (auto &kv : ctx->tlas) free_tlas_device(*kv.second);
+    for (auto &kv : ctx->tlas) { free_tlas_device(*kv.second); free_tlas_host(*kv.second); }
     Workspace &w = ctx->ws;
     for (SampleSet &st : w.set) {
         void *sp[] = {st.rays[0], st.rays[1], st.hit_tuvp, st.hit_inst, st.bin_items, st.chain, st.result, st.stages};
@@ -438,12 +520,20 @@ int hrt_blas_build_triangles(HrtContext *ctx, const HrtFloat3 *d_vertices, uint3
     if (n_vertices % 3 != 0) return fail(ctx, HRT_ERR_INVALID, "n_vertices (%u) is not a multiple of 3", n_vertices);
     if (n_vertices && !d_vertices) return fail(ctx, HRT_ERR_INVALID, "d_vertices is NULL");
     (void)hipSetDevice(ctx->device);
-    std::unique_ptr<Blas> b(new Blas());
+    std::shared_ptr<Blas> b(new Blas());
     b->kind = kPrimKindTriangle; b->n_prims = n_vertices / 3;
     b->verts.resize(3 * (size_t)n_vertices);
     if (n_vertices) {
-        HIP_TRY(ctx, hipMemcpyAsync(b->verts.data(), d_vertices, sizeof(float) * 3 * (size_t)n_vertices, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        const size_t bytes = sizeof(float) * 3 * (size_t)n_vertices;
+        HIP_TRY(ctx, hipMalloc((void **)&b->d_verts, bytes));
+        HIP_TRY(ctx, hipMemcpyAsync(b->d_verts, d_vertices, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        HIP_TRY(ctx, hipMemcpyAsync(b->verts.data(), d_vertices, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
         HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+        for (size_t v = 0; v < n_vertices; ++v) {
+            const float *q = &b->verts[3 * v];
+            if (!(std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2]))) continue;
+            for (int a = 0; a < 3; ++a) { b->lo[a] = std::fmin(b->lo[a], q[a]); b->hi[a] = std::fmax(b->hi[a], q[a]); }
+        }
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const uint64_t h = ctx->next_handle++;
@@ -456,13 +546,18 @@ int hrt_blas_build_spheres(HrtContext *ctx, const HrtFloat3 *d_centers, const fl
     if (!ctx || !out_blas) return HRT_ERR_INVALID;
     if (n && (!d_centers || !d_radii)) return fail(ctx, HRT_ERR_INVALID, "sphere arrays are NULL");
     (void)hipSetDevice(ctx->device);
-    std::unique_ptr<Blas> b(new Blas());
+    std::shared_ptr<Blas> b(new Blas());
     b->kind = kPrimKindSphere; b->n_prims = n;
     b->centers.resize(3 * (size_t)n); b->radii.resize(n);
     if (n) {
         HIP_TRY(ctx, hipMemcpyAsync(b->centers.data(), d_centers, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, (hipStream_t)stream));
         HIP_TRY(ctx, hipMemcpyAsync(b->radii.data(), d_radii, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, (hipStream_t)stream));
         HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+        for (size_t p = 0; p < n; ++p) {
+            const float *c = &b->centers[3 * p]; const float rr = std::fabs(b->radii[p]);
+            if (!(std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(rr))) continue;
+            for (int a = 0; a < 3; ++a) { b->lo[a] = std::fmin(b->lo[a], c[a] - rr); b->hi[a] = std::fmax(b->hi[a], c[a] + rr); }
+        }
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const uint64_t h = ctx->next_handle++;
@@ -482,8 +577,10 @@ int hrt_tlas_build(HrtContext *ctx, const HrtInstance *d_instances, uint32_t n, 
     if (n && !d_instances) return fail(ctx, HRT_ERR_INVALID, "d_instances is NULL");
     (void)hipSetDevice(ctx->device);
     std::unique_ptr<Tlas> t(new Tlas());
-    const int rc = build_tlas_into(ctx, *t, d_instances, n, (hipStream_t)stream);
-    if (rc != HRT_OK) { free_tlas_device(*t); return rc; }
+    std::vector<HrtInstance> inst;
+    int rc = download_instances(ctx, d_instances, n, (hipStream_t)stream, inst);
+    if (rc == HRT_OK) rc = build_tlas_into(ctx, *t, inst, (hipStream_t)stream);
+    if (rc != HRT_OK) { free_tlas_device(*t); free_tlas_host(*t); return rc; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const uint64_t h = ctx->next_handle++;
     ctx->tlas[h] = std::move(t);
@@ -491,15 +588,37 @@ int hrt_tlas_build(HrtContext *ctx, const HrtInstance *d_instances, uint32_t n, 
     return HRT_OK;
 }
 
+// updateIAS (RendererImpl.cu:210-242): the instance transforms changed.  When nothing else did, the tree
+// keeps its topology and is refitted on the device (refit.hip), asynchronously on `stream`; a change of
+// BLAS handle / visibility, or a refitted tree that has degraded past refit_rebuild_ratio, rebuilds.
 int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_instances, uint32_t n, void *stream) {
     if (!ctx) return HRT_ERR_INVALID;
     (void)hipSetDevice(ctx->device);
+    hipStream_t s = (hipStream_t)stream;
     Tlas *t;
     { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->tlas.find(tlas); if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle"); t = it->second.get(); }
     if (n != t->n_instances) return fail(ctx, HRT_ERR_INVALID, "update must keep the instance count (%u != %u)", n, t->n_instances);
-    // The flattened world-space tree is rebuilt (a refit of a two-level structure is a later row).
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    return build_tlas_into(ctx, *t, d_instances, n, (hipStream_t)stream);
+    if (n && !d_instances) return fail(ctx, HRT_ERR_INVALID, "d_instances is NULL");
+    std::vector<HrtInstance> inst;
+    const int rc = download_instances(ctx, d_instances, n, s, inst);
+    if (rc != HRT_OK) return rc;
+    bool same = ctx->refit != 0 && !t->bvh.prims.empty();
+    for (uint32_t i = 0; i < n && same; ++i)
+        same = inst[i].traversableHandle == t->sig_handle[i] && (inst[i].visibilityMask & 1u) == t->sig_visibility[i];
+    if (same && t->area_pending) {
+        HIP_TRY(ctx, hipEventSynchronize(t->area_ready));
+        t->area_pending = false;
+        // a refit keeps the topology: once the boxes have grown this much, a fresh build pays for itself
+        if (!((double)*t->h_area <= (double)ctx->refit_rebuild_ratio * t->bvh.area_sum)) same = false;
+    }
+    if (same) {
+        bool sbt_changed = false;
+        for (uint32_t i = 0; i < n; ++i) if (inst[i].sbtOffset != t->sbt_offset[i]) { t->sbt_offset[i] = inst[i].sbtOffset; sbt_changed = true; }
+        if (sbt_changed) t->generation++;                 // the material tables are re-derived at the next launch
+        return refit_tlas(ctx, *t, inst, s);
+    }
+    HIP_TRY(ctx, hipDeviceSynchronize());                 // launches on other streams may still read the old tree
+    return build_tlas_into(ctx, *t, inst, s);
 }
 
 int hrt_tlas_destroy(HrtContext *ctx, HrtTraversable tlas) {
@@ -509,7 +628,7 @@ int hrt_tlas_destroy(HrtContext *ctx, HrtTraversable tlas) {
     auto it = ctx->tlas.find(tlas);
     if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle");
     (void)hipDeviceSynchronize();
-    free_tlas_device(*it->second);
+    free_tlas_device(*it->second); free_tlas_host(*it->second);
     ctx->tlas.erase(it);
     return HRT_OK;
 }
@@ -645,7 +764,6 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
     const bool use_fused = !count && (ctx->fused > 0 || (ctx->fused < 0 && n <= (uint32_t)ctx->fused_max_pixels));
     if (use_fused) {
         StageCounters *stg = w.set[0].stages;
-        HIP_TRY(ctx, hipMemsetAsync(stg, 0, sizeof(StageCounters), s));
         TraverseArgs ta{};
         ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.node_stride = t->node_stride; ta.prim_stride = t->prim_stride;
         ta.fetch_counter = stg[0].fetch;
@@ -661,7 +779,15 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         pa.hitgroups = ctx->d_hitgroups; pa.inst_program = ctx->d_inst_program; pa.accum = w.accum;
         pa.rays_closest = &ctx->d_stats->rays_closest; pa.rays_any = &ctx->d_stats->rays_any;
         const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (n + 63u) / 64u);
-        { Timer tm(ctx, s, HRT_K_PATHS); launch_paths(ta, t->has_spheres, grid, s); }
+        // very long renders are cut into launches of at most fused_max_spp samples (a launch should stay in the
+        // range of seconds); the RNG states and the running sums carry over, so the result is the same bits
+        for (uint32_t done_spp = 0; done_spp < spp;) {
+            const uint32_t now = std::min<uint32_t>(spp - done_spp, (uint32_t)ctx->fused_max_spp);
+            pa.spp = now; pa.continue_sum = done_spp > 0 ? 1u : 0u;
+            HIP_TRY(ctx, hipMemsetAsync(stg, 0, sizeof(StageCounters), s));
+            { Timer tm(ctx, s, HRT_K_PATHS); launch_paths(ta, t->has_spheres, grid, s); }
+            done_spp += now;
+        }
         FinalizeArgs fa{};
         fa.accum = w.accum; fa.rows = w.rows; fa.n_tile_pixels = n; fa.width = rg->width; fa.spp = spp;
         fa.color = reinterpret_cast<float4 *>(rg->colorBuffer); fa.albedo = reinterpret_cast<float4 *>(rg->albedoBuffer);
@@ -852,6 +978,7 @@ int hrt_stats_get(HrtContext *ctx, HrtStats *out) {
     out->paths = ctx->paths; out->node_visits = ds.nodes_closest + ds.nodes_any; out->prim_tests = ds.prims_closest + ds.prims_any;
     out->node_visits_closest = ds.nodes_closest; out->prim_tests_closest = ds.prims_closest;
     for (int k = 0; k < 4; ++k) out->debug[k] = ds.debug[k];
+    out->tlas_refits = ctx->tlas_refits; out->tlas_rebuilds = ctx->tlas_rebuilds;
     for (int k = 0; k < HRT_K_COUNT; ++k) { out->kernel_ms[k] = ctx->kernel_ms[k]; out->kernel_launches[k] = ctx->kernel_launches[k]; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     auto it = ctx->tlas.find(ctx->last_tlas);
@@ -939,10 +1066,17 @@ int hrt_host_build_bvh8(const float *h_triangles, uint32_t n_triangles, HrtBvhBl
 
 int hrt_tlas_download(HrtContext *ctx, HrtTraversable tlas, HrtBvhBlob *out) {
     if (!ctx || !out) return HRT_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    auto it = ctx->tlas.find(tlas);
-    if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle");
-    return fill_blob(it->second->bvh, out);
+    (void)hipSetDevice(ctx->device);
+    Tlas *t;
+    { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->tlas.find(tlas); if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle"); t = it->second.get(); }
+    const int rc = fill_blob(t->bvh, out);
+    if (rc != HRT_OK) return rc;
+    // the device copy is the truth: a refit rewrites it in place
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    const size_t n_nodes = t->bvh.nodes.size(), n_prims = t->bvh.prims.size();
+    HIP_TRY(ctx, hipMemcpy2D(out->nodes, sizeof(Bvh8Node), t->d_nodes, t->node_stride, sizeof(Bvh8Node), n_nodes, hipMemcpyDeviceToHost));
+    if (n_prims) HIP_TRY(ctx, hipMemcpy2D(out->triangles, sizeof(PrimRecord), t->d_prims, t->prim_stride, sizeof(PrimRecord), n_prims, hipMemcpyDeviceToHost));
+    return HRT_OK;
 }
 
 void hrt_host_free(HrtBvhBlob *blob) {

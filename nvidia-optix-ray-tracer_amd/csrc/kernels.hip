@@ -409,7 +409,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     // FUSED (path mode): the lane owns a pixel and carries its path state; a finished ray is shaded in
     // place and the next ray (bounce, next sample, next pixel) starts in the same lane -- no queues, no
     // per-stage launches, no stage barriers.  Used for small tiles where per-stage latency dominates.
-    bool have_pixel = false, waiting = false;
+    bool have_pixel = false, waiting = false, px_first = true;
     uint32_t px_local = 0u, px_tid = 0u, px_sample = 0u, px_depth = 1u;
     uint32_t px_chain[4] = {0u, 0u, 0u, 0u};
     float px_ax = 0.0f, px_ay = 0.0f, px_az = 0.0f;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                     const bool miss = s.bprim == kMissPrim;
                     if (miss || px_depth >= kRayTraceDepth) {
                         const V3 r = fold_chain(miss, a.path.bg, px_chain, px_depth, a.path.hitgroups);
-                        if (px_sample == 0u) { px_ax = r.x; px_ay = r.y; px_az = r.z; }
+                        if (px_first) { px_ax = r.x; px_ay = r.y; px_az = r.z; px_first = false; }
                         else { px_ax += r.x; px_ay += r.y; px_az += r.z; }
                         ++px_sample;
                         if (px_sample >= a.path.spp) {
@@ -534,6 +534,8 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                             const uint32_t iy = a.path.rows[row];
                             px_local = j; px_tid = iy * a.path.width + ix;
                             px_sample = 0u; px_rng = rng_load(a.path.states + px_tid);
+                            px_first = a.path.continue_sum == 0u;         // later launches of a long render continue the pixel's sum
+                            if (!px_first) { const float4 acc = a.path.accum[px_local]; px_ax = acc.x; px_ay = acc.y; px_az = acc.z; }
                             have_pixel = true; want_primary = true;
                         }
                     }

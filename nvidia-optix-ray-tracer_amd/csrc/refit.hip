@@ -1,0 +1,113 @@
+// refit.hip -- per-frame update of the flattened world-space BVH8 on the device (gfx950).
+//
+// Replaces the reference's updateIAS (src/Global/RendererImpl.cu:210-242: optixAccelBuild with
+// OPTIX_BUILD_OPERATION_UPDATE, called every frame at src/Global/RendererTime.cu:480 after the host
+// loop has rewritten the instance transforms).  The tree keeps its topology; k_refit_level
+//   * re-derives every world-space primitive record from the object-space source geometry and the
+//     instance's new transform (same arithmetic as the host flatten: bvh8_geom.h), and
+//   * recomputes each node's origin, exponents and quantised child boxes bottom-up, one level per
+//     launch (nodes are stored breadth first, so a level is a contiguous range).
+// Eight lanes cooperate on a node, one per child slot; the union box is a 3-step butterfly.
+// HBM-bound: per node 80 B read + 80 B written + 24 B box, per primitive 36 B source + 48 B record.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bvh8_geom.h"
+#include "device_types.h"
+
+#pragma clang fp contract(off)
+
+namespace hrt {
+
+__device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
+
+__global__ __launch_bounds__(256) void k_refit_level(RefitArgs a) {
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t local = tid >> 3, slot = tid & 7u;
+    const bool live = local < a.n_nodes;                       // whole 8-lane groups are live or not
+    const uint32_t node = a.first_node + (live ? local : 0u);
+    unsigned char *nd = a.nodes + (size_t)node * a.node_stride;
+    const uint32_t *ndw = reinterpret_cast<const uint32_t *>(nd);
+
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    uint32_t meta = 0;
+    if (live) {
+        const uint32_t imask = ndw[3] >> 24, child_base = ndw[4], prim_base = ndw[5];
+        meta = nd[24 + slot];
+        if (meta != 0u) {
+            if ((imask >> slot) & 1u) {
+                const uint32_t c = child_base + (uint32_t)__popc(imask & ((1u << slot) - 1u));
+                const float *b = a.node_box + 6 * (size_t)c;
+                for (int k = 0; k < 3; ++k) { lo[k] = b[k]; hi[k] = b[3 + k]; }
+            } else {
+                const uint32_t cbits = meta >> 5, off = meta & 0x1fu;
+                const uint32_t cnt = cbits == 1u ? 1u : cbits == 3u ? 2u : 3u;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    unsigned char *rec = a.prims + (size_t)(prim_base + off + k) * a.prim_stride;
+                    float *rf = reinterpret_cast<float *>(rec);
+                    const uint32_t *ru = reinterpret_cast<const uint32_t *>(rec);
+                    const uint32_t prim = ru[3], inst = ru[7], kind = ru[11];
+                    const float *m = a.inst_xf + 12 * (size_t)inst;
+                    const bool ident = a.inst_identity[inst] != 0u;
+                    float plo[3], phi[3];
+                    if (kind == 0u) {
+                        const float *src = reinterpret_cast<const float *>(a.inst_src[inst]) + 9 * (size_t)prim;
+                        float s9[9];
+                        for (int q = 0; q < 9; ++q) s9[q] = src[q];
+                        float v0[3], e1[3], e2[3];
+                        triangle_world(s9, m, ident, v0, e1, e2, plo, phi);
+                        rf[0] = v0[0]; rf[1] = v0[1]; rf[2] = v0[2];
+                        rf[4] = e1[0]; rf[5] = e1[1]; rf[6] = e1[2];
+                        rf[8] = e2[0]; rf[9] = e2[1]; rf[10] = e2[2];
+                    } else {
+                        const float c3[3] = {rf[0], rf[1], rf[2]};
+                        sphere_world_bounds(c3, rf[4], m, ident, plo, phi);
+                    }
+                    if (finite_box(plo, phi))
+                        for (int q = 0; q < 3; ++q) { lo[q] = fminf(lo[q], plo[q] - a.pad); hi[q] = fmaxf(hi[q], phi[q] + a.pad); }
+                }
+            }
+        }
+    }
+    // union over the node's eight slots
+    float nlo[3], nhi[3];
+    for (int k = 0; k < 3; ++k) {
+        float l = lo[k], h = hi[k];
+        l = fminf(l, shfl_xor_f(l, 1)); h = fmaxf(h, shfl_xor_f(h, 1));
+        l = fminf(l, shfl_xor_f(l, 2)); h = fmaxf(h, shfl_xor_f(h, 2));
+        l = fminf(l, shfl_xor_f(l, 4)); h = fmaxf(h, shfl_xor_f(h, 4));
+        nlo[k] = l; nhi[k] = h;
+    }
+    if (!live) return;
+    const bool empty_node = !(nlo[0] <= nhi[0]);
+    if (empty_node) for (int k = 0; k < 3; ++k) { nlo[k] = 0.0f; nhi[k] = 0.0f; }
+    uint8_t e[3];
+    for (int k = 0; k < 3; ++k) e[k] = node_exponent(nhi[k] - nlo[k]);
+    // this slot's quantised box
+    for (int k = 0; k < 3; ++k) {
+        uint8_t ql = 255, qh = 0;
+        if (meta != 0u && lo[k] <= hi[k]) quantise_axis(nlo[k], e[k], lo[k], hi[k], &ql, &qh);
+        nd[32 + 8 * k + slot] = ql;
+        nd[56 + 8 * k + slot] = qh;
+    }
+    if (slot == 0u) {
+        float *pf = reinterpret_cast<float *>(nd);
+        pf[0] = nlo[0]; pf[1] = nlo[1]; pf[2] = nlo[2];
+        nd[12] = e[0]; nd[13] = e[1]; nd[14] = e[2];
+        float *b = a.node_box + 6 * (size_t)node;
+        if (empty_node) { for (int k = 0; k < 3; ++k) { b[k] = INFINITY; b[3 + k] = -INFINITY; } }
+        else {
+            for (int k = 0; k < 3; ++k) { b[k] = nlo[k]; b[3 + k] = nhi[k]; }
+            const float ex = nhi[0] - nlo[0], ey = nhi[1] - nlo[1], ez = nhi[2] - nlo[2];
+            const float area = ex * ey + ey * ez + ez * ex;
+            if (a.area_sum && area < 3.0e38f) atomicAdd(a.area_sum, area);
+        }
+    }
+}
+
+void launch_refit_level(const RefitArgs &a, hipStream_t s) {
+    if (a.n_nodes == 0) return;
+    const uint32_t threads = a.n_nodes * 8u;
+    hipLaunchKernelGGL(k_refit_level, dim3((threads + 255u) / 256u), dim3(256), 0, s, a);
+}
+
+}  // namespace hrt

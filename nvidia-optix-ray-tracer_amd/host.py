@@ -115,15 +115,22 @@ class Renderer:
         n = len(insts)
         h_inst = (Instance * max(n, 1))()
         h_rec = (SbtRecord * max(n, 1))()
+        shared = {}                                        # "shape" id -> (GAS handle, normals): RendererTime.cu:116-130
         for i, it in enumerate(insts):
             handle = C.c_uint64()
             if it["geometry"] == "triangles":
-                verts = self._dev(it["vertices"].reshape(-1, 3))
-                normals = self._dev(it["normals"].reshape(-1, 3))
-                self._check(lib.hrt_blas_build_triangles(self.ctx, verts.data_ptr(), verts.shape[0], st, C.byref(handle)),
-                            "hrt_blas_build_triangles")
-                del verts                                  # the reference frees vertices after the build too
-                self._keep.append(normals)
+                key = it.get("shape")
+                if key is not None and key in shared:
+                    handle.value, normals = shared[key]
+                else:
+                    verts = self._dev(it["vertices"].reshape(-1, 3))
+                    normals = self._dev(it["normals"].reshape(-1, 3))
+                    self._check(lib.hrt_blas_build_triangles(self.ctx, verts.data_ptr(), verts.shape[0], st, C.byref(handle)),
+                                "hrt_blas_build_triangles")
+                    del verts                              # the reference frees vertices after the build too
+                    self._keep.append(normals)
+                    if key is not None:
+                        shared[key] = (handle.value, normals)
                 h_rec[i].data.ptr0 = normals.data_ptr()
                 prog = PROGRAM_TRIANGLE_ROUGH if it["material"] == "rough" else PROGRAM_TRIANGLE_METAL
             else:

@@ -199,4 +199,70 @@ def mixed_test_scene(n_triangles=2000, n_spheres=40, seed=7, width=96, height=64
             "width": width, "height": height, "spp": spp}
 
 
+def _blob_shape(subdiv, radius, seed):
+    """A closed, lumpy triangle mesh: an octahedron subdivided ``subdiv`` times, vertices pushed out to
+    ``radius`` x (1 +- 25 % noise keyed on the vertex direction) -- a stand-in for the reference's STL particles."""
+    o = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=np.float64)
+    faces = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
+    tris = np.array([[o[a], o[b], o[c]] for a, b, c in faces])
+    for _ in range(subdiv):
+        a, b, c = tris[:, 0], tris[:, 1], tris[:, 2]
+        ab, bc, ca = (a + b) / 2, (b + c) / 2, (c + a) / 2
+        tris = np.concatenate([np.stack([a, ab, ca], 1), np.stack([ab, b, bc], 1), np.stack([ca, bc, c], 1), np.stack([ab, bc, ca], 1)])
+    d = tris / np.linalg.norm(tris, axis=2, keepdims=True)
+    k = np.array([1.7, 2.3, 2.9]) + seed
+    bump = 1.0 + 0.25 * np.sin((d * k).sum(axis=2) * 3.0)
+    return (d * bump[..., None] * radius).astype(np.float32)
+
+
+def rigid_transform(position, axis, angle, scale=1.0):
+    """3x4 row-major transform: rotation by ``angle`` (radians) about ``axis``, uniform scale, then translation."""
+    axis = np.asarray(axis, dtype=np.float64)
+    axis = axis / np.linalg.norm(axis)
+    x, y, z = axis
+    c, s_ = np.cos(angle), np.sin(angle)
+    r = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s_, x * z * (1 - c) + y * s_],
+                  [y * x * (1 - c) + z * s_, c + y * y * (1 - c), y * z * (1 - c) - x * s_],
+                  [z * x * (1 - c) - y * s_, z * y * (1 - c) + x * s_, c + z * z * (1 - c)]]) * scale
+    m = np.concatenate([r, np.asarray(position, dtype=np.float64).reshape(3, 1)], axis=1)
+    return m.astype(np.float32).reshape(12)
+
+
+def particle_poses(n_particles, frame, seed=5):
+    """Transforms of the particles of ``particle_scene`` at an animation frame: a 5-wide grid 0.2 apart (the layout
+    of the reference's files/particle/*.vtk), falling along -z and tumbling, as in its Time mode."""
+    ax = uniform_f32(seed * 77 + 1, 3 * n_particles, -1.0, 1.0).reshape(n_particles, 3) + np.float32(1e-3)
+    w = uniform_f32(seed * 77 + 2, n_particles, -0.4, 0.4)
+    out = []
+    for i in range(n_particles):
+        gx, gy = i % 5, (i // 5) % 5
+        layer = i // 25
+        pos = (-0.4 + 0.2 * gx + 0.01 * np.sin(i), -0.4 + 0.2 * gy, 0.4 + 0.2 * layer - 0.02 * frame)
+        out.append(rigid_transform(pos, ax[i], float(w[i]) * frame + 0.1 * i))
+    return out
+
+
+def particle_scene(n_particles=25, width=96, height=64, spp=1, frame=0, subdiv=2, seed=5):
+    """The structure of the reference's Time-mode scenes (files/config.json, files/particle/*.vtk): particles
+    instancing a few shared shapes (``shape`` = BLAS to share, RendererTime.cu:116-130), one transform each per
+    frame, over a huge ground sphere shifted by its instance transform (quirk Q1)."""
+    shapes = [_blob_shape(subdiv, 0.06, seed), _blob_shape(max(subdiv - 1, 0), 0.05, seed + 1),
+              np.asarray(_box((-0.04, -0.04, -0.04), (0.04, 0.04, 0.04), skip_bottom=False), dtype=np.float32)]
+    albedos = [RED, WHITE, GREEN, SAND]
+    poses = particle_poses(n_particles, frame, seed)
+    inst = []
+    for i in range(n_particles):
+        sid = i % len(shapes)
+        metal = i % 4 == 3
+        it = _tri_instance(shapes[sid], STEEL if metal else albedos[i % 4], "metal" if metal else "rough", 0.1 if metal else 0.0, poses[i])
+        it["shape"] = sid
+        inst.append(it)
+    ground = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, -1000.5], dtype=np.float32)       # files/config.json:26
+    inst.append(_sphere_instance([[0, 0, 0]], [1000.0], SAND, "rough", 0.0, ground))
+    cam = {"center": np.array([2.2, 0.3, 0.9], dtype=np.float32), "target": np.array([0, 0, 0.2], dtype=np.float32),
+           "up": np.array([0, 0, 1], dtype=np.float32), "opengl": False}
+    return {"name": "particles-%d" % n_particles, "instances": inst, "camera": cam, "background": BACKGROUND.copy(),
+            "width": width, "height": height, "spp": spp}
+
+
 BASELINE_CONFIGS = {"C1": cornell_box, "C2": sphere_in_box, "C3": soup_100k, "C4": soup_1m, "C5": soup_1m_8mat}

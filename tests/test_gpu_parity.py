@@ -211,22 +211,127 @@ def test_empty_scene_and_all_miss(hrt, oracle, renderer):
     assert np.abs(renderer.color.cpu().numpy()[..., :3] - bg).max() <= 1e-6
 
 
-def test_update_instances_rebuilds(hrt, oracle, renderer):
-    """updateIAS path: move an instance, re-render, compare with the oracle on the moved scene."""
+def _download_tree(hrt, renderer):
+    import ctypes as C
+    blob = hrt.BvhBlob()
+    assert renderer.lib.hrt_tlas_download(renderer.ctx, renderer.tlas, C.byref(blob)) == 0
+    nodes = np.ctypeslib.as_array(C.cast(blob.nodes, C.POINTER(C.c_uint8)), shape=(blob.n_nodes * 80,)).copy()
+    prims = np.ctypeslib.as_array(C.cast(blob.triangles, C.POINTER(C.c_uint8)), shape=(max(blob.n_triangles, 1) * 48,)).copy()
+    renderer.lib.hrt_host_free(C.byref(blob))
+    return nodes, prims
+
+
+def _moved_scene_matches_oracle(hrt, oracle, renderer, scene, width, height, salt, spp=1):
+    renderer.set_frame(width, height, salt, linear=True)
+    renderer.render(spp)
+    osc = oracle.OracleScene(scene)
+    st = oracle.rng_init(width, height, salt)
+    ref = osc.render(width, height, st, spp)
+    assert np.array_equal(renderer.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32))
+    o, d = oracle.random_rays(20000, 31)
+    t, u, v, prim, inst = renderer.trace_rays(o, d)
+    rt, ru, rv, rprim, rinst = oracle.OracleScene(scene, force_brute=True).trace(o, d)
+    assert np.array_equal(prim, rprim) and np.array_equal(inst, rinst) and np.array_equal(t.view(np.uint32), rt.view(np.uint32))
+
+
+def test_refit_with_unchanged_transforms_reproduces_the_built_tree(hrt, renderer):
+    """updateIAS with the transforms it was built with: the device refit (same arithmetic as the host
+    flatten + quantisation) must write back the very bytes the builder produced -- nodes and records."""
+    scene = hrt.scenes.mixed_test_scene(3000, 40, 5)
+    renderer.load_scene(scene)
+    nodes0, prims0 = _download_tree(hrt, renderer)
+    before = renderer.stats()
+    renderer.update_instances([it["transform"] for it in scene["instances"]])
+    nodes1, prims1 = _download_tree(hrt, renderer)
+    after = renderer.stats()
+    assert after.tlas_refits == before.tlas_refits + 1 and after.tlas_rebuilds == before.tlas_rebuilds
+    assert np.array_equal(prims0, prims1)
+    assert np.array_equal(nodes0, nodes1)
+
+
+def test_update_instances_refit_matches_oracle(hrt, oracle, renderer):
+    """updateIAS path (RendererMesh.cu:379-401): move, rotate and scale instances, refit on the device,
+    re-render, compare with the oracle on the moved scene -- triangles and spheres (Q1/Q2 included)."""
     scene = hrt.scenes.mixed_test_scene(900, 20, 5, 64, 48, 1)
     renderer.load_scene(scene)
+    before = renderer.stats()
     moved = [it["transform"].copy() for it in scene["instances"]]
     moved[0][3] += 0.25
+    moved[1] = hrt.scenes.rigid_transform((0.1, -0.2, 0.05), (0.3, 1.0, 0.2), 0.7, 1.1)
     moved[3][7] -= 0.2
+    moved[4] = hrt.scenes.rigid_transform((-0.1, 0.1, 0.0), (0.0, 0.0, 1.0), 0.4)
     renderer.update_instances(moved)
+    after = renderer.stats()
+    assert after.tlas_refits == before.tlas_refits + 1 and after.tlas_rebuilds == before.tlas_rebuilds
     for it, m in zip(scene["instances"], moved):
         it["transform"] = m
-    renderer.set_frame(64, 48, 99, linear=True)
-    renderer.render(1)
-    osc = oracle.OracleScene(scene)
-    st = oracle.rng_init(64, 48, 99)
-    ref = osc.render(64, 48, st, 1)
-    assert np.array_equal(renderer.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32))
+    _moved_scene_matches_oracle(hrt, oracle, renderer, scene, 64, 48, 99)
+
+
+def test_update_instances_rebuild_path(hrt, oracle, monkeypatch):
+    """HRT_REFIT=0: every update rebuilds the tree on the host (the fallback when handles change)."""
+    monkeypatch.setenv("HRT_REFIT", "0")
+    r = hrt.Renderer(0, 0)
+    try:
+        scene = hrt.scenes.mixed_test_scene(900, 20, 5, 64, 48, 1)
+        r.load_scene(scene)
+        moved = [it["transform"].copy() for it in scene["instances"]]
+        moved[0][3] += 0.25
+        moved[3][7] -= 0.2
+        r.update_instances(moved)
+        s = r.stats()
+        assert s.tlas_refits == 0 and s.tlas_rebuilds == 2
+        for it, m in zip(scene["instances"], moved):
+            it["transform"] = m
+        _moved_scene_matches_oracle(hrt, oracle, r, scene, 64, 48, 99)
+    finally:
+        r.close()
+
+
+def test_particle_animation_refit_every_frame(hrt, oracle, renderer):
+    """The reference's Time mode in small: particles instancing shared shapes over the huge ground sphere,
+    new transforms every frame (RendererTime.cu:436-480), updateIAS, one launch -- each frame bit-exact
+    against the oracle on that frame's scene; the RNG streams carry over from frame to frame (Q8)."""
+    w, h, salt = 72, 48, 4242
+    scene = hrt.scenes.particle_scene(27, w, h, 1, frame=0)
+    renderer.load_scene(scene)
+    renderer.set_frame(w, h, salt, linear=True)
+    states = oracle.rng_init(w, h, salt)
+    n_p = 27
+    for frame in range(4):
+        poses = hrt.scenes.particle_poses(n_p, frame)
+        ground = scene["instances"][-1]["transform"]
+        renderer.update_instances(poses + [ground])
+        for it, m in zip(scene["instances"], poses):
+            it["transform"] = m
+        renderer.render(1)
+        ref = oracle.OracleScene(scene).render(w, h, states, 1)
+        assert np.array_equal(renderer.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32)), "frame %d" % frame
+        assert np.array_equal(renderer.rng_states_numpy(), states)
+    s = renderer.stats()
+    assert s.tlas_refits >= 4
+
+
+def test_refit_quality_guard_rebuilds(hrt, oracle, monkeypatch):
+    """A refit keeps the topology; when the instances have moved so far that the boxes' area sum passes
+    HRT_REFIT_REBUILD_RATIO x the built tree's, the next update rebuilds -- and the image is still the oracle's."""
+    monkeypatch.setenv("HRT_REFIT_REBUILD_RATIO", "1.2")
+    r = hrt.Renderer(0, 0)
+    try:
+        w, h = 64, 48
+        scene = hrt.scenes.particle_scene(12, w, h, 1, frame=0)
+        r.load_scene(scene)
+        ground = scene["instances"][-1]["transform"]
+        far = [hrt.scenes.rigid_transform((0.9 * np.cos(i), 0.9 * np.sin(i), 0.3 + 0.05 * i), (0, 0, 1), 0.3 * i) for i in range(12)]
+        r.update_instances(far + [ground])           # refit, boxes grow a lot
+        r.update_instances(far + [ground])           # sees the degraded tree -> rebuild
+        s = r.stats()
+        assert s.tlas_refits == 1 and s.tlas_rebuilds == 2
+        for it, m in zip(scene["instances"], far):
+            it["transform"] = m
+        _moved_scene_matches_oracle(hrt, oracle, r, scene, w, h, 7)
+    finally:
+        r.close()
 
 
 def test_full_size_properties_1080p(hrt, renderer):
@@ -274,6 +379,7 @@ MODES = {
     "wavefront-lds-dma-gather": {"HRT_FUSED": "0", "HRT_LDS_GATHER": "1"},
     "wavefront-substreams": {"HRT_FUSED": "0", "HRT_SUBSTREAMS": "3", "HRT_SUBSTREAM_MIN_PIXELS": "1024"},
     "wavefront-no-tail-split-small-slices": {"HRT_FUSED": "0", "HRT_TAIL_SPLIT": "0", "HRT_FETCH_CHUNK": "16", "HRT_REFILL_THRESHOLD": "4"},
+    "fused-two-samples-per-launch": {"HRT_FUSED_MAX_SPP": "2"},
     "fused-small-slices": {"HRT_FETCH_CHUNK": "16", "HRT_REFILL_THRESHOLD": "4", "HRT_TRAVERSE_BLOCKS_PER_CU": "3"},
     "aligned-records": {"HRT_NODE_STRIDE": "128", "HRT_PRIM_STRIDE": "64"},
 }

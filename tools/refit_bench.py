@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Per-frame updateIAS cost: device refit (hrt_tlas_update) vs a host rebuild, on one MI355X.
+
+Prints one JSON line per scene: wall time of hrt_tlas_update, the refit kernels' HIP-event time, the
+algorithmic bytes they move (per node 80 B read + 80 B written + 24 B box written + 24 B box read by the
+parent; per triangle 36 B source + 48 B record written) and the resulting GB/s against the 8 TB/s HBM peak.
+Usage: python tools/refit_bench.py [--frames 20]"""
+import argparse, importlib, json, os, sys, time
+from pathlib import Path
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+hrt = importlib.import_module("nvidia-optix-ray-tracer_amd")
+
+
+def run(name, scene, poses_of, frames, refit):
+    os.environ["HRT_REFIT"] = "1" if refit else "0"
+    import torch
+    r = hrt.Renderer(0, hrt.CTX_TIMING)
+    r.load_scene(scene)
+    s0 = r.stats(reset=True)
+    n_nodes, n_tris = s0.bvh_nodes, s0.bvh_triangles
+    r.update_instances(poses_of(0))                         # warm-up
+    torch.cuda.synchronize()
+    r.reset_stats()
+    t0 = time.perf_counter()
+    for f in range(1, frames + 1):
+        r.update_instances(poses_of(f))
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3 / frames
+    s = r.stats()
+    out = {"scene": name, "mode": "refit" if refit else "rebuild", "instances": len(scene["instances"]),
+           "bvh_nodes": int(n_nodes), "triangles": int(n_tris), "frames": frames, "update_wall_ms": round(wall_ms, 4),
+           "tlas_refits": int(s.tlas_refits), "tlas_rebuilds": int(s.tlas_rebuilds)}
+    if refit and s.kernel_launches[hrt.K_REFIT]:
+        k_ms = s.kernel_ms[hrt.K_REFIT] / s.kernel_launches[hrt.K_REFIT]
+        bytes_ = n_nodes * (80 + 80 + 24 + 24) + n_tris * (36 + 48)
+        out.update({"refit_kernels_ms": round(k_ms, 4), "algorithmic_bytes": int(bytes_),
+                    "achieved_GBps": round(bytes_ / (k_ms * 1e-3) / 1e9, 1), "hbm_peak_GBps": 8000})
+    r.close()
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=20)
+    a = ap.parse_args()
+    # the reference's Time-mode structure: particles instancing shared shapes + ground sphere
+    for n_p, sub in ((25, 2), (2000, 3)):
+        sc = hrt.scenes.particle_scene(n_p, 1200, 800, 1, 0, subdiv=sub)
+        ground = sc["instances"][-1]["transform"]
+        poses = lambda f, n_p=n_p, ground=ground: hrt.scenes.particle_poses(n_p, f) + [ground]   # noqa: E731
+        cache = {}
+        cached = lambda f, poses=poses, cache=cache: cache.setdefault(f, poses(f))               # noqa: E731
+        for f in range(a.frames + 1):
+            cached(f)
+        run("particles-%d" % n_p, sc, cached, a.frames, True)
+        run("particles-%d" % n_p, sc, cached, min(a.frames, 5), False)
+    # one big static instance that moves as a whole (C4 geometry)
+    sc = hrt.scenes.soup_1m(1920, 1080, 1)
+    base = sc["instances"][0]["transform"]
+    def poses(f, base=base):
+        m = base.copy(); m[3] += 0.01 * f
+        return [m]
+    run("soup-1m", sc, poses, a.frames, True)
+    run("soup-1m", sc, poses, 1, False)
+
+
+if __name__ == "__main__":
+    main()
