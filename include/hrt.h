@@ -124,6 +124,7 @@ typedef struct HrtStats {
     uint64_t debug[4];                     /* HRT_CTX_COUNT, closest-hit kernel: wave iterations, wave leaf passes,
                                               sum of alive lanes over iterations, reserved                     */
     uint64_t tlas_refits, tlas_rebuilds;   /* hrt_tlas_update calls served by the device refit / builds + rebuilds    */
+    double   tlas_refit_ratio;             /* quality sum of the last refitted tree checked / that of the built tree  */
 } HrtStats;
 
 int  hrt_stats_reset(HrtContext *ctx);

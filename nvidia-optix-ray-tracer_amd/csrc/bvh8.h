@@ -61,7 +61,7 @@ struct Bvh8 {
     std::vector<uint32_t>   level_begin;
     std::vector<float>      node_box;      // 6 floats per node: union of the padded primitive boxes below it
     float pad = 0.0f;                      // what was added around every primitive box
-    double area_sum = 0.0;                 // sum of the nodes' half areas (refit quality baseline)
+    std::vector<float>      node_ref;      // 2 floats per node: {primitives-below weight (sums to 1), 1 / half area as built}
 };
 
 // Deterministic host build (binned SAH BVH2 -> greedy collapse to 8-wide -> octant slot

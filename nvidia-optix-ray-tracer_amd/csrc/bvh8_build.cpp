@@ -320,10 +320,6 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
         if (out.level_begin.size() <= it.depth) out.level_begin.push_back(self);
         for (int a = 0; a < 3; ++a) out.node_box.push_back(bn.lo[a]);
         for (int a = 0; a < 3; ++a) out.node_box.push_back(bn.hi[a]);
-        {
-            const double ex = (double)bn.hi[0] - bn.lo[0], ey = (double)bn.hi[1] - bn.lo[1], ez = (double)bn.hi[2] - bn.lo[2];
-            out.area_sum += ex * ey + ey * ez + ez * ex;
-        }
         nd.child_base = (uint32_t)queue.size();
         nd.prim_base = (uint32_t)out.prims.size();
         uint32_t prim_off = 0;
@@ -355,6 +351,28 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
         out.nodes[self] = nd;
     }
     out.level_begin.push_back((uint32_t)out.nodes.size());
+
+    // refit quality reference: per node {weight, 1 / built half area}; weight = primitives below the node,
+    // normalised so that the weighted mean of area_now / area_built is 1 for the tree as built (refit.hip)
+    const size_t nn = out.nodes.size();
+    std::vector<double> below(nn, 0.0);
+    double total = 0.0;
+    for (size_t i = nn; i-- > 0;) {
+        const Bvh8Node &nd = out.nodes[i];
+        uint32_t rank = 0;
+        for (int s = 0; s < 8; ++s) {
+            const uint8_t m = nd.meta[s];
+            if (m == 0) continue;
+            if ((nd.imask >> s) & 1u) below[i] += below[nd.child_base + rank++];
+            else { const uint32_t cb = m >> 5; below[i] += cb == 1 ? 1.0 : cb == 3 ? 2.0 : 3.0; }
+        }
+    }
+    out.node_ref.assign(2 * nn, 0.0f);
+    for (size_t i = 0; i < nn; ++i) {
+        const float ar = box_half_area(&out.node_box[6 * i], &out.node_box[6 * i + 3]);
+        if (ar > 0.0f && std::isfinite(ar)) { total += below[i]; out.node_ref[2 * i + 1] = 1.0f / ar; } else below[i] = 0.0;
+    }
+    for (size_t i = 0; i < nn; ++i) out.node_ref[2 * i] = total > 0.0 ? (float)(below[i] / total) : 0.0f;
 }
 
 // Walk the packed tree and check containment of every primitive in every ancestor slot box.

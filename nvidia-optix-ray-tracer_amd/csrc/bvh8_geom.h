@@ -53,6 +53,11 @@ HRT_HD void sphere_world_bounds(const float *c, float r, const float *m, bool id
     }
 }
 
+HRT_HD float box_half_area(const float *lo, const float *hi) {
+    const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+    return ex * ey + ey * ez + ez * ex;
+}
+
 HRT_HD bool finite_box(const float *lo, const float *hi) {
     bool ok = true;
     for (int a = 0; a < 3; ++a) ok = ok && (fabsf(lo[a]) <= 3.0e38f) && (fabsf(hi[a]) <= 3.0e38f);

@@ -130,9 +130,13 @@ struct RefitArgs {
     const uint32_t *inst_identity;
     const void *const *inst_src;   // per instance: object-space triangle vertices (9 floats per triangle) of its BLAS
     float pad;
-    float *area_sum;               // sum of the nodes' half areas (tree quality after the refit), may be NULL
+    const float *node_ref;         // 2 floats per node: {weight, 1 / half area as built}
+    float *area_sum;               // weighted mean of area now / area as built (quality after the refit), may be NULL
 };
+constexpr uint32_t kRefitTopLevels = 16, kRefitTopLevelNodes = 1024;
+struct RefitLevels { uint32_t n_levels; uint32_t begin[kRefitTopLevels + 1]; };   // levels 0 .. n_levels-1, each at most kRefitTopLevelNodes wide
 void launch_refit_level(const RefitArgs &a, hipStream_t s);
+void launch_refit_top(const RefitArgs &a, const RefitLevels &lv, hipStream_t s);
 
 // host-callable launchers (defined in kernels.hip)
 void launch_rng_init(RngState *states, uint32_t n, uint64_t salt, const uint32_t *d_jump, hipStream_t s);

@@ -53,7 +53,7 @@ struct Tlas {
     std::vector<std::shared_ptr<Blas>> blas_refs;       // keeps the source geometry alive
     std::vector<uint64_t> sig_handle; std::vector<uint32_t> sig_visibility;
     std::vector<float> h_xf, h_inv; std::vector<uint32_t> h_ident;   // staging of the per-instance uploads
-    float *d_node_box = nullptr, *d_inst_xf = nullptr, *d_area = nullptr;
+    float *d_node_box = nullptr, *d_node_ref = nullptr, *d_inst_xf = nullptr, *d_area = nullptr;
     const void **d_inst_src = nullptr;
     float *h_area = nullptr;                             // pinned: area sum of the last refit
     hipEvent_t area_ready = nullptr; bool area_pending = false;
@@ -129,8 +129,8 @@ struct HrtContext {
     int fetch_chunk = 64;
     int substream_min_pixels = 32768;
     int refit = 1;                              // hrt_tlas_update: 1 = device refit when only transforms changed, 0 = always rebuild
-    float refit_rebuild_ratio = 2.0f;           // rebuild when the refitted tree's node area sum exceeds this x the built tree's
-    uint64_t tlas_refits = 0, tlas_rebuilds = 0;
+    float refit_rebuild_ratio = 1.5f;           // rebuild when the refitted tree's weighted mean node area has grown by this factor
+    uint64_t tlas_refits = 0, tlas_rebuilds = 0; double tlas_refit_ratio = 1.0;
     int substreams = 0;                         // sub-tiles rendered on their own HIP streams so that one's tail overlaps another's bulk
     std::vector<hipStream_t> sub_streams; std::vector<hipEvent_t> sub_done; hipEvent_t ev_begin = nullptr;
 };
@@ -210,11 +210,12 @@ void free_tlas_device(Tlas &t) {
     if (t.d_inst_inv) (void)hipFree(t.d_inst_inv);
     if (t.d_inst_identity) (void)hipFree(t.d_inst_identity);
     if (t.d_node_box) (void)hipFree(t.d_node_box);
+    if (t.d_node_ref) (void)hipFree(t.d_node_ref);
     if (t.d_inst_xf) (void)hipFree(t.d_inst_xf);
     if (t.d_area) (void)hipFree(t.d_area);
     if (t.d_inst_src) (void)hipFree((void *)t.d_inst_src);
     t.d_nodes = t.d_prims = nullptr; t.d_inst_inv = nullptr; t.d_inst_identity = nullptr;
-    t.d_node_box = t.d_inst_xf = t.d_area = nullptr; t.d_inst_src = nullptr;
+    t.d_node_box = t.d_node_ref = t.d_inst_xf = t.d_area = nullptr; t.d_inst_src = nullptr;
     t.area_pending = false;
 }
 void free_tlas_host(Tlas &t) {
@@ -313,6 +314,7 @@ int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &in
     HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_identity, sizeof(uint32_t) * t.h_ident.size()));
     HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_src, sizeof(void *) * src.size()));
     HIP_TRY(ctx, hipMalloc((void **)&t.d_node_box, sizeof(float) * std::max<size_t>(t.bvh.node_box.size(), 6)));
+    HIP_TRY(ctx, hipMalloc((void **)&t.d_node_ref, sizeof(float) * std::max<size_t>(t.bvh.node_ref.size(), 2)));
     HIP_TRY(ctx, hipMalloc((void **)&t.d_area, sizeof(float)));
     if (!t.h_area) HIP_TRY(ctx, hipHostMalloc((void **)&t.h_area, sizeof(float), hipHostMallocDefault));
     if (!t.area_ready) HIP_TRY(ctx, hipEventCreateWithFlags(&t.area_ready, hipEventDisableTiming));
@@ -334,6 +336,8 @@ int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &in
     HIP_TRY(ctx, hipMemcpyAsync((void *)t.d_inst_src, src.data(), sizeof(void *) * src.size(), hipMemcpyHostToDevice, s));
     if (!t.bvh.node_box.empty())
         HIP_TRY(ctx, hipMemcpyAsync(t.d_node_box, t.bvh.node_box.data(), sizeof(float) * t.bvh.node_box.size(), hipMemcpyHostToDevice, s));
+    if (!t.bvh.node_ref.empty())
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_node_ref, t.bvh.node_ref.data(), sizeof(float) * t.bvh.node_ref.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     t.generation++;
     t.rebuilds++; ctx->tlas_rebuilds++;
@@ -418,16 +422,23 @@ int refit_tlas(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, h
     RefitArgs ra{};
     ra.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); ra.node_stride = t.node_stride;
     ra.prims = reinterpret_cast<unsigned char *>(t.d_prims); ra.prim_stride = t.prim_stride;
-    ra.node_box = t.d_node_box; ra.inst_xf = t.d_inst_xf; ra.inst_identity = t.d_inst_identity; ra.inst_src = t.d_inst_src;
+    ra.node_box = t.d_node_box; ra.node_ref = t.d_node_ref; ra.inst_xf = t.d_inst_xf; ra.inst_identity = t.d_inst_identity; ra.inst_src = t.d_inst_src;
     ra.pad = 4e-6f * std::max(1.0f, scene_scale);
     ra.area_sum = t.d_area;
     {
         Timer tm(ctx, s, HRT_K_REFIT);
         const std::vector<uint32_t> &lv = t.bvh.level_begin;
-        for (size_t l = lv.size() - 1; l-- > 0;) {
+        const size_t n_levels = lv.size() - 1;
+        // the narrow levels at the top go into one single-workgroup launch, the wide ones get a launch each
+        RefitLevels top{};
+        while (top.n_levels < kRefitTopLevels && top.n_levels < n_levels &&
+               lv[top.n_levels + 1] - lv[top.n_levels] <= kRefitTopLevelNodes) ++top.n_levels;
+        for (uint32_t l = 0; l <= top.n_levels; ++l) top.begin[l] = lv[l];
+        for (size_t l = n_levels; l-- > top.n_levels;) {
             ra.first_node = lv[l]; ra.n_nodes = lv[l + 1] - lv[l];
             launch_refit_level(ra, s);
         }
+        launch_refit_top(ra, top, s);
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(t.h_area, t.d_area, sizeof(float), hipMemcpyDeviceToHost, s));
@@ -609,7 +620,8 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
         HIP_TRY(ctx, hipEventSynchronize(t->area_ready));
         t->area_pending = false;
         // a refit keeps the topology: once the boxes have grown this much, a fresh build pays for itself
-        if (!((double)*t->h_area <= (double)ctx->refit_rebuild_ratio * t->bvh.area_sum)) same = false;
+        ctx->tlas_refit_ratio = (double)*t->h_area;
+        if (!(ctx->tlas_refit_ratio <= (double)ctx->refit_rebuild_ratio)) same = false;
     }
     if (same) {
         bool sbt_changed = false;
@@ -978,7 +990,7 @@ int hrt_stats_get(HrtContext *ctx, HrtStats *out) {
     out->paths = ctx->paths; out->node_visits = ds.nodes_closest + ds.nodes_any; out->prim_tests = ds.prims_closest + ds.prims_any;
     out->node_visits_closest = ds.nodes_closest; out->prim_tests_closest = ds.prims_closest;
     for (int k = 0; k < 4; ++k) out->debug[k] = ds.debug[k];
-    out->tlas_refits = ctx->tlas_refits; out->tlas_rebuilds = ctx->tlas_rebuilds;
+    out->tlas_refits = ctx->tlas_refits; out->tlas_rebuilds = ctx->tlas_rebuilds; out->tlas_refit_ratio = ctx->tlas_refit_ratio;
     for (int k = 0; k < HRT_K_COUNT; ++k) { out->kernel_ms[k] = ctx->kernel_ms[k]; out->kernel_launches[k] = ctx->kernel_launches[k]; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     auto it = ctx->tlas.find(ctx->last_tlas);

@@ -20,11 +20,9 @@ namespace hrt {
 
 __device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
 
-__global__ __launch_bounds__(256) void k_refit_level(RefitArgs a) {
-    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t local = tid >> 3, slot = tid & 7u;
-    const bool live = local < a.n_nodes;                       // whole 8-lane groups are live or not
-    const uint32_t node = a.first_node + (live ? local : 0u);
+// One child slot of one node; the eight lanes of a node call this together (they exchange boxes by
+// shuffles), dead groups (live == false) go through the motions without touching memory.
+__device__ __forceinline__ void refit_slot(const RefitArgs &a, uint32_t node, uint32_t slot, bool live) {
     unsigned char *nd = a.nodes + (size_t)node * a.node_stride;
     const uint32_t *ndw = reinterpret_cast<const uint32_t *>(nd);
 
@@ -95,12 +93,37 @@ __global__ __launch_bounds__(256) void k_refit_level(RefitArgs a) {
         nd[12] = e[0]; nd[13] = e[1]; nd[14] = e[2];
         float *b = a.node_box + 6 * (size_t)node;
         if (empty_node) { for (int k = 0; k < 3; ++k) { b[k] = INFINITY; b[3 + k] = -INFINITY; } }
-        else {
-            for (int k = 0; k < 3; ++k) { b[k] = nlo[k]; b[3 + k] = nhi[k]; }
-            const float ex = nhi[0] - nlo[0], ey = nhi[1] - nlo[1], ez = nhi[2] - nlo[2];
-            const float area = ex * ey + ey * ez + ez * ex;
-            if (a.area_sum && area < 3.0e38f) atomicAdd(a.area_sum, area);
+        else for (int k = 0; k < 3; ++k) { b[k] = nlo[k]; b[3 + k] = nhi[k]; }
+    }
+    // tree quality: primitives-below weighted mean of area(node now) / area(node as built); 1.0 for the built tree
+    if (a.area_sum && slot == 0u && !empty_node) {
+        const float2 ref = reinterpret_cast<const float2 *>(a.node_ref)[node];
+        const float g = box_half_area(nlo, nhi) * ref.y;
+        if (ref.x > 0.0f && g < 3.0e38f) atomicAdd(a.area_sum, ref.x * g);
+    }
+}
+
+// a wide level: one launch, eight lanes per node
+__global__ __launch_bounds__(256) void k_refit_level(RefitArgs a) {
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t local = tid >> 3;
+    const bool live = local < a.n_nodes;                       // whole 8-lane groups are live or not
+    refit_slot(a, a.first_node + (live ? local : 0u), tid & 7u, live);
+}
+
+// the narrow levels at the top of the tree (and all of a small tree): one workgroup walks them bottom-up
+// with a barrier between levels, instead of one launch per level
+__global__ __launch_bounds__(1024) void k_refit_top(RefitArgs a, RefitLevels lv) {
+    const uint32_t group = threadIdx.x >> 3, slot = threadIdx.x & 7u;
+    for (int l = (int)lv.n_levels - 1; l >= 0; --l) {
+        const uint32_t first = lv.begin[l], n = lv.begin[l + 1] - first;
+        for (uint32_t base = 0; base < n; base += 128u) {
+            const uint32_t local = base + group;
+            const bool live = local < n;
+            refit_slot(a, first + (live ? local : 0u), slot, live);
         }
+        __threadfence_block();
+        __syncthreads();                                       // the next level reads this level's node boxes
     }
 }
 
@@ -108,6 +131,11 @@ void launch_refit_level(const RefitArgs &a, hipStream_t s) {
     if (a.n_nodes == 0) return;
     const uint32_t threads = a.n_nodes * 8u;
     hipLaunchKernelGGL(k_refit_level, dim3((threads + 255u) / 256u), dim3(256), 0, s, a);
+}
+
+void launch_refit_top(const RefitArgs &a, const RefitLevels &lv, hipStream_t s) {
+    if (lv.n_levels == 0) return;
+    hipLaunchKernelGGL(k_refit_top, dim3(1), dim3(1024), 0, s, a, lv);
 }
 
 }  // namespace hrt
