@@ -25,6 +25,10 @@ $(LIBDIR)/refit.o: $(CSRC)/refit.hip $(CSRC)/device_types.h $(CSRC)/bvh8_geom.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+$(LIBDIR)/pose.o: $(CSRC)/pose.hip $(CSRC)/device_types.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 $(LIBDIR)/hrt_api.o: $(CSRC)/hrt_api.cpp $(CSRC)/device_types.h $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.h include/hrt.h include/hrt_params.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -33,7 +37,7 @@ $(LIBDIR)/bvh8_build.o: $(CSRC)/bvh8_build.cpp $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
-$(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/refit.o $(LIBDIR)/hrt_api.o $(LIBDIR)/bvh8_build.o
+$(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/bvh8_build.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -pthread
 
 oracle:

@@ -72,6 +72,14 @@ int  hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_
                      uint32_t n_instances, void *stream);
 int  hrt_tlas_destroy(HrtContext *ctx, HrtTraversable tlas);
 
+/* replaces the per-frame host loop of Time mode, src/Global/RendererTime.cu:436-472: for particle i,
+ * slerp(cur.quat, next.quat, factor) (:296-340) -> quatToEuler (:343-370) -> constructTransformMatrix(offset + shift,
+ * rotate, scale) (include/Global/DeviceFunctions.cuh:133-148), written to d_instances[first_instance + i].transform
+ * on the device -- no host loop, no H2D copy of the instance array.  Follow with hrt_tlas_update. */
+int  hrt_pose_instances(HrtContext *ctx, HrtInstance *d_instances, uint32_t first_instance, uint32_t n_particles,
+                        const HrtParticleState *d_current, const HrtParticleState *d_next,
+                        const HrtPoseParams *h_params, void *stream);
+
 /* replaces optixSbtRecordPackHeader as used at src/Global/RendererImpl.cu:514-560 */
 int  hrt_sbt_record_pack_header(HrtProgram program, void *record_header);
 /* replaces the hit-group SBT upload, src/Global/RendererMesh.cu:283-305: record i belongs

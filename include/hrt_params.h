@@ -12,6 +12,8 @@
  *   HrtSbtRecord      <- SbtRecord<HitGroupParams>  include/Global/RendererImpl.cuh:9-16 (64 B)
  *   HrtInstance       <- OptixInstance as filled at src/Global/RendererMesh.cu:131-144 (80 B)
  *   HrtRngState       <- curandState (XORWOW) as allocated at src/Global/HostFunctions.cu:133 (48 B)
+ *   HrtParticleState  <- the fields of RendererTimeParticleReference the frame loop reads,
+ *                        include/Global/RendererImpl.cuh:93-99 (48 B)
  *
  * Plain C, no HIP/torch types.  float3 is three packed floats (12 B, align 4);
  * float4 is four floats (16 B, align 16) exactly as the CUDA vector types.
@@ -120,6 +122,25 @@ typedef struct HrtTile {
     uint32_t stripe_rows, stripe_period, stripe_phase;
 } HrtTile;
 
+/* One particle of one time step: what src/Global/RendererTime.cu:436-472 reads per particle and frame.
+ * quat keeps the reference's float4 field order as loaded at src/Util/VTKReaderImpl.cpp:194-200
+ * (x,y,z,w = file components 0..3). */
+typedef struct HrtParticleState {
+    HrtFloat4 quat;
+    HrtFloat3 position;
+    HrtFloat3 velocity;
+    uint32_t  _pad[2];
+} HrtParticleState;             /* 48 B */
+
+/* Frame-loop scalars of the pose update (src/Global/RendererTime.cu:425-470). */
+typedef struct HrtPoseParams {
+    float     duration;         /* data.durations[currentFileIndex]                               */
+    uint32_t  frame;            /* frameCount                                                     */
+    uint32_t  frame_count;      /* frameCountThisFile                                             */
+    HrtFloat3 particle_offset;  /* loopData.particleOffset                                        */
+    HrtFloat3 particle_scale;   /* loopData.particleScale                                         */
+} HrtPoseParams;
+
 #ifdef __cplusplus
 }
 /* layout checks (values verified against the reference structs) */
@@ -130,6 +151,7 @@ static_assert(sizeof(HrtHitGroupParams) == 32, "HitGroupParams is 32 B");
 static_assert(sizeof(HrtSbtRecord) == 64, "SbtRecord<HitGroupParams> is 64 B");
 static_assert(sizeof(HrtInstance) == 80, "OptixInstance is 80 B");
 static_assert(sizeof(HrtRngState) == 48, "curandState is 48 B");
+static_assert(sizeof(HrtParticleState) == 48, "HrtParticleState is 48 B");
 #endif
 
 #endif /* HRT_PARAMS_H */

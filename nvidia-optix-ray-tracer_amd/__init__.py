@@ -54,6 +54,15 @@ class Instance(C.Structure):
                 ("pad", C.c_uint32 * 2)]
 
 
+class PoseParams(C.Structure):
+    """HrtPoseParams: frame-loop scalars of the Time-mode pose update (src/Global/RendererTime.cu:425-470)."""
+    _fields_ = [("duration", C.c_float), ("frame", C.c_uint32), ("frame_count", C.c_uint32),
+                ("particle_offset", C.c_float * 3), ("particle_scale", C.c_float * 3)]
+
+
+PARTICLE_STATE_FLOATS = 12      # HrtParticleState as floats: quat.xyzw, position.xyz, velocity.xyz, 2 pad
+
+
 class Tile(C.Structure):
     _fields_ = [("y_begin", C.c_uint32), ("y_end", C.c_uint32), ("stripe_rows", C.c_uint32),
                 ("stripe_period", C.c_uint32), ("stripe_phase", C.c_uint32)]
@@ -88,7 +97,7 @@ CTX_TIMING, CTX_COUNT = 1, 2
 EXPORTS = [
     "hrt_ctx_create", "hrt_ctx_destroy", "hrt_ctx_set_flags", "hrt_last_error", "hrt_version",
     "hrt_blas_build_triangles", "hrt_blas_build_spheres", "hrt_blas_destroy",
-    "hrt_tlas_build", "hrt_tlas_update", "hrt_tlas_destroy",
+    "hrt_tlas_build", "hrt_tlas_update", "hrt_tlas_destroy", "hrt_pose_instances",
     "hrt_sbt_record_pack_header", "hrt_materials_set", "hrt_miss_set",
     "hrt_rng_init", "hrt_rng_free", "hrt_render_launch", "hrt_sync", "hrt_to_rgba8",
     "hrt_stats_reset", "hrt_stats_get", "hrt_trace_rays", "hrt_debug_set_linear_output",
@@ -127,6 +136,7 @@ def load_library():
     lib.hrt_tlas_build.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]
     lib.hrt_tlas_update.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.hrt_tlas_destroy.argtypes = [C.c_void_p, C.c_uint64]
+    lib.hrt_pose_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hrt_sbt_record_pack_header.argtypes = [C.c_int, C.c_void_p]
     lib.hrt_materials_set.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     lib.hrt_miss_set.argtypes = [C.c_void_p, C.POINTER(MissParams)]

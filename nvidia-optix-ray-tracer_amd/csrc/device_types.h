@@ -138,6 +138,16 @@ struct RefitLevels { uint32_t n_levels; uint32_t begin[kRefitTopLevels + 1]; }; 
 void launch_refit_level(const RefitArgs &a, hipStream_t s);
 void launch_refit_top(const RefitArgs &a, const RefitLevels &lv, hipStream_t s);
 
+// particle pose update (pose.hip)
+struct PoseArgs {
+    void *instances;               // HrtInstance[] (80 B each, transform first)
+    uint32_t first_instance, n;
+    const float4 *current, *next;  // HrtParticleState[] as 3 float4 each
+    float duration; uint32_t frame, frame_count;
+    float offset[3], scale[3];
+};
+void launch_pose_instances(const PoseArgs &a, hipStream_t s);
+
 // host-callable launchers (defined in kernels.hip)
 void launch_rng_init(RngState *states, uint32_t n, uint64_t salt, const uint32_t *d_jump, hipStream_t s);
 void launch_generate(const GenerateArgs &a, hipStream_t s);

@@ -633,6 +633,25 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
     return build_tlas_into(ctx, *t, inst, s);
 }
 
+int hrt_pose_instances(HrtContext *ctx, HrtInstance *d_instances, uint32_t first_instance, uint32_t n_particles,
+                       const HrtParticleState *d_current, const HrtParticleState *d_next, const HrtPoseParams *h_params, void *stream) {
+    if (!ctx) return HRT_ERR_INVALID;
+    if (n_particles == 0) return HRT_OK;
+    if (!d_instances || !d_current || !d_next || !h_params) return fail(ctx, HRT_ERR_INVALID, "hrt_pose_instances: NULL argument");
+    if (h_params->frame_count == 0) return fail(ctx, HRT_ERR_INVALID, "hrt_pose_instances: frame_count is 0");
+    if ((reinterpret_cast<uintptr_t>(d_instances) & 15u) || (reinterpret_cast<uintptr_t>(d_current) & 15u) || (reinterpret_cast<uintptr_t>(d_next) & 15u))
+        return fail(ctx, HRT_ERR_INVALID, "hrt_pose_instances: arrays must be 16-byte aligned");
+    (void)hipSetDevice(ctx->device);
+    PoseArgs a{};
+    a.instances = d_instances; a.first_instance = first_instance; a.n = n_particles;
+    a.current = reinterpret_cast<const float4 *>(d_current); a.next = reinterpret_cast<const float4 *>(d_next);
+    a.duration = h_params->duration; a.frame = h_params->frame; a.frame_count = h_params->frame_count;
+    std::memcpy(a.offset, &h_params->particle_offset, 12); std::memcpy(a.scale, &h_params->particle_scale, 12);
+    launch_pose_instances(a, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return HRT_OK;
+}
+
 int hrt_tlas_destroy(HrtContext *ctx, HrtTraversable tlas) {
     if (!ctx) return HRT_ERR_INVALID;
     (void)hipSetDevice(ctx->device);

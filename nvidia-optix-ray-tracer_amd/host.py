@@ -87,6 +87,7 @@ class Renderer:
         self.ctx = ctx
         self._keep = []             # device tensors the SBT records point into
         self._blas = []
+        self._n_inst = None
         self.tlas = None
         self.states = None
         self.width = self.height = 0
@@ -160,6 +161,7 @@ class Renderer:
         self.tlas = tl.value
         self._d_inst = d_inst
         self._h_inst = h_inst
+        self._n_inst = n
         self._check(lib.hrt_materials_set(self.ctx, h_rec, n), "hrt_materials_set")
         bg = scene.get("background", np.array([0.7, 0.8, 0.9], dtype=np.float32))
         miss = MissParams(Float3(float(bg[0]), float(bg[1]), float(bg[2])))
@@ -176,6 +178,28 @@ class Renderer:
         self._d_inst.copy_(self._torch.from_numpy(np.frombuffer(bytes(self._h_inst), dtype=np.uint8).copy()))
         self._check(self.lib.hrt_tlas_update(self.ctx, self.tlas, self._d_inst.data_ptr(), len(transforms), self._stream()),
                     "hrt_tlas_update")
+
+    def pose_instances(self, current, nxt, duration, frame, frame_count, first_instance=0,
+                       offset=(0.0, 0.0, 0.0), scale=(1.0, 1.0, 1.0), update=True):
+        """Time mode's per-frame pose step on the device (src/Global/RendererTime.cu:436-480): ``current`` / ``nxt`` are
+        (n, 12) float32 particle states (quat.xyzw, position, velocity, 2 pad) of this and the next time step; writes the
+        transforms of instances [first_instance, first_instance + n) in device memory, then updateIAS."""
+        from . import PoseParams
+        cur = current if hasattr(current, "data_ptr") else self._dev(np.ascontiguousarray(current, dtype=np.float32))
+        nx = nxt if hasattr(nxt, "data_ptr") else self._dev(np.ascontiguousarray(nxt, dtype=np.float32))
+        n = cur.shape[0]
+        pp = PoseParams(float(duration), int(frame), int(frame_count),
+                        (C.c_float * 3)(*[float(x) for x in offset]), (C.c_float * 3)(*[float(x) for x in scale]))
+        self._check(self.lib.hrt_pose_instances(self.ctx, self._d_inst.data_ptr(), first_instance, n, cur.data_ptr(), nx.data_ptr(),
+                                                C.byref(pp), self._stream()), "hrt_pose_instances")
+        if update:
+            self._check(self.lib.hrt_tlas_update(self.ctx, self.tlas, self._d_inst.data_ptr(), self._n_inst,
+                                                 self._stream()), "hrt_tlas_update")
+
+    def instance_transforms(self):
+        """The transforms currently in the device instance array, (n, 12) float32."""
+        raw = self._d_inst.cpu().numpy().view(np.uint8).reshape(-1, 80)
+        return raw[: self._n_inst, :48].copy().view(np.float32).reshape(-1, 12)
 
     def set_camera(self, center, target, up, opengl=True):
         u, v, w = configure_camera(center, target, up, opengl)

@@ -242,23 +242,41 @@ def particle_poses(n_particles, frame, seed=5):
     return out
 
 
+def particle_states(n_particles, step, seed=5):
+    """(n, 12) float32 particle states of time step ``step`` in HrtParticleState layout (quat.xyzw as the four
+    file components, position, velocity, 2 pad): the 5-wide grid of files/particle/*.vtk, velocity (0, 0, -2) as in
+    that data, unit quaternions drifting from step to step."""
+    st = np.zeros((n_particles, 12), dtype=np.float32)
+    a = uniform_f32(seed * 131 + 3, 4 * n_particles, -1.0, 1.0).reshape(n_particles, 4)
+    b = uniform_f32(seed * 131 + 4, 4 * n_particles, -1.0, 1.0).reshape(n_particles, 4)
+    q = a + np.float32(0.35 * step) * b
+    q = q / np.sqrt((q.astype(np.float64) ** 2).sum(axis=1, keepdims=True))
+    st[:, 0:4] = q.astype(np.float32)
+    i = np.arange(n_particles)
+    st[:, 4] = -0.4 + 0.2 * (i % 5)
+    st[:, 5] = -0.4 + 0.2 * ((i // 5) % 5)
+    st[:, 6] = 0.4 + 0.2 * (i // 25) - 0.02 * step
+    st[:, 9] = -2.0
+    return st
+
+
 def particle_scene(n_particles=25, width=96, height=64, spp=1, frame=0, subdiv=2, seed=5):
-    """The structure of the reference's Time-mode scenes (files/config.json, files/particle/*.vtk): particles
-    instancing a few shared shapes (``shape`` = BLAS to share, RendererTime.cu:116-130), one transform each per
-    frame, over a huge ground sphere shifted by its instance transform (quirk Q1)."""
+    """The structure of the reference's Time-mode scenes (files/config.json, files/particle/*.vtk): the extra
+    geometry first (a huge ground sphere shifted by its instance transform, quirk Q1), then the particles
+    (RendererTime.cu:436: instances [addGeoCount, instanceCount)) instancing a few shared shapes (``shape`` =
+    BLAS to share, RendererTime.cu:116-130), one transform each per frame."""
     shapes = [_blob_shape(subdiv, 0.06, seed), _blob_shape(max(subdiv - 1, 0), 0.05, seed + 1),
               np.asarray(_box((-0.04, -0.04, -0.04), (0.04, 0.04, 0.04), skip_bottom=False), dtype=np.float32)]
     albedos = [RED, WHITE, GREEN, SAND]
     poses = particle_poses(n_particles, frame, seed)
-    inst = []
+    ground = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, -1000.5], dtype=np.float32)       # files/config.json:26
+    inst = [_sphere_instance([[0, 0, 0]], [1000.0], SAND, "rough", 0.0, ground)]
     for i in range(n_particles):
         sid = i % len(shapes)
         metal = i % 4 == 3
         it = _tri_instance(shapes[sid], STEEL if metal else albedos[i % 4], "metal" if metal else "rough", 0.1 if metal else 0.0, poses[i])
         it["shape"] = sid
         inst.append(it)
-    ground = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, -1000.5], dtype=np.float32)       # files/config.json:26
-    inst.append(_sphere_instance([[0, 0, 0]], [1000.0], SAND, "rough", 0.0, ground))
     cam = {"center": np.array([2.2, 0.3, 0.9], dtype=np.float32), "target": np.array([0, 0, 0.2], dtype=np.float32),
            "up": np.array([0, 0, 1], dtype=np.float32), "opengl": False}
     return {"name": "particles-%d" % n_particles, "instances": inst, "camera": cam, "background": BACKGROUND.copy(),

@@ -825,3 +825,112 @@ void oracle_bvh8_trace(const void *nodes_blob, const void *prims_blob,
     }
     if (out_counters) { out_counters[0] = tot_nodes; out_counters[1] = tot_prims; }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Time-mode pose pipeline: src/Global/RendererTime.cu:436-472 per particle --
+ * slerp :296-340, quatToEuler :343-370, constructTransformMatrix include/Global/DeviceFunctions.cuh:43-148.
+ * Float libm calls (acosf, sinf, cosf, asinf, atan2f) where the reference calls the float overloads.
+ * Reference behaviour kept: the aggregate returns of slerp fill a float4 positionally with the
+ * {w, x, y, z} expressions (so they land in .x .y .z .w), and the Z*Y*X Euler angles are composed as Rx*Ry*Rz.
+ * ------------------------------------------------------------------------------------------ */
+#define ORACLE_PI 3.1415926f                      /* PI, DeviceFunctions.cuh:19 */
+typedef struct { float x, y, z, w; } quat4;
+typedef struct { float m[4][4]; } mat4;
+
+static mat4 m4_mul(const mat4 *a, const mat4 *b) {          /* Matrix::operator*, :48-61 */
+    mat4 r;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float sum = 0.0f;
+            for (int n = 0; n < 4; ++n) sum += a->m[i][n] * b->m[n][j];
+            r.m[i][j] = sum;
+        }
+    return r;
+}
+static mat4 m4_identity(void) {
+    mat4 r; memset(&r, 0, sizeof r);
+    r.m[0][0] = r.m[1][1] = r.m[2][2] = r.m[3][3] = 1.0f;
+    return r;
+}
+static mat4 m4_rotation(float degree, int axis) {           /* constructRotateMatrix, :88-123 */
+    const float theta = degree * ORACLE_PI / 180.0f;        /* degreeToRadian :27-29 */
+    const float c = cosf(theta), s = sinf(theta);
+    mat4 r = m4_identity();
+    if (axis == 0) { r.m[1][1] = c; r.m[1][2] = -s; r.m[2][1] = s; r.m[2][2] = c; }
+    else if (axis == 1) { r.m[0][0] = c; r.m[0][2] = s; r.m[2][0] = -s; r.m[2][2] = c; }
+    else { r.m[0][0] = c; r.m[0][1] = -s; r.m[1][0] = s; r.m[1][1] = c; }
+    return r;
+}
+static quat4 pose_slerp(quat4 q1, quat4 q2, float t) {      /* RendererTime.cu:296-340 */
+    float dot = q1.w * q2.w + q1.x * q2.x + q1.y * q2.y + q1.z * q2.z;
+    if (dot < 0.0f) { q2.w = -q2.w; q2.x = -q2.x; q2.y = -q2.y; q2.z = -q2.z; dot = -dot; }
+    if (dot > 0.9995f) {
+        quat4 r = {q1.w + t * (q2.w - q1.w), q1.x + t * (q2.x - q1.x), q1.y + t * (q2.y - q1.y), q1.z + t * (q2.z - q1.z)};
+        const float mag = sqrtf(r.w * r.w + r.x * r.x + r.y * r.y + r.z * r.z);
+        if (mag > 0.0f) { r.w /= mag; r.x /= mag; r.y /= mag; r.z /= mag; }
+        return r;
+    }
+    {
+        const float theta_0 = acosf(dot);
+        const float theta = theta_0 * t;
+        const float sin_theta = sinf(theta);
+        const float sin_theta_0 = sinf(theta_0);
+        const float s0 = cosf(theta) - dot * sin_theta / sin_theta_0;
+        const float s1 = sin_theta / sin_theta_0;
+        quat4 r = {(s0 * q1.w) + (s1 * q2.w), (s0 * q1.x) + (s1 * q2.x), (s0 * q1.y) + (s1 * q2.y), (s0 * q1.z) + (s1 * q2.z)};
+        return r;
+    }
+}
+static void pose_quat_to_euler(quat4 q, float *deg) {       /* RendererTime.cu:343-370 */
+    const float sinr_cosp = 2.0f * (q.w * q.x + q.y * q.z);
+    const float cosr_cosp = 1.0f - 2.0f * (q.x * q.x + q.y * q.y);
+    const float roll = atan2f(sinr_cosp, cosr_cosp);
+    const float sinp = 2.0f * (q.w * q.y - q.z * q.x);
+    const float pitch = fabsf(sinp) >= 1.0f ? copysignf(ORACLE_PI / 2.0f, sinp) : asinf(sinp);
+    const float siny_cosp = 2.0f * (q.w * q.z + q.x * q.y);
+    const float cosy_cosp = 1.0f - 2.0f * (q.y * q.y + q.z * q.z);
+    const float yaw = atan2f(siny_cosp, cosy_cosp);
+    deg[0] = roll * 180.0f / ORACLE_PI; deg[1] = pitch * 180.0f / ORACLE_PI; deg[2] = yaw * 180.0f / ORACLE_PI;   /* radianToDegree :30-32 */
+}
+
+/* constructTransformMatrix(shift, rotate [degrees], scale) -> 12 floats, DeviceFunctions.cuh:133-148 */
+void oracle_construct_transform(const float *shift, const float *rotate_deg, const float *scale, float *out12) {
+    mat4 s = m4_identity(), sc = m4_identity();
+    s.m[0][3] = shift[0]; s.m[1][3] = shift[1]; s.m[2][3] = shift[2];
+    sc.m[0][0] = scale[0]; sc.m[1][1] = scale[1]; sc.m[2][2] = scale[2];
+    const mat4 rx = m4_rotation(rotate_deg[0], 0), ry = m4_rotation(rotate_deg[1], 1), rz = m4_rotation(rotate_deg[2], 2);
+    const mat4 rxy = m4_mul(&rx, &ry), r = m4_mul(&rxy, &rz);
+    const mat4 sr = m4_mul(&s, &r), t = m4_mul(&sr, &sc);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) out12[4 * i + j] = t.m[i][j];
+}
+
+/* quat4 in / out as 4 floats in float4 field order (x, y, z, w) */
+void oracle_slerp(const float *q1, const float *q2, float t, float *out4) {
+    const quat4 a = {q1[0], q1[1], q1[2], q1[3]}, b = {q2[0], q2[1], q2[2], q2[3]};
+    const quat4 r = pose_slerp(a, b, t);
+    out4[0] = r.x; out4[1] = r.y; out4[2] = r.z; out4[3] = r.w;
+}
+void oracle_quat_to_euler(const float *q, float *deg3) {
+    const quat4 a = {q[0], q[1], q[2], q[3]};
+    pose_quat_to_euler(a, deg3);
+}
+
+/* The frame loop body for n particles.  states: 12 floats per particle laid out as HrtParticleState
+ * {quat.xyzw, position.xyz, velocity.xyz, pad, pad}.  out: 12 floats per particle. */
+void oracle_pose_transforms(const float *current, const float *next, uint32_t n, float duration, uint32_t frame,
+                            uint32_t frame_count, const float *offset, const float *scale, float *out) {
+    const float fcount = (float)frame_count, fframe = (float)frame;
+    const float factor = frame_count > 1u ? fframe / (float)(frame_count - 1u) : 1.0f;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float *c = current + 12 * (size_t)i, *nx = next + 12 * (size_t)i;
+        float shift[3], deg[3];
+        for (int k = 0; k < 3; ++k) {
+            const float total = c[7 + k] * duration;
+            const float per_frame = total / fcount;
+            shift[k] = offset[k] + (c[4 + k] + per_frame * fframe);
+        }
+        const quat4 qc = {c[0], c[1], c[2], c[3]}, qn = {nx[0], nx[1], nx[2], nx[3]};
+        pose_quat_to_euler(pose_slerp(qc, qn, factor), deg);
+        oracle_construct_transform(shift, deg, scale, out + 12 * (size_t)i);
+    }
+}

@@ -7,6 +7,8 @@ Provenance (what each file pins):
                                XORWOW recurrence + 2^67 sub-sequence skip-ahead.  Pins the oracle's GF(2) algebra.
   reference_kat.json           the one number the reference itself yielded in this container (SURVEY.md 8c probe:
                                colorToFloat4 of the miss colour), plus struct sizes measured there.
+  pose_vectors.json            transforms of the Time-mode pose pipeline produced by oracle/oracle.c (slerp -> quatToEuler ->
+                               constructTransformMatrix) for fixed particle states; pins the oracle against drift only.
   oracle_*.npz                 images / hit records produced by oracle/oracle.c itself.  They pin the oracle
                                against drift and let the GPU tests run without re-rendering; they are NOT
                                reference outputs (the reference cannot be built or run here: "parity unpinned").
@@ -65,8 +67,23 @@ def oracle_images():
     np.savez_compressed(G / "oracle_hits_mixed.npz", t=t, u=u, v=v, prim=prim, inst=inst)
 
 
+def pose_vectors():
+    cur, nxt = hrt.scenes.particle_states(8, 0), hrt.scenes.particle_states(8, 1)
+    cases = []
+    for dur, frame, count, off, sc in ((0.5, 0, 120, (0, 0, 0), (1, 1, 1)), (0.5, 77, 120, (0, 0, 0), (1, 1, 1)),
+                                       (0.25, 119, 120, (0.5, -0.25, 1.0), (1.5, 1.5, 1.5)), (1.0, 0, 1, (0, 0, 0), (1, 2, 3))):
+        out = O.pose_transforms(cur, nxt, dur, frame, count, off, sc)
+        cases.append({"duration": dur, "frame": frame, "frame_count": count, "offset": list(off), "scale": list(sc),
+                      "transforms_hex": [int(x) for x in out.view(np.uint32).reshape(-1)]})
+    (G / "pose_vectors.json").write_text(json.dumps({
+        "source": "oracle/oracle.c: oracle_pose_transforms on nvidia-optix-ray-tracer_amd.scenes.particle_states(8, 0 / 1)",
+        "current": [[float(x) for x in row] for row in cur], "next": [[float(x) for x in row] for row in nxt],
+        "cases": cases}, indent=0))
+
+
 if __name__ == "__main__":
     rocrand_vectors()
+    pose_vectors()
     (G / "reference_kat.json").write_text(json.dumps({
         "source": "SURVEY.md 8(c): the reference's own colorToFloat4 (include/Global/DeviceFunctions.cuh:188-209) evaluated "
                   "in the survey container on the miss colour (0.7, 0.8, 0.9) of src/Global/RendererMesh.cu:262, and sizeof() "

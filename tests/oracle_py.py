@@ -51,6 +51,11 @@ def lib():
     L.oracle_color_to_uchar4.argtypes = [C.c_void_p, C.c_void_p]
     L.oracle_to_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
     L.oracle_configure_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_construct_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_slerp.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    L.oracle_quat_to_euler.argtypes = [C.c_void_p, C.c_void_p]
+    L.oracle_pose_transforms.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
     L.oracle_num_threads.restype = C.c_int
     L.oracle_set_threads.argtypes = [C.c_int]
     L.oracle_init()
@@ -148,6 +153,37 @@ class OracleScene:
             self.close()
         except Exception:
             pass
+
+
+def construct_transform(shift, rotate_deg, scale):
+    a, b, c = (np.ascontiguousarray(x, dtype=np.float32) for x in (shift, rotate_deg, scale))
+    out = np.zeros(12, np.float32)
+    lib().oracle_construct_transform(_p(a), _p(b), _p(c), _p(out))
+    return out
+
+
+def slerp(q1, q2, t):
+    a, b = np.ascontiguousarray(q1, dtype=np.float32), np.ascontiguousarray(q2, dtype=np.float32)
+    out = np.zeros(4, np.float32)
+    lib().oracle_slerp(_p(a), _p(b), float(t), _p(out))
+    return out
+
+
+def quat_to_euler(q):
+    a = np.ascontiguousarray(q, dtype=np.float32)
+    out = np.zeros(3, np.float32)
+    lib().oracle_quat_to_euler(_p(a), _p(out))
+    return out
+
+
+def pose_transforms(current, nxt, duration, frame, frame_count, offset=(0, 0, 0), scale=(1, 1, 1)):
+    """(n, 12) float32 particle states of two time steps -> (n, 12) transforms of the frame."""
+    cur = np.ascontiguousarray(current, dtype=np.float32)
+    nx = np.ascontiguousarray(nxt, dtype=np.float32)
+    off, sc = np.ascontiguousarray(offset, dtype=np.float32), np.ascontiguousarray(scale, dtype=np.float32)
+    out = np.zeros((cur.shape[0], 12), np.float32)
+    lib().oracle_pose_transforms(_p(cur), _p(nx), cur.shape[0], float(duration), int(frame), int(frame_count), _p(off), _p(sc), _p(out))
+    return out
 
 
 def rng_init(width, height, salt):

@@ -300,9 +300,9 @@ def test_particle_animation_refit_every_frame(hrt, oracle, renderer):
     n_p = 27
     for frame in range(4):
         poses = hrt.scenes.particle_poses(n_p, frame)
-        ground = scene["instances"][-1]["transform"]
-        renderer.update_instances(poses + [ground])
-        for it, m in zip(scene["instances"], poses):
+        ground = scene["instances"][0]["transform"]
+        renderer.update_instances([ground] + poses)
+        for it, m in zip(scene["instances"][1:], poses):
             it["transform"] = m
         renderer.render(1)
         ref = oracle.OracleScene(scene).render(w, h, states, 1)
@@ -310,6 +310,63 @@ def test_particle_animation_refit_every_frame(hrt, oracle, renderer):
         assert np.array_equal(renderer.rng_states_numpy(), states)
     s = renderer.stats()
     assert s.tlas_refits >= 4
+
+
+def test_pose_instances_matches_oracle(hrt, oracle, renderer):
+    """hrt_pose_instances (slerp -> quatToEuler -> constructTransformMatrix on the device, RendererTime.cu:436-472)
+    against the oracle, which calls float libm like the reference.  Bars: the translation column has no
+    transcendental in it and is bit-exact; rotation / scale entries within 1e-5 absolute (north_star's float
+    tolerance) and 2e-7 in the median: the kernel rounds double-precision sin/cos/acos/asin/atan2 once, libm's
+    float versions are within 1 ULP of that, and atan2 amplifies a 1-ULP difference by 1/cos(pitch) near the poles."""
+    n = 300
+    scene = hrt.scenes.particle_scene(n, 32, 32, 1, subdiv=0)
+    renderer.load_scene(scene)
+    cur, nxt = hrt.scenes.particle_states(n, 0), hrt.scenes.particle_states(n, 1)
+    s = np.float32(np.sqrt(0.5))
+    nxt[0, :4] = cur[0, :4]                                   # identical quaternions: normalised-lerp branch
+    nxt[1, :4] = cur[1, :4] + np.float32([1e-3, 0, -1e-3, 0])  # nearly identical
+    nxt[2, :4] = -cur[2, :4]                                  # dot < 0: negated
+    cur[3, :4] = nxt[3, :4] = np.float32([s, 0, s, 0]) * np.float32(1.0000002)   # |sinp| >= 1 after the placement shuffle
+    cur[4, :4] = nxt[4, :4] = [0, 0, 1, 0]                    # identity as quatToEuler sees it
+    identical = total = 0
+    for dur, frame, count, off, sc in ((0.5, 0, 120, (0, 0, 0), (1, 1, 1)), (0.5, 59, 120, (0, 0, 0), (1, 1, 1)),
+                                       (0.5, 119, 120, (0.1, 0.2, -0.3), (1.5, 0.5, 2.0)), (2.0, 0, 1, (0, 0, 0), (1, 1, 1))):
+        renderer.pose_instances(cur, nxt, dur, frame, count, first_instance=1, offset=off, scale=sc, update=False)
+        got = renderer.instance_transforms()
+        want = oracle.pose_transforms(cur, nxt, dur, frame, count, off, sc)
+        assert np.array_equal(got[0], scene["instances"][0]["transform"])           # the extra geometry is not touched
+        g, w = got[1:].reshape(n, 3, 4), want.reshape(n, 3, 4)
+        assert np.array_equal(g[:, :, 3].view(np.uint32), w[:, :, 3].view(np.uint32)), "translation must be bit-exact"
+        err = np.abs(g[:, :, :3] - w[:, :, :3])
+        assert err.max() <= 1e-5 and np.median(err) <= 2e-7
+        identical += int((g.view(np.uint32) == w.view(np.uint32)).sum())
+        total += g.size
+    assert identical / total > 0.8, identical / total        # measured: 85 % of the entries are the same bits
+
+
+def test_time_mode_frames_pose_refit_render(hrt, oracle, renderer):
+    """The whole Time-mode frame on the device: pose kernel -> updateIAS (refit) -> launch, several frames across two
+    time steps; every frame's image is bit-exact against the oracle rendering the scene with the transforms the
+    pose kernel produced (read back), and the RNG streams carry over (Q8)."""
+    w, h, salt, n = 72, 48, 777, 27
+    scene = hrt.scenes.particle_scene(n, w, h, 1)
+    renderer.load_scene(scene)
+    renderer.set_frame(w, h, salt, linear=True)
+    states = oracle.rng_init(w, h, salt)
+    steps = [hrt.scenes.particle_states(n, k) for k in range(3)]
+    for step in range(2):
+        for frame in (0, 3, 5):
+            renderer.pose_instances(steps[step], steps[step + 1], 0.05, frame, 6, first_instance=1)
+            renderer.render(1)
+            xf = renderer.instance_transforms()
+            want = oracle.pose_transforms(steps[step], steps[step + 1], 0.05, frame, 6)
+            assert np.abs(xf[1:] - want).max() <= 1e-5
+            for it, m in zip(scene["instances"], xf):
+                it["transform"] = m.copy()
+            ref = oracle.OracleScene(scene).render(w, h, states, 1)
+            assert np.array_equal(renderer.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32)), (step, frame)
+    assert np.array_equal(renderer.rng_states_numpy(), states)
+    assert renderer.stats().tlas_refits == 6
 
 
 def test_refit_quality_guard_rebuilds(hrt, oracle, monkeypatch):
@@ -321,13 +378,13 @@ def test_refit_quality_guard_rebuilds(hrt, oracle, monkeypatch):
         w, h = 64, 48
         scene = hrt.scenes.particle_scene(12, w, h, 1, frame=0)
         r.load_scene(scene)
-        ground = scene["instances"][-1]["transform"]
+        ground = scene["instances"][0]["transform"]
         far = [hrt.scenes.rigid_transform((0.9 * np.cos(i), 0.9 * np.sin(i), 0.3 + 0.05 * i), (0, 0, 1), 0.3 * i) for i in range(12)]
-        r.update_instances(far + [ground])           # refit, boxes grow a lot
-        r.update_instances(far + [ground])           # sees the degraded tree -> rebuild
+        r.update_instances([ground] + far)           # refit, boxes grow a lot
+        r.update_instances([ground] + far)           # sees the degraded tree -> rebuild
         s = r.stats()
         assert s.tlas_refits == 1 and s.tlas_rebuilds == 2, s.tlas_refit_ratio
-        for it, m in zip(scene["instances"], far):
+        for it, m in zip(scene["instances"][1:], far):
             it["transform"] = m
         _moved_scene_matches_oracle(hrt, oracle, r, scene, w, h, 7)
     finally:

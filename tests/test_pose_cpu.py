@@ -1,0 +1,175 @@
+"""Time-mode pose pipeline -- the oracle's restatement of slerp / quatToEuler /
+constructTransformMatrix (src/Global/RendererTime.cu:296-370, include/Global/DeviceFunctions.cuh:43-148)
+against closed forms evaluated independently in float64, its known answers, and the committed fixture.
+
+The reference cannot be built here (CUDA + OptiX headers), so these pin the restatement against the
+mathematics the reference's code states, including its two quirks: the positional aggregate returns of
+slerp (the {w,x,y,z} expressions land in .x .y .z .w) and Euler angles of a Z*Y*X rotation composed as Rx*Ry*Rz.
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+
+GOLDEN = Path(__file__).resolve().parent / "golden" / "pose_vectors.json"
+PI_F = float(np.float32(3.1415926))
+
+
+def _rot(deg, axis):
+    t = np.deg2rad(deg) * (PI_F / np.pi)          # the reference's truncated PI
+    c, s = np.cos(t), np.sin(t)
+    m = np.eye(4)
+    if axis == 0:
+        m[1, 1], m[1, 2], m[2, 1], m[2, 2] = c, -s, s, c
+    elif axis == 1:
+        m[0, 0], m[0, 2], m[2, 0], m[2, 2] = c, s, -s, c
+    else:
+        m[0, 0], m[0, 1], m[1, 0], m[1, 1] = c, -s, s, c
+    return m
+
+
+def _transform64(shift, rot, scale):
+    s = np.eye(4)
+    s[:3, 3] = shift
+    sc = np.diag([scale[0], scale[1], scale[2], 1.0])
+    return (s @ _rot(rot[0], 0) @ _rot(rot[1], 1) @ _rot(rot[2], 2) @ sc)[:3].reshape(12)
+
+
+def _slerp64(q1, q2, t):
+    """float64 slerp on fields named x,y,z,w = q[0..3]; returns the reference's placement [w', x', y', z']."""
+    q1, q2 = np.asarray(q1, np.float64), np.asarray(q2, np.float64)
+    dot = float(q1 @ q2)
+    if dot < 0:
+        q2, dot = -q2, -dot
+    if dot > 0.9995:
+        r = q1 + t * (q2 - q1)
+        r = r / np.linalg.norm(r)
+    else:
+        th0 = np.arccos(dot)
+        th = th0 * t
+        r = (np.cos(th) - dot * np.sin(th) / np.sin(th0)) * q1 + (np.sin(th) / np.sin(th0)) * q2
+    x, y, z, w = r
+    return np.array([w, x, y, z])
+
+
+def _euler64(q):
+    x, y, z, w = (float(v) for v in q)
+    roll = np.arctan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y))
+    sinp = 2 * (w * y - z * x)
+    pitch = np.copysign(PI_F / 2, sinp) if abs(sinp) >= 1 else np.arcsin(sinp)
+    yaw = np.arctan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z))
+    return np.array([roll, pitch, yaw]) * 180.0 / PI_F
+
+
+def test_construct_transform_known_answers(oracle):
+    ident = oracle.construct_transform((0, 0, 0), (0, 0, 0), (1, 1, 1))
+    assert np.array_equal(ident, np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32))
+    # the shipped ground sphere: shift only (files/config.json:26)
+    g = oracle.construct_transform((0, 0, -1000.5), (0, 0, 0), (1, 1, 1))
+    assert np.array_equal(g, np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, -1000.5], np.float32))
+    # 90 degrees about z, uniform scale 2, shift (1,2,3): x -> 2y, y -> -2x
+    m = oracle.construct_transform((1, 2, 3), (0, 0, 90), (2, 2, 2)).reshape(3, 4)
+    want = np.array([[0, -2, 0, 1], [2, 0, 0, 2], [0, 0, 2, 3]], np.float64)
+    assert np.abs(m - want).max() < 2e-7       # cos(90 deg) with PI = 3.1415926f is 2.7e-8, not 0
+    assert m[0, 0] != 0.0                      # ... and the restatement keeps that
+
+
+def test_construct_transform_matches_float64_composition(oracle):
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for _ in range(300):
+        shift = rng.uniform(-3, 3, 3)
+        rot = rng.uniform(-180, 180, 3)
+        scale = rng.uniform(0.2, 2.5, 3)
+        got = oracle.construct_transform(shift, rot, scale)
+        want = _transform64(np.float32(shift), np.float32(rot), np.float32(scale))
+        worst = max(worst, np.abs(got - want).max())
+    assert worst < 5e-6
+    # rotation order is Rx * Ry * Rz (DeviceFunctions.cuh:127-130), not Rz * Ry * Rx
+    m = oracle.construct_transform((0, 0, 0), (90, 0, 90), (1, 1, 1)).reshape(3, 4)[:, :3]
+    assert np.abs(m - (_rot(90, 0) @ _rot(90, 2))[:3, :3]).max() < 1e-6
+    assert np.abs(m - (_rot(90, 2) @ _rot(90, 0))[:3, :3]).max() > 0.5
+
+
+def test_slerp_branches_and_placement(oracle):
+    rng = np.random.default_rng(4)
+    for _ in range(300):
+        q1 = rng.normal(size=4)
+        q1 /= np.linalg.norm(q1)
+        q2 = rng.normal(size=4)
+        q2 /= np.linalg.norm(q2)
+        t = rng.uniform(0, 1)
+        got = oracle.slerp(q1, q2, t)
+        want = _slerp64(np.float32(q1), np.float32(q2), np.float32(t))
+        assert np.abs(got - want).max() < 3e-6
+        assert abs(np.linalg.norm(got.astype(np.float64)) - 1.0) < 1e-5
+    q1 = np.float32([0.1, 0.2, 0.3, 0.9273618])
+    q2 = np.float32([0.5, -0.5, 0.5, 0.5])
+    # endpoints, with the positional placement: out = [w, x, y, z] of the input
+    assert np.abs(oracle.slerp(q1, q2, 0.0) - q1[[3, 0, 1, 2]]).max() < 1e-6
+    assert np.abs(oracle.slerp(q1, q2, 1.0) - q2[[3, 0, 1, 2]]).max() < 1e-6
+    # dot < 0: the second quaternion is negated (shortest arc)
+    assert np.abs(oracle.slerp(q1, -q2, 1.0) - q2[[3, 0, 1, 2]]).max() < 1e-6
+    # nearly equal quaternions take the normalised-lerp branch (dot > 0.9995)
+    q3 = q1 + np.float32([1e-3, -1e-3, 0, 0])
+    got = oracle.slerp(q1, q3, 0.5)
+    mid = (q1.astype(np.float64) + q3) / 2
+    mid /= np.linalg.norm(mid)
+    assert np.abs(got - mid[[3, 0, 1, 2]]).max() < 1e-6
+
+
+def test_quat_to_euler_against_float64_and_pitch_clamp(oracle):
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        got = oracle.quat_to_euler(q)
+        want = _euler64(np.float32(q))
+        d = np.abs(got - want)
+        d = np.minimum(d, np.abs(d - 360.0))
+        assert d.max() < 2e-2 if abs(want[1]) > 89.0 else d.max() < 2e-3       # asin is ill-conditioned at the poles
+    # identity (w = 1): all angles zero; 90 degrees about z: yaw = 90 * (pi / PI)
+    assert np.array_equal(oracle.quat_to_euler([0, 0, 0, 1]), np.zeros(3, np.float32))
+    s = np.sqrt(0.5)
+    e = oracle.quat_to_euler([0, 0, s, s])
+    assert abs(e[2] - 90.0) < 1e-4 and abs(e[0]) < 1e-6 and abs(e[1]) < 1e-6
+    # |sinp| >= 1: pitch clamps to +-PI/2 -> 90 degrees exactly in the reference's own PI
+    e = oracle.quat_to_euler(np.float32([0, s, 0, s]) * np.float32(1.0000002))
+    assert abs(abs(e[1]) - 90.0) < 1e-5
+
+
+def test_pose_transforms_frame_loop(oracle, hrt):
+    """factor, shift and the chain slerp -> euler -> matrix, for the frame scalars of RendererTime.cu:425-470."""
+    cur = hrt.scenes.particle_states(25, 0)
+    nxt = hrt.scenes.particle_states(25, 1)
+    dur, count = 0.5, 120
+    first = oracle.pose_transforms(cur, nxt, dur, 0, count)
+    last = oracle.pose_transforms(cur, nxt, dur, count - 1, count)
+    for i in range(25):
+        for f, out in ((0, first[i]), (count - 1, last[i])):
+            q = oracle.slerp(cur[i, :4], nxt[i, :4], np.float32(f) / np.float32(count - 1))
+            rot = oracle.quat_to_euler(q)
+            shift = (cur[i, 4:7] + (cur[i, 7:10] * np.float32(dur) / np.float32(count)) * np.float32(f)).astype(np.float32)
+            assert np.array_equal(out, oracle.construct_transform(shift, rot, (1, 1, 1)))
+    # velocity (0, 0, -2) for 0.5 s: the last frame has moved by 119/120 of -1
+    assert np.allclose(last[:, 11] - first[:, 11], -1.0 * 119 / 120, atol=1e-6)
+    # offset and scale enter as in constructTransformMatrix(particleOffset + shift, rotate, particleScale)
+    moved = oracle.pose_transforms(cur, nxt, dur, 7, count, offset=(1, 2, 3), scale=(2, 2, 2))
+    plain = oracle.pose_transforms(cur, nxt, dur, 7, count)
+    assert np.allclose(moved[:, [3, 7, 11]] - plain[:, [3, 7, 11]], [1, 2, 3], atol=1e-6)
+    assert np.allclose(moved.reshape(-1, 3, 4)[:, :, :3], 2 * plain.reshape(-1, 3, 4)[:, :, :3], atol=1e-6)
+    # a single frame: factor = 1 (RendererTime.cu:449-452)
+    one = oracle.pose_transforms(cur, nxt, dur, 0, 1)
+    q = oracle.slerp(cur[0, :4], nxt[0, :4], 1.0)
+    assert np.array_equal(one[0], oracle.construct_transform(cur[0, 4:7], oracle.quat_to_euler(q), (1, 1, 1)))
+
+
+def test_pose_golden_vectors(oracle):
+    """Committed outputs of the oracle (tests/golden/make_golden.py): a change of the restatement shows up here."""
+    g = json.loads(GOLDEN.read_text())
+    cur = np.array(g["current"], np.float32)
+    nxt = np.array(g["next"], np.float32)
+    for case in g["cases"]:
+        got = oracle.pose_transforms(cur, nxt, case["duration"], case["frame"], case["frame_count"], case["offset"], case["scale"])
+        want = np.array(case["transforms_hex"], dtype=np.uint32).view(np.float32).reshape(-1, 12)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

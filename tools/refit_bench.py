@@ -64,8 +64,8 @@ def main():
     # the reference's Time-mode structure: particles instancing shared shapes + ground sphere
     for n_p, sub in ((25, 2), (2000, 3)):
         sc = hrt.scenes.particle_scene(n_p, 1200, 800, 1, 0, subdiv=sub)
-        ground = sc["instances"][-1]["transform"]
-        poses = lambda f, n_p=n_p, ground=ground: hrt.scenes.particle_poses(n_p, f) + [ground]   # noqa: E731
+        ground = sc["instances"][0]["transform"]
+        poses = lambda f, n_p=n_p, ground=ground: [ground] + hrt.scenes.particle_poses(n_p, f)   # noqa: E731
         cache = {}
         cached = lambda f, poses=poses, cache=cache: cache.setdefault(f, poses(f))               # noqa: E731
         for f in range(a.frames + 1):

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Time-mode frame loop of the reference (src/Global/RendererTime.cu:425-500) on one MI355X:
+per frame  pose kernel -> hrt_tlas_update (device refit) -> hrt_render_launch (1 spp) -> hrt_to_rgba8.
+Prints one JSON line per scene with ms per frame, frames/s and Mrays/s (window 1200x800 as files/config.json).
+Usage: python tools/time_mode_bench.py [--frames 200]"""
+import argparse, importlib, json, sys, time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+hrt = importlib.import_module("nvidia-optix-ray-tracer_amd")
+
+
+def run(n_particles, subdiv, frames, w=1200, h=800):
+    import torch
+    scene = hrt.scenes.particle_scene(n_particles, w, h, 1, subdiv=subdiv)
+    r = hrt.Renderer(0, 0)
+    r.load_scene(scene)
+    r.set_frame(w, h, hrt.scenes.SEED_SALT, aov=False)
+    cur = r._dev(hrt.scenes.particle_states(n_particles, 0))
+    nxt = r._dev(hrt.scenes.particle_states(n_particles, 1))
+
+    def frame(f):
+        r.pose_instances(cur, nxt, 0.5, f, frames, first_instance=1)
+        r.render(1, sync=True)                       # the reference synchronises after every launch (:500)
+        r.to_rgba8()
+
+    for f in range(3):
+        frame(f)
+    torch.cuda.synchronize()
+    r.reset_stats()
+    t0 = time.perf_counter()
+    for f in range(frames):
+        frame(f)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    s = r.stats()
+    print(json.dumps({"scene": scene["name"], "window": [w, h], "triangles": int(s.bvh_triangles), "frames": frames,
+                      "ms_per_frame": round(dt * 1e3 / frames, 4), "fps": round(frames / dt, 1),
+                      "Mrays_per_s": round(s.rays / dt / 1e6, 1), "rays_per_frame": int(s.rays // frames),
+                      "tlas_refits": int(s.tlas_refits), "tlas_rebuilds": int(s.tlas_rebuilds)}), flush=True)
+    r.close()
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=200)
+    a = ap.parse_args()
+    run(25, 2, a.frames)
+    run(2000, 3, a.frames)
