@@ -15,7 +15,7 @@ CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) -Wall -pt
 
 all: lib oracle tools
 
-lib: $(LIBDIR)/libhrt.so
+lib: $(LIBDIR)/libhrt.so $(LIBDIR)/libhrt_io.so
 
 $(LIBDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/device_types.h
 	@mkdir -p $(LIBDIR)
@@ -39,6 +39,11 @@ $(LIBDIR)/bvh8_build.o: $(CSRC)/bvh8_build.cpp $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.
 
 $(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/bvh8_build.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -pthread
+
+# host-side readers of the reference's input formats (include/hrt_io.h): plain C++, no GPU
+$(LIBDIR)/libhrt_io.so: $(CSRC)/host/scene_io.cpp $(CSRC)/host/json_min.hpp include/hrt_io.h include/hrt_params.h
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -shared -o $@ $<
 
 oracle:
 	$(MAKE) -C oracle

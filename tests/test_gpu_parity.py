@@ -369,6 +369,41 @@ def test_time_mode_frames_pose_refit_render(hrt, oracle, renderer):
     assert renderer.stats().tlas_refits == 6
 
 
+def test_real_data_time_mode_frames(hrt, oracle, renderer):
+    """The reference's shipped sample (tests/golden/files: config.json, STL shapes, particle VTK steps, series) through
+    the whole chain: readers -> scene as RendererTime::commitRendererData assembles it -> per frame pose kernel,
+    updateIAS (refit), launch.  Window reduced to 300x200 (config: 1200x800) so the scalar oracle finishes in seconds;
+    every frame bit-exact against the oracle rendering with the transforms the pose kernel produced."""
+    import importlib
+    from pathlib import Path
+    io = importlib.import_module("nvidia-optix-ray-tracer_amd.io")
+    tm = io.time_mode_scene(Path(__file__).resolve().parent / "golden" / "files" / "config.json", width=300, height=200)
+    scene, cfg = tm["scene"], tm["config"]
+    w, h, salt = 300, 200, hrt.scenes.SEED_SALT
+    renderer.load_scene(scene)
+    renderer.set_frame(w, h, salt, linear=True)
+    states = oracle.rng_init(w, h, salt)
+    hits = 0
+    for file_index, frame in ((0, 0), (0, 8), (1, 4)):
+        cur = tm["states"][file_index]
+        nxt = tm["states"][min(file_index + 1, len(tm["states"]) - 1)]            # RendererTime.cu:443-447
+        renderer.pose_instances(cur, nxt, float(tm["durations"][file_index]), frame, tm["frame_counts"][file_index],
+                                first_instance=tm["n_extra"], offset=cfg["particle-shift"], scale=cfg["particle-scale"])
+        renderer.render(1)
+        xf = renderer.instance_transforms()
+        want = oracle.pose_transforms(cur, nxt, float(tm["durations"][file_index]), frame, tm["frame_counts"][file_index],
+                                      cfg["particle-shift"], cfg["particle-scale"])
+        assert np.abs(xf[1:] - want).max() <= 1e-5
+        assert np.array_equal(xf[0], scene["instances"][0]["transform"])
+        for it, m in zip(scene["instances"], xf):
+            it["transform"] = m.copy()
+        ref = oracle.OracleScene(scene).render(w, h, states, 1)
+        assert np.array_equal(renderer.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32)), (file_index, frame)
+        hits += int(ref["rays"]) - w * h
+    assert hits > w * h // 2                                   # the ground sphere fills the lower half of the frame
+    assert np.array_equal(renderer.rng_states_numpy(), states)
+
+
 def test_refit_quality_guard_rebuilds(hrt, oracle, monkeypatch):
     """A refit keeps the topology; when the instances have moved so far that the boxes' area sum passes
     HRT_REFIT_REBUILD_RATIO x the built tree's, the next update rebuilds -- and the image is still the oracle's."""

@@ -1,0 +1,212 @@
+"""Host-side readers of the reference's input formats (include/hrt_io.h) on the reference's
+own shipped sample data (tests/golden/files/: config.json, STL shapes, particle VTK time steps, series file)."""
+import ctypes as C
+import importlib
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+FILES = ROOT / "tests" / "golden" / "files"
+
+
+@pytest.fixture(scope="module")
+def io(hrt):
+    return importlib.import_module("nvidia-optix-ray-tracer_amd.io")
+
+
+def test_io_library_exports_every_declared_symbol(io):
+    header = (ROOT / "include" / "hrt_io.h").read_text()
+    declared = sorted(set(re.findall(r"\b(hrt_io_[a-z0-9_]+)\s*\(", header)))
+    assert declared == sorted(io.IO_EXPORTS)
+    for name in declared:
+        assert hasattr(io.lib(), name)
+    assert C.sizeof(io.IoSphere) == 80
+
+
+def test_stl_shapes(io):
+    counts = []
+    for k in range(8):
+        m = io.read_stl(FILES / "shape" / "separated" / ("shape_%010d.stl" % k))
+        v, n, fn = m["vertices"], m["normals"], m["file_normals"]
+        counts.append(len(v))
+        assert v.dtype == np.float32 and v.shape[1:] == (3, 3) and n.shape == v.shape and fn.shape == (len(v), 3)
+        # per-vertex layout: the facet's unit geometric normal three times (what Shader.cu:140-142 indexes)
+        assert np.array_equal(n[:, 0], n[:, 1]) and np.array_equal(n[:, 0], n[:, 2])
+        assert np.abs(np.linalg.norm(n[:, 0].astype(np.float64), axis=1) - 1).max() < 1e-6
+        # the winding normal agrees with the normal the file states (to its 6 printed digits)
+        assert np.abs(n[:, 0] - fn).max() < 1e-4        # vertices are printed with 6 digits, so is the stated normal
+    assert counts == [252, 396, 2, 2, 2, 2, 2, 2]
+    # the two particle shapes are closed surfaces: every undirected edge belongs to exactly two triangles, and the
+    # normals point away from the centroid (star-shaped bodies)
+    for k in (0, 1):
+        m = io.read_stl(FILES / "shape" / "separated" / ("shape_%010d.stl" % k))
+        v = m["vertices"]
+        edges = {}
+        for t in v:
+            for a, b in ((0, 1), (1, 2), (2, 0)):
+                key = tuple(sorted((tuple(t[a]), tuple(t[b]))))
+                edges[key] = edges.get(key, 0) + 1
+        assert set(edges.values()) == {2}
+        c = v.reshape(-1, 3).mean(axis=0)
+        assert (((v.mean(axis=1) - c) * m["normals"][:, 0]).sum(axis=1) > 0).all()
+    # first vertex of the first file, as float(strtod(...))
+    m0 = io.read_stl(FILES / "shape" / "separated" / "shape_0000000000.stl")
+    assert np.array_equal(m0["vertices"][0, 0], np.float32([0.0240016, 0.0302721, -0.0297948]))
+
+
+def test_stl_errors(io, tmp_path):
+    with pytest.raises(io.IoError, match="cannot open"):
+        io.read_stl(tmp_path / "missing.stl")
+    bad = tmp_path / "bad.stl"
+    bad.write_text("solid x\nfacet normal 0 0 1\nouter loop\nvertex 0 0 0\nvertex 1 0 0\nendloop\nendfacet\nendsolid x\n")
+    with pytest.raises(io.IoError, match="bad vertex"):
+        io.read_stl(bad)
+    empty = tmp_path / "empty.stl"
+    empty.write_text("solid x\nendsolid x\n")
+    assert len(io.read_stl(empty)["vertices"]) == 0
+
+
+def test_particle_vtk(io):
+    steps = [io.read_particle_vtk(FILES / "particle" / ("particle_%015d.vtk" % k)) for k in (0, 100, 200)]
+    for s in steps:
+        st = s["states"]
+        assert st.shape == (25, 12) and st.dtype == np.float32
+        assert np.array_equal(s["ids"], np.arange(25, dtype=np.uint64))
+        assert set(s["shape_ids"].tolist()) <= {0, 1}
+        assert np.abs(np.linalg.norm(st[:, :4].astype(np.float64), axis=1) - 1).max() < 1e-5      # unit quaternions
+        assert not st[:, 10:].any()
+    s0 = steps[0]["states"]
+    # first record of the file: quat components in file order, position, velocity (0, 0, -2)
+    assert np.array_equal(s0[0, :4], np.float32([0.987695, 0.113077, 0.0865597, 0.064658]))
+    assert np.array_equal(s0[0, 4:7], np.float32([-0.403633, -0.403633, 0.396367]))
+    assert np.array_equal(s0[:, 7:10], np.tile(np.float32([0, 0, -2]), (25, 1)))
+    assert np.array_equal(steps[0]["shape_ids"][:5], [0, 1, 0, 1, 1])
+    # the particles fall: z decreases from step to step by about v * dt = 0.02
+    dz = steps[1]["states"][:, 6] - s0[:, 6]
+    assert (dz < 0).all() and np.abs(dz + 0.02).max() < 5e-3
+
+
+def test_particle_vtk_errors(io, tmp_path):
+    src = (FILES / "particle" / "particle_000000000000000.vtk").read_text()
+    cut = tmp_path / "cut.vtk"
+    cut.write_text(src[: len(src) // 3])
+    with pytest.raises(io.IoError):
+        io.read_particle_vtk(cut)
+    noquat = tmp_path / "noquat.vtk"
+    noquat.write_text(src.replace("SCALARS quat double 4", "SCALARS tauq double 4"))
+    with pytest.raises(io.IoError, match="quat"):
+        io.read_particle_vtk(noquat)
+    binary = tmp_path / "bin.vtk"
+    binary.write_text(src.replace("ASCII", "BINARY", 1))
+    with pytest.raises(io.IoError, match="ASCII"):
+        io.read_particle_vtk(binary)
+
+
+def test_series_durations(io, tmp_path):
+    files, dur = io.read_series(str(FILES) + "/", "particle.vtk.series")
+    assert [Path(f).name for f in files] == ["particle_%015d.vtk" % k for k in (0, 100, 200)]
+    assert all(f.startswith(str(FILES) + "/particle/") for f in files)
+    t = np.float32([0.0, 1e-2, 2e-2])
+    assert np.array_equal(dur, np.float32([t[1] - t[0], t[2] - t[1], t[2] - t[1]]))     # the last one repeats (VTKTimeReader.cu:80-81)
+    one = tmp_path / "one.series"
+    one.write_text(json.dumps({"file-series-version": "1.0", "files": [{"name": "a.vtk", "time": 3.5}]}))
+    files, dur = io.read_series(str(tmp_path) + "/", "one.series")
+    assert files == [str(tmp_path) + "/a.vtk"] and np.array_equal(dur, np.float32([1000.0]))
+    bad = tmp_path / "bad.series"
+    bad.write_text('{"file-series-version": "1.0", "files": 3}')
+    with pytest.raises(io.IoError, match="files"):
+        io.read_series(str(tmp_path) + "/", "bad.series")
+
+
+def test_color_ramp(io):
+    r = io.bake_color_ramp("terrain", 25)
+    assert r.shape == (25, 3)
+    assert np.array_equal(r[0], np.float32([0.149, 0.149, 0.149])) and np.array_equal(r[24], np.float32([0.996, 0.922, 0.545]))
+    # u = 12/24 = 0.5 is a stop: lower + (upper - lower) * 1
+    lo, hi = np.float32([0.114, 0.451, 0.208]), np.float32([0.639, 0.784, 0.325])
+    assert np.array_equal(r[12], lo + (hi - lo) * np.float32(1.0))
+    # between stops: plain float32 lerp with t = (u - p0) / (p1 - p0)
+    u = np.float32(7) / np.float32(24)
+    t = (u - np.float32(0.25)) / (np.float32(0.5) - np.float32(0.25))
+    assert np.array_equal(r[7], lo + (hi - lo) * t)
+    assert np.array_equal(io.bake_color_ramp("TeRRain", 25), r)                         # case-insensitive
+    assert np.array_equal(io.bake_color_ramp("no-such-preset", 5), io.bake_color_ramp("viridis", 5))
+    assert np.array_equal(io.bake_color_ramp("grayscale", 1), np.float32([[0.95, 0.95, 0.95]]))   # count 1: the last stop
+    assert io.bake_color_ramp("plasma", 0).shape == (0, 3)
+    g = io.bake_color_ramp("grayscale", 11)
+    assert np.allclose(g[:, 0], np.linspace(0.05, 0.95, 11), atol=1e-6)
+
+
+def test_construct_transform_equals_oracle(io, oracle):
+    rng = np.random.default_rng(8)
+    for _ in range(100):
+        s, r, c = rng.uniform(-3, 3, 3), rng.uniform(-180, 180, 3), rng.uniform(0.2, 2, 3)
+        assert np.array_equal(io.construct_transform(s, r, c).view(np.uint32), oracle.construct_transform(s, r, c).view(np.uint32))
+
+
+def test_config(io, tmp_path):
+    c = io.load_config(FILES / "config.json")
+    assert c["mesh"] is False and c["api"] == "VK" and c["opengl"] is False and c["window"] == (1200, 800)
+    assert c["series-name"] == "particle.vtk.series" and c["stl-path"] == "../files/shape/separated/"
+    assert c["particle-material-preset"] == "terrain" and c["fps"] == 240 and c["render-speed-ratio"] == 4
+    assert np.array_equal(c["roughs"], np.float32([[0.65, 0.05, 0.05], [0.73, 0.73, 0.73], [0.12, 0.45, 0.15], [0.70, 0.60, 0.50]]))
+    assert np.array_equal(c["metals"], np.float32([[0.8, 0.85, 0.88, 0.0]]))
+    assert len(c["spheres"]) == 1
+    s = c["spheres"][0]
+    assert s["radius"] == 1000.0 and not s["metal"] and s["material_index"] == 3
+    assert np.array_equal(s["transform"], np.float32([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, -1000.5]))
+    assert np.array_equal(c["camera-center"], np.float32([5, 0, 0])) and np.array_equal(c["up-direction"], np.float32([0, 0, 1]))
+    src = json.loads((FILES / "config.json").read_text())
+    for api, msg in (("D3D12", "Windows"), ("Metal", "Invalid api")):
+        src["loop-data"]["api"] = api
+        p = tmp_path / "c.json"
+        p.write_text(json.dumps(src))
+        with pytest.raises(io.IoError, match=msg):
+            io.load_config(p)
+    src["loop-data"]["api"] = "OGL"
+    del src["stl-path"]
+    p.write_text(json.dumps(src))
+    with pytest.raises(io.IoError, match="stl-path"):
+        io.load_config(p)
+    p.write_text("{ not json")
+    with pytest.raises(io.IoError, match="parse error"):
+        io.load_config(p)
+
+
+def test_mesh_cache_round_trip_and_layout(io, tmp_path):
+    """particleN.cache (VTKMeshReader.cuh:15-23): [u64 n] { [u64 id] [float3 vel] [u64 vertices] [float3 xN] [float3 xN] }."""
+    shapes = [io.read_stl(FILES / "shape" / "separated" / ("shape_%010d.stl" % k)) for k in (0, 2)]
+    parts = [{"id": 7, "velocity": np.float32([0, 0, -2]), "vertices": shapes[0]["vertices"], "normals": shapes[0]["normals"]},
+             {"id": 3, "velocity": np.float32([1, 2, 3]), "vertices": shapes[1]["vertices"], "normals": shapes[1]["normals"]},
+             {"id": 9, "velocity": np.float32([0, 0, 0]), "vertices": np.zeros((0, 3, 3), np.float32), "normals": np.zeros((0, 3, 3), np.float32)}]
+    path = tmp_path / "particle0.cache"
+    io.write_mesh_cache(path, parts)
+    raw = path.read_bytes()
+    assert len(raw) == 8 + sum(8 + 12 + 8 + 2 * 36 * len(p["vertices"]) for p in parts)
+    assert int.from_bytes(raw[:8], "little") == 3 and int.from_bytes(raw[8:16], "little") == 7
+    assert np.array_equal(np.frombuffer(raw[16:28], np.float32), [0, 0, -2])
+    assert int.from_bytes(raw[28:36], "little") == 3 * 252
+    assert np.array_equal(np.frombuffer(raw[36:36 + 36], np.float32).reshape(3, 3), shapes[0]["vertices"][0])
+    back = io.read_mesh_cache(path)
+    assert [p["id"] for p in back] == [7, 3, 9]
+    for a, b in zip(parts, back):
+        assert np.array_equal(a["vertices"], b["vertices"]) and np.array_equal(a["normals"], b["normals"]) and np.array_equal(a["velocity"], b["velocity"])
+    (tmp_path / "short.cache").write_bytes(raw[: len(raw) // 2])
+    with pytest.raises(io.IoError, match="truncated"):
+        io.read_mesh_cache(tmp_path / "short.cache")
+
+
+def test_time_mode_scene_assembly(io):
+    """RendererTime::commitRendererData in small: extra sphere first, then the particles of file 0 sharing shapes."""
+    tm = io.time_mode_scene(FILES / "config.json")
+    sc = tm["scene"]
+    assert len(sc["instances"]) == 26 and tm["n_extra"] == 1
+    assert sc["instances"][0]["geometry"] == "spheres" and np.array_equal(sc["instances"][0]["albedo"], np.float32([0.70, 0.60, 0.50]))
+    assert [it["shape"] for it in sc["instances"][1:6]] == [0, 1, 0, 1, 1]
+    assert all(np.array_equal(it["albedo"], tm["ramp"][i]) for i, it in enumerate(sc["instances"][1:]))
+    assert tm["frame_counts"] == [9, 9, 9]                     # size_t(0.01f * float(240 * 4)), RendererTime.cu:427-428
+    assert sc["width"] == 1200 and sc["height"] == 800 and sc["camera"]["opengl"] is False
