@@ -48,10 +48,13 @@ $(LIBDIR)/libhrt_io.so: $(CSRC)/host/scene_io.cpp $(CSRC)/host/json_min.hpp incl
 oracle:
 	$(MAKE) -C oracle
 
-tools: $(LIBDIR)/hrt_render
+tools: $(LIBDIR)/hrt_render $(LIBDIR)/hrt_time_render
 
 $(LIBDIR)/hrt_render: $(CSRC)/host/hrt_render.cpp $(CSRC)/host/renderer_host.hpp $(LIBDIR)/libhrt.so
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Iinclude -I$(CSRC) -o $@ $< -L$(LIBDIR) -lhrt -Wl,-rpath,'$$ORIGIN'
+
+$(LIBDIR)/hrt_time_render: $(CSRC)/host/hrt_time_render.cpp $(CSRC)/host/renderer_host.hpp $(LIBDIR)/libhrt.so $(LIBDIR)/libhrt_io.so
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Iinclude -I$(CSRC) -o $@ $< -L$(LIBDIR) -lhrt -lhrt_io -Wl,-rpath,'$$ORIGIN'
 
 clean:
 	rm -rf $(LIBDIR)
