@@ -80,11 +80,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs for a box with fewer GPUs than ranks (never set by the driver): HRT_BENCH_BACKEND=gloo lets several
+    # ranks share a card (RCCL refuses duplicate devices), HRT_BENCH_SHARE_GPU=1 maps local ranks onto the visible cards
+    backend = os.environ.get("HRT_BENCH_BACKEND", "nccl")
+    if os.environ.get("HRT_BENCH_SHARE_GPU") == "1":
+        local_rank %= max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    def barrier():
+        if backend == "nccl":
+            dist.barrier(device_ids=[local_rank])
+        else:
+            dist.barrier()
 
     hrt = importlib.import_module("nvidia-optix-ray-tracer_amd")
     scene = hrt.scenes.BASELINE_CONFIGS[args.config]()
@@ -109,7 +123,7 @@ def main():
     def fence():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            barrier()
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
@@ -128,6 +142,8 @@ def main():
     rays = torch.tensor([float(st.rays), float(st.rays_closest), st.kernel_ms[hrt.K_TRAVERSE],
                          float(st.kernel_launches[hrt.K_TRAVERSE])], dtype=torch.float64, device=dev)
     if world > 1:
+        if backend != "nccl":
+            tt, rays = tt.cpu(), rays.cpu()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     elapsed = float(tt.item())
@@ -195,11 +211,11 @@ def main():
                          "rays_per_launch": round(rays_per_launch, 1), "launches": trav_launches},
             "kernel_ms": {hrt.KERNEL_NAMES[k]: round(st.kernel_ms[k], 3) for k in range(hrt.K_COUNT)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:             # the CPU leg is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(hrt, scene, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
     r.close()
 

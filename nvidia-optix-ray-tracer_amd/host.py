@@ -63,7 +63,14 @@ def reduce_tiles(frame, dst=0):
     own row stripes, so x + 0 is exact) into rank ``dst`` over torch.distributed (RCCL on GPUs)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM)
+        if frame.is_cuda and dist.get_backend() != "nccl":
+            # rehearsal on a box with fewer cards than ranks (gloo has no CUDA reduce): stage through the host
+            staged = frame.cpu()
+            dist.reduce(staged, dst=dst, op=dist.ReduceOp.SUM)
+            if dist.get_rank() == dst:
+                frame.copy_(staged)
+        else:
+            dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM)
     return frame
 
 
