@@ -453,6 +453,93 @@ def test_full_size_properties_1080p(hrt, renderer):
     assert np.array_equal(a, renderer.color.cpu().numpy())
 
 
+def test_full_size_c4_c5_properties(hrt, gpu_available):
+    """BASELINE configs[3] / [4] geometry at full size (1 M triangles, 1920x1080; spp reduced to 2): size-independent
+    properties with the production kernels -- determinism, 1..5 rays per path, at most one any-hit ray per path, the
+    union of 4 stripe tiles is the full frame bit for bit, and the 8-instance split of the same triangles (C5) with one
+    material gives the very image of the single instance (C4): the hit and everything after it do not depend on how
+    the triangles are grouped into instances."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    import torch
+    r = hrt.Renderer(0, 0)
+    try:
+        w, h, spp = 1920, 1080, 2
+        c4 = hrt.scenes.soup_1m(w, h, spp)
+        r.load_scene(c4)
+        r.set_frame(w, h, hrt.scenes.SEED_SALT, aov=False)
+        r.render(spp)
+        full = r.color.cpu().numpy().copy()
+        s = r.stats()
+        assert s.paths == w * h * spp and s.paths <= s.rays <= 5 * s.paths and s.rays_any <= s.paths
+        assert s.bvh_triangles == 1_000_000
+        assert np.isfinite(full).all() and (full[..., 3] == 1).all() and 0 <= full.min() and full.max() <= 1
+        r.set_frame(w, h, hrt.scenes.SEED_SALT, aov=False)
+        r.color.zero_()
+        for rank in range(4):
+            r.render(spp, tile=hrt.tile_for_rank(h, rank, 4), sync=False)
+        torch.cuda.synchronize()
+        assert np.array_equal(full, r.color.cpu().numpy())
+        # C5's instance split with C4's single material
+        c5 = hrt.scenes.soup_1m_8mat(w, h, spp)
+        assert len(c5["instances"]) == 8
+        for it in c5["instances"]:
+            it["material"], it["albedo"], it["fuzz"] = c4["instances"][0]["material"], c4["instances"][0]["albedo"], 0.0
+        r.load_scene(c5)
+        r.set_frame(w, h, hrt.scenes.SEED_SALT, aov=False)
+        r.reset_stats()
+        r.render(spp)
+        assert np.array_equal(full, r.color.cpu().numpy())
+        assert r.stats().rays == s.rays
+    finally:
+        r.close()
+
+
+def test_concurrent_blas_builds(hrt, oracle, renderer):
+    """The reference builds its GASes from several host threads, one stream each (RendererMesh.cu:98-100, 205-219):
+    hrt_blas_build_* must be safe to call concurrently on one context."""
+    import ctypes as C
+    import threading
+    import torch
+    scene = hrt.scenes.mixed_test_scene(1200, 24, 4, 64, 48, 1)
+    tri = [it for it in scene["instances"] if it["geometry"] == "triangles"]
+    handles = [[None] * 8 for _ in tri]
+    verts = [torch.from_numpy(np.ascontiguousarray(it["vertices"].reshape(-1, 3))).cuda() for it in tri]
+    streams = [torch.cuda.Stream() for _ in range(8)]
+    torch.cuda.synchronize()
+
+    def work(k):
+        for j, v in enumerate(verts):
+            hdl = C.c_uint64()
+            rc = renderer.lib.hrt_blas_build_triangles(renderer.ctx, v.data_ptr(), v.shape[0], C.c_void_p(streams[k].cuda_stream), C.byref(hdl))
+            handles[j][k] = (rc, hdl.value)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    flat = [x for row in handles for x in row]
+    assert all(rc == 0 for rc, _ in flat)
+    assert len({hd for _, hd in flat}) == len(flat), "every build returns its own handle"
+    # any of the concurrently built handles renders like a sequential build
+    renderer.load_scene(scene)
+    renderer.set_frame(64, 48, 5, linear=True)
+    renderer.render(1)
+    want = renderer.linear.cpu().numpy().copy()
+    j = 0
+    for i, it in enumerate(scene["instances"]):
+        if it["geometry"] == "triangles":
+            renderer._h_inst[i].traversableHandle = handles[j][(3 * j + 1) % 8][1]
+            j += 1
+    renderer._d_inst.copy_(torch.from_numpy(np.frombuffer(bytes(renderer._h_inst), dtype=np.uint8).copy()))
+    renderer._check(renderer.lib.hrt_tlas_update(renderer.ctx, renderer.tlas, renderer._d_inst.data_ptr(), len(scene["instances"]), renderer._stream()), "update")
+    assert renderer.stats().tlas_rebuilds == 2              # changed handles: not a refit
+    renderer.set_frame(64, 48, 5, linear=True)
+    renderer.render(1)
+    assert np.array_equal(want.view(np.uint32), renderer.linear.cpu().numpy().view(np.uint32))
+
+
 def test_errors_are_loud(hrt, renderer):
     import ctypes as C
     lib = renderer.lib
@@ -462,6 +549,26 @@ def test_errors_are_loud(hrt, renderer):
     assert len(lib.hrt_last_error(renderer.ctx)) > 0
     bad = C.c_uint64()
     assert lib.hrt_blas_build_triangles(renderer.ctx, None, 4, None, C.byref(bad)) == -1
+    assert lib.hrt_blas_build_triangles(renderer.ctx, None, 3, None, C.byref(bad)) < 0          # NULL vertices
+    assert lib.hrt_tlas_update(renderer.ctx, 0xbeef, None, 0, None) < 0 and b"TLAS" in lib.hrt_last_error(renderer.ctx)
+    assert lib.hrt_blas_destroy(renderer.ctx, 0xbeef) < 0
+    # an instance that names a handle which is not a BLAS
+    inst = hrt.Instance()
+    inst.traversableHandle = 0x7777
+    inst.visibilityMask = 1
+    import torch
+    d = torch.from_numpy(np.frombuffer(bytes(inst), dtype=np.uint8).copy()).cuda()
+    tl = C.c_uint64()
+    assert lib.hrt_tlas_build(renderer.ctx, d.data_ptr(), 1, None, C.byref(tl)) < 0 and b"BLAS" in lib.hrt_last_error(renderer.ctx)
+    # update must keep the instance count
+    scene = hrt.scenes.cornell_box(16, 16, 1)
+    renderer.load_scene(scene)
+    assert lib.hrt_tlas_update(renderer.ctx, renderer.tlas, renderer._d_inst.data_ptr(), 99, None) < 0
+    # pose: zero frame count, misaligned arrays
+    pp = hrt.PoseParams(0.5, 0, 0, (C.c_float * 3)(0, 0, 0), (C.c_float * 3)(1, 1, 1))
+    assert lib.hrt_pose_instances(renderer.ctx, renderer._d_inst.data_ptr(), 0, 1, d.data_ptr(), d.data_ptr(), C.byref(pp), None) < 0
+    pp.frame_count = 4
+    assert lib.hrt_pose_instances(renderer.ctx, renderer._d_inst.data_ptr() + 4, 0, 1, d.data_ptr(), d.data_ptr(), C.byref(pp), None) < 0
 
 
 MODES = {
