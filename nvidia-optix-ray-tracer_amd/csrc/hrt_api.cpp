@@ -119,6 +119,7 @@ struct HrtContext {
     int refill_threshold = 16;                  // wavefront mode; fused mode: fused_refill_threshold
     int fused_refill_threshold = 24, fused_fetch_chunk = 16;   // measured optimum of the fused path mode (profiles/r01_sweep_fused_*.txt)
     int traverse_blocks_per_cu = 16;            // one-wave workgroups of the traverse kernel per CU
+    bool traverse_blocks_auto = true;           // fused mode: fewer of them for small tiles (not when the env knob is set)
     int postpone_pct = 25;
     int tail_split = 1;
     int node_stride = 80, prim_stride = 64;     // bytes between records in HBM (80/48 packed; 128/64 = one cache line each)
@@ -477,7 +478,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
         hipMalloc((void **)&ctx->d_stats, sizeof(DeviceStats)) != hipSuccess ||
         hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)) != hipSuccess)
         return fail(nullptr, HRT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(hipGetLastError()));
-    if (const char *e = std::getenv("HRT_TRAVERSE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) ctx->traverse_blocks_per_cu = v; }
+    if (const char *e = std::getenv("HRT_TRAVERSE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) { ctx->traverse_blocks_per_cu = v; ctx->traverse_blocks_auto = false; } }
     if (const char *e = std::getenv("HRT_FETCH_CHUNK")) { const int v = std::atoi(e); if (v >= 8 && v <= 4096) { ctx->fetch_chunk = v; ctx->fused_fetch_chunk = v; } }
     if (const char *e = std::getenv("HRT_NODE_STRIDE")) { const int v = std::atoi(e); if (v >= 80 && v <= 256 && v % 16 == 0) ctx->node_stride = v; }
     if (const char *e = std::getenv("HRT_PRIM_STRIDE")) { const int v = std::atoi(e); if (v >= 48 && v <= 256 && v % 16 == 0) ctx->prim_stride = v; }
@@ -809,7 +810,16 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         pa.states = reinterpret_cast<RngState *>(h_params->stateArray);
         pa.hitgroups = ctx->d_hitgroups; pa.inst_program = ctx->d_inst_program; pa.accum = w.accum;
         pa.rays_closest = &ctx->d_stats->rays_closest; pa.rays_any = &ctx->d_stats->rays_any;
-        const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (n + 63u) / 64u);
+        // Waves per CU: a lane runs its pixel's samples one after the other, so a small tile (the multi-GPU split) ends
+        // with its slowest pixels; about 1.4 pixels per lane lets the lanes that drew cheap pixels take a second one
+        // while fewer waves share each SIMD (measured, profiles/r01_sweep_tile_waves.txt: 1/8 of the C4 frame takes
+        // 172 ms on 12 waves per CU, 210 ms on 16).  A full frame has many pixels per lane and keeps the maximum.
+        uint32_t blocks_per_cu = (uint32_t)ctx->traverse_blocks_per_cu;
+        if (ctx->traverse_blocks_auto) {
+            const uint32_t fit = (uint32_t)((10ull * n + 14ull * 64ull * (uint64_t)ctx->n_cu - 1ull) / (14ull * 64ull * (uint64_t)ctx->n_cu));
+            blocks_per_cu = std::min(blocks_per_cu, std::max(fit, 4u));
+        }
+        const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * blocks_per_cu, (n + 63u) / 64u);
         // very long renders are cut into launches of at most fused_max_spp samples (a launch should stay in the
         // range of seconds); the RNG states and the running sums carry over, so the result is the same bits
         for (uint32_t done_spp = 0; done_spp < spp;) {

@@ -12,7 +12,7 @@ r = hrt.Renderer(0, 0)
 r.load_scene(scene)
 W, H = 1920, 1080
 base = None
-for n in (1, 2, 4, 8):
+for n in [int(x) for x in os.environ.get("TILE_NS", "1,2,4,8").split(",")]:
     r.set_frame(W, H, hrt.scenes.SEED_SALT, aov=False)
     tile = hrt.tile_for_rank(H, 0, n) if n > 1 else None
     r.render(2, tile=tile)                       # warm-up
