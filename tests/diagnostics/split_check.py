@@ -2,7 +2,7 @@
 """Does tail splitting shorten a lone long ray?  Trace 1 / 8 / 64 copies of the longest ray of a sample."""
 import importlib, sys, ctypes as C
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np
 import oracle_py as O

@@ -3,7 +3,7 @@
 walk of the same BVH bytes) in a single wave, then at full occupancy."""
 import importlib, sys, ctypes as C
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np
 import oracle_py as O
