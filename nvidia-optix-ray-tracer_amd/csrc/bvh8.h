@@ -66,8 +66,28 @@ struct Bvh8 {
 
 // Deterministic host build (binned SAH BVH2 -> greedy collapse to 8-wide -> octant slot
 // assignment -> outward-rounded 8-bit quantisation).  threads <= 0: hardware concurrency.
-// scene_scale > 0 overrides the largest |coordinate| the padding is derived from.
-void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads = 0, float scene_scale = 0.0f);
+// scene_scale > 0 overrides the largest |coordinate| the padding is derived from; max_leaf_prims (1..3) caps the
+// primitives per leaf slot (1 for the tree over instances, whose "primitives" are whole subtrees).
+void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads = 0, float scene_scale = 0.0f,
+                uint32_t max_leaf_prims = kMaxLeafPrims);
+
+// A tree over instances: a top tree built over the instances' world boxes, whose leaf slots point at per-instance
+// copies of object-space template trees (one template per BLAS, shared by all its instances).  Only the TOPOLOGY is
+// produced here (child / primitive bases, masks, meta bytes, primitive ids): every box, origin, exponent and
+// world-space record is computed by the device refit (refit.hip), which walks the nodes bottom-up in the order
+// given by `order` / `phase_begin` (phase h = nodes of height h; children always have a smaller height).
+struct InstancedTree {
+    std::vector<Bvh8Node>   nodes;
+    std::vector<PrimRecord> prims;
+    std::vector<uint32_t>   order;         // node indices sorted by height
+    std::vector<uint32_t>   phase_begin;   // phase h = order[phase_begin[h] .. phase_begin[h+1])
+    std::vector<float>      weight;        // per node: primitives below it / sum over nodes (refit quality weights)
+    uint32_t max_depth = 0;
+    uint32_t n_triangles = 0, n_spheres = 0;
+};
+// tmpl[i]: template of instance i (NULL: the instance contributes nothing); box: 6 floats per instance (world bounds,
+// used for the top tree's topology only).
+void assemble_instanced_bvh8(const std::vector<const Bvh8 *> &tmpl, const std::vector<float> &box, InstancedTree &out);
 
 // Structural self-check used by the CPU tests: every primitive's bounds lie inside the
 // dequantised box of every ancestor slot.  Returns an empty string when consistent.

@@ -154,7 +154,8 @@ inline uint8_t unary_count(uint32_t n) { return (uint8_t)((1u << n) - 1u); }
 
 }  // namespace
 
-void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, float scene_scale) {
+void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, float scene_scale, uint32_t max_leaf_prims) {
+    max_leaf_prims = std::min(std::max(max_leaf_prims, 1u), kMaxLeafPrims);
     out = Bvh8();
     const uint32_t n = (uint32_t)prims.size();
     for (const auto &p : prims) { if (p.rec.kind == kPrimKindSphere) out.n_spheres++; else out.n_triangles++; }
@@ -193,6 +194,7 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
     if (hw < 1) hw = 1;
     B.max_par_depth = 0;
     if (const char *e = std::getenv("HRT_BVH2_SINGLE")) B.split_to_single = std::atoi(e) != 0;
+    if (max_leaf_prims < kMaxLeafPrims) B.split_to_single = true;
     while ((1 << B.max_par_depth) < hw && B.max_par_depth < 6) B.max_par_depth++;
     B.build(0, 0, n, 0);
 
@@ -211,7 +213,7 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
         Cost &cn = cost[ni];
         std::memset(&cn, 0, sizeof cn);
         const float area = half_area(bn.lo, bn.hi);
-        const float c_leaf = bn.nprims <= kMaxLeafPrims ? area * kCPrim * (float)bn.nprims : kInf;
+        const float c_leaf = bn.nprims <= max_leaf_prims ? area * kCPrim * (float)bn.nprims : kInf;
         if (bn.count > 0) {                      // BVH2 leaf
             for (int i = 1; i <= 7; ++i) cn.c[i] = c_leaf;
             cn.leaf1 = 1;
@@ -270,7 +272,7 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
 
         uint32_t ch[8]; int nch = 0;
         bool ch_leaf[8];
-        if (bn.count > 0 || (it.b2 == 0 && bn.nprims <= kMaxLeafPrims)) {
+        if (bn.count > 0 || (it.b2 == 0 && bn.nprims <= max_leaf_prims)) {
             ch[nch] = it.b2; ch_leaf[nch] = true; ++nch;         // the whole scene fits one leaf: wrap it
         } else {
             Collector col{B, cost};
@@ -373,6 +375,92 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
         if (ar > 0.0f && std::isfinite(ar)) { total += below[i]; out.node_ref[2 * i + 1] = 1.0f / ar; } else below[i] = 0.0;
     }
     for (size_t i = 0; i < nn; ++i) out.node_ref[2 * i] = total > 0.0 ? (float)(below[i] / total) : 0.0f;
+}
+
+// ---- tree over instances -------------------------------------------------------------------------------------
+void assemble_instanced_bvh8(const std::vector<const Bvh8 *> &tmpl, const std::vector<float> &box, InstancedTree &out) {
+    out = InstancedTree();
+    const uint32_t n_inst = (uint32_t)tmpl.size();
+    // the top tree: one "primitive" per contributing instance, one instance per leaf slot
+    std::vector<BuildPrim> tp;
+    std::vector<uint32_t> inst_of;
+    for (uint32_t i = 0; i < n_inst; ++i) {
+        if (!tmpl[i] || tmpl[i]->prims.empty()) continue;
+        BuildPrim bp; std::memset(&bp, 0, sizeof bp);
+        for (int a = 0; a < 3; ++a) { bp.lo[a] = box[6 * (size_t)i + a]; bp.hi[a] = box[6 * (size_t)i + 3 + a]; }
+        bp.rec.prim = (uint32_t)inst_of.size();
+        tp.push_back(bp); inst_of.push_back(i);
+    }
+    Bvh8 top;
+    build_bvh8(tp, top, 0, 0.0f, 1);
+    if (tp.empty()) { out.nodes = top.nodes; out.order = {0u}; out.phase_begin = {0u, 1u}; out.weight = {0.0f}; return; }
+
+    // Re-emit the top tree breadth first with the instance roots inside the child blocks: a node's children --
+    // top nodes and instance roots alike -- are contiguous in slot order, as the traversal expects.
+    struct Pending { uint32_t top_node; uint32_t out_index; uint32_t depth; };
+    std::vector<Pending> queue{{0u, 0u, 0u}};
+    struct RootRef { uint32_t out_index; uint32_t inst; uint32_t depth; };
+    std::vector<RootRef> roots;
+    out.nodes.emplace_back();
+    for (size_t head = 0; head < queue.size(); ++head) {
+        const Pending it = queue[head];
+        Bvh8Node nd = top.nodes[it.top_node];
+        const uint32_t child_base = (uint32_t)out.nodes.size();
+        uint32_t rank_in = 0;
+        for (int s = 0; s < 8; ++s) {
+            const uint8_t m = nd.meta[s];
+            if (m == 0) continue;
+            const uint32_t at = (uint32_t)out.nodes.size();
+            out.nodes.emplace_back();
+            if ((nd.imask >> s) & 1u) queue.push_back({top.nodes[it.top_node].child_base + rank_in++, at, it.depth + 1});
+            else {
+                const uint32_t k = top.prims[nd.prim_base + (m & 0x1fu)].prim;       // one instance per leaf slot
+                roots.push_back({at, inst_of[k], it.depth + 1});
+                nd.meta[s] = (uint8_t)(0x20u | (24u + (uint32_t)s));
+                nd.imask |= (uint8_t)(1u << s);
+            }
+        }
+        nd.child_base = child_base; nd.prim_base = 0;
+        out.nodes[it.out_index] = nd;
+    }
+    // instance bodies and primitives
+    for (const RootRef &r : roots) {
+        const Bvh8 &t = *tmpl[r.inst];
+        const uint32_t body = (uint32_t)out.nodes.size(), pbase = (uint32_t)out.prims.size();
+        for (size_t k = 0; k < t.nodes.size(); ++k) {
+            Bvh8Node nd = t.nodes[k];
+            nd.child_base = body + (nd.child_base - 1u);            // template node j > 0 lives at body + j - 1
+            nd.prim_base = pbase + nd.prim_base;
+            if (k == 0) out.nodes[r.out_index] = nd; else out.nodes.push_back(nd);
+        }
+        for (PrimRecord pr : t.prims) { pr.inst = r.inst; out.prims.push_back(pr); }
+        out.n_triangles += t.n_triangles; out.n_spheres += t.n_spheres;
+        out.max_depth = std::max(out.max_depth, r.depth + t.max_depth);
+    }
+    // heights and primitive counts bottom-up: every child has a larger index than its parent
+    const size_t nn = out.nodes.size();
+    std::vector<uint32_t> height(nn, 0);
+    std::vector<double> below(nn, 0.0);
+    uint32_t max_h = 0; double total = 0.0;
+    for (size_t i = nn; i-- > 0;) {
+        const Bvh8Node &nd = out.nodes[i];
+        uint32_t rank = 0;
+        for (int s = 0; s < 8; ++s) {
+            const uint8_t m = nd.meta[s];
+            if (m == 0) continue;
+            if ((nd.imask >> s) & 1u) { const uint32_t c = nd.child_base + rank++; height[i] = std::max(height[i], height[c] + 1u); below[i] += below[c]; }
+            else { const uint32_t cb = m >> 5; below[i] += cb == 1 ? 1.0 : cb == 3 ? 2.0 : 3.0; }
+        }
+        max_h = std::max(max_h, height[i]); total += below[i];
+    }
+    out.phase_begin.assign(max_h + 2, 0u);
+    for (size_t i = 0; i < nn; ++i) out.phase_begin[height[i] + 1]++;
+    for (uint32_t h = 0; h <= max_h; ++h) out.phase_begin[h + 1] += out.phase_begin[h];
+    out.order.resize(nn);
+    std::vector<uint32_t> cursor(out.phase_begin.begin(), out.phase_begin.end() - 1);
+    for (size_t i = 0; i < nn; ++i) out.order[cursor[height[i]]++] = (uint32_t)i;
+    out.weight.resize(nn);
+    for (size_t i = 0; i < nn; ++i) out.weight[i] = total > 0.0 ? (float)(below[i] / total) : 0.0f;
 }
 
 // Walk the packed tree and check containment of every primitive in every ancestor slot box.

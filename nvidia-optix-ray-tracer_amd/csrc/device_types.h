@@ -125,16 +125,18 @@ struct RefitArgs {
     unsigned char *nodes; uint32_t node_stride;
     unsigned char *prims; uint32_t prim_stride;
     float *node_box;               // 6 floats per node: padded bounds of everything below it
-    uint32_t first_node, n_nodes;  // the level
+    uint32_t first_node, n_nodes;  // the phase: nodes first_node .. first_node + n_nodes (positions in `order` when it is set)
+    const uint32_t *order;         // NULL: node index = position (trees stored breadth first)
     const float *inst_xf;          // 12 floats per instance: object -> world
     const uint32_t *inst_identity;
     const void *const *inst_src;   // per instance: object-space triangle vertices (9 floats per triangle) of its BLAS
     float pad;
-    const float *node_ref;         // 2 floats per node: {weight, 1 / half area as built}
+    float *node_ref;               // 2 floats per node: {weight, 1 / half area as built}
+    uint32_t write_reference;      // 1: this refit completes a build -- record the areas instead of comparing with them
     float *area_sum;               // weighted mean of area now / area as built (quality after the refit), may be NULL
 };
 constexpr uint32_t kRefitTopLevels = 16, kRefitTopLevelNodes = 1024;
-struct RefitLevels { uint32_t n_levels; uint32_t begin[kRefitTopLevels + 1]; };   // levels 0 .. n_levels-1, each at most kRefitTopLevelNodes wide
+struct RefitLevels { uint32_t n_levels; uint32_t first[kRefitTopLevels], count[kRefitTopLevels]; };   // phases in processing order, each at most kRefitTopLevelNodes wide
 void launch_refit_level(const RefitArgs &a, hipStream_t s);
 void launch_refit_top(const RefitArgs &a, const RefitLevels &lv, hipStream_t s);
 

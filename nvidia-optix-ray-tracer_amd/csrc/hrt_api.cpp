@@ -35,6 +35,8 @@ struct Blas {
     float *d_verts = nullptr;        // device copy of verts: the refit re-derives the world-space records from it
                                      // (the caller may free its vertex buffer after the build, RendererMesh.cu:116)
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};   // object-space bounds
+    // object-space BVH8 of this geometry alone: the per-instance subtree of the trees over instances (built on first use)
+    std::mutex tmpl_mu; bool tmpl_built = false; Bvh8 tmpl;
     ~Blas() { if (d_verts) (void)hipFree(d_verts); }
 };
 
@@ -54,6 +56,9 @@ struct Tlas {
     std::vector<uint64_t> sig_handle; std::vector<uint32_t> sig_visibility;
     std::vector<float> h_xf, h_inv; std::vector<uint32_t> h_ident;   // staging of the per-instance uploads
     float *d_node_box = nullptr, *d_node_ref = nullptr, *d_inst_xf = nullptr, *d_area = nullptr;
+    uint32_t *d_order = nullptr;                         // trees over instances: refit order (NULL: breadth-first index ranges)
+    std::vector<std::pair<uint32_t, uint32_t>> phases;   // (first, count) in processing order, children before parents
+    bool instanced = false;
     const void **d_inst_src = nullptr;
     float *h_area = nullptr;                             // pinned: area sum of the last refit
     hipEvent_t area_ready = nullptr; bool area_pending = false;
@@ -129,6 +134,7 @@ struct HrtContext {
     int lds_gather = 0;                         // 1: cooperative LDS-DMA gathers, 0: per-lane register loads
     int fetch_chunk = 64;
     int substream_min_pixels = 32768;
+    int tlas_instanced = 0;                     // 1: hrt_tlas_build makes trees over instances too, 0: only rebuilds during updates do, -1: never
     int refit = 1;                              // hrt_tlas_update: 1 = device refit when only transforms changed, 0 = always rebuild
     float refit_rebuild_ratio = 1.5f;           // rebuild when the refitted tree's weighted mean node area has grown by this factor
     uint64_t tlas_refits = 0, tlas_rebuilds = 0; double tlas_refit_ratio = 1.0;
@@ -212,11 +218,12 @@ void free_tlas_device(Tlas &t) {
     if (t.d_inst_identity) (void)hipFree(t.d_inst_identity);
     if (t.d_node_box) (void)hipFree(t.d_node_box);
     if (t.d_node_ref) (void)hipFree(t.d_node_ref);
+    if (t.d_order) (void)hipFree(t.d_order);
     if (t.d_inst_xf) (void)hipFree(t.d_inst_xf);
     if (t.d_area) (void)hipFree(t.d_area);
     if (t.d_inst_src) (void)hipFree((void *)t.d_inst_src);
     t.d_nodes = t.d_prims = nullptr; t.d_inst_inv = nullptr; t.d_inst_identity = nullptr;
-    t.d_node_box = t.d_node_ref = t.d_inst_xf = t.d_area = nullptr; t.d_inst_src = nullptr;
+    t.d_node_box = t.d_node_ref = t.d_inst_xf = t.d_area = nullptr; t.d_inst_src = nullptr; t.d_order = nullptr;
     t.area_pending = false;
 }
 void free_tlas_host(Tlas &t) {
@@ -250,9 +257,40 @@ float instance_tables(const std::vector<HrtInstance> &inst, const std::vector<st
     return smax;
 }
 
-// Flatten the instances into world space, build the BVH8 on the host, upload it together with the
-// tables the device refit needs (hrt_tlas_update).
-int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s) {
+void launch_refit_phases(RefitArgs ra, const std::vector<std::pair<uint32_t, uint32_t>> &phases, hipStream_t s);
+
+// Object-space BVH8 of one BLAS (built once): the subtree every instance of it gets in a tree over instances.
+void ensure_template(Blas &b) {
+    std::lock_guard<std::mutex> lk(b.tmpl_mu);
+    if (b.tmpl_built) return;
+    std::vector<BuildPrim> prims;
+    prims.reserve(b.n_prims);
+    for (uint32_t p = 0; p < b.n_prims; ++p) {
+        BuildPrim bp; std::memset(&bp, 0, sizeof bp);
+        if (b.kind == kPrimKindTriangle) {
+            triangle_world(&b.verts[9 * (size_t)p], nullptr, true, bp.rec.a, bp.rec.b, bp.rec.c, bp.lo, bp.hi);
+            bp.rec.kind = kPrimKindTriangle;
+        } else {
+            const float *c = &b.centers[3 * (size_t)p];
+            bp.rec.a[0] = c[0]; bp.rec.a[1] = c[1]; bp.rec.a[2] = c[2]; bp.rec.b[0] = b.radii[p]; bp.rec.kind = kPrimKindSphere;
+            sphere_world_bounds(c, b.radii[p], nullptr, true, bp.lo, bp.hi);
+        }
+        bp.rec.prim = p;
+        if (finite_box(bp.lo, bp.hi)) prims.push_back(bp);
+    }
+    build_bvh8(prims, b.tmpl, 0);
+    b.tmpl_built = true;
+}
+
+// Build a TLAS on the host and upload it together with the tables the device refit needs (hrt_tlas_update).
+//  * merged (default of hrt_tlas_build): every instance is flattened into world space and ONE tree is built over all
+//    primitives -- the best tree, at the price of a full SAH build;
+//  * instanced: a top tree over the instances' boxes whose leaves are per-instance copies of object-space template
+//    trees; only the topology comes from the host (milliseconds for thousands of instances), the device refit
+//    computes every box and world-space record.  The shape the reference's own scenes have (particles instancing a
+//    few shapes); used when a refitted tree has degraded and has to be rebuilt while frames are being rendered.
+// Either way the result is one world-space BVH8: the traversal kernels do not know the difference.
+int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s, bool instanced) {
     const uint32_t n = (uint32_t)inst.size();
     std::vector<std::shared_ptr<Blas>> refs(n);
     size_t total = 0;
@@ -268,34 +306,69 @@ int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &in
     const float scene_scale = instance_tables(inst, refs, t.h_xf, t.h_inv, t.h_ident);
     t.sbt_offset.assign(n, 0); t.kind.assign(n, 0); t.has_spheres = false;
     t.sig_handle.assign(n, 0); t.sig_visibility.assign(n, 0);
-    std::vector<BuildPrim> prims;
-    prims.reserve(total);
     for (uint32_t i = 0; i < n; ++i) {
-        const Blas *b = refs[i].get();
-        const float *m = inst[i].transform;
-        const bool id = t.h_ident[i] != 0u;
         t.sbt_offset[i] = inst[i].sbtOffset;
-        t.kind[i] = b->kind;
+        t.kind[i] = refs[i]->kind;
         t.sig_handle[i] = inst[i].traversableHandle; t.sig_visibility[i] = inst[i].visibilityMask & 1u;
-        if ((inst[i].visibilityMask & 1u) == 0) continue;       // the reference traces with mask 1 (Shader.cu:71)
-        for (uint32_t p = 0; p < b->n_prims; ++p) {
-            BuildPrim bp; std::memset(&bp, 0, sizeof bp);
-            if (b->kind == kPrimKindTriangle) {
-                triangle_world(&b->verts[9 * (size_t)p], m, id, bp.rec.a, bp.rec.b, bp.rec.c, bp.lo, bp.hi);
-                bp.rec.prim = p; bp.rec.inst = i; bp.rec.kind = kPrimKindTriangle;
-            } else {
-                t.has_spheres = true;
-                const float *c = &b->centers[3 * (size_t)p];
-                bp.rec.a[0] = c[0]; bp.rec.a[1] = c[1]; bp.rec.a[2] = c[2]; bp.rec.prim = p;
-                bp.rec.b[0] = b->radii[p]; bp.rec.inst = i; bp.rec.kind = kPrimKindSphere;
-                sphere_world_bounds(c, b->radii[p], m, id, bp.lo, bp.hi);
-            }
-            // NaN / Inf geometry never hits anything; keep it out of the tree
-            if (!finite_box(bp.lo, bp.hi)) continue;
-            prims.push_back(bp);
-        }
+        if ((inst[i].visibilityMask & 1u) != 0 && refs[i]->kind == kPrimKindSphere && refs[i]->n_prims) t.has_spheres = true;
     }
-    build_bvh8(prims, t.bvh, 0, scene_scale);
+    std::vector<uint32_t> order;
+    t.phases.clear();
+    if (instanced) {
+        std::vector<const Bvh8 *> tmpl(n, nullptr);
+        std::vector<float> box(6 * (size_t)std::max(n, 1u), 0.0f);
+        for (uint32_t i = 0; i < n; ++i) {
+            Blas &b = *refs[i];
+            if ((inst[i].visibilityMask & 1u) == 0 || !(b.lo[0] <= b.hi[0])) continue;      // the reference traces with mask 1 (Shader.cu:71)
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int c = 0; c < 8; ++c) {
+                const float q[3] = {(c & 1) ? b.hi[0] : b.lo[0], (c & 2) ? b.hi[1] : b.lo[1], (c & 4) ? b.hi[2] : b.lo[2]};
+                float w[3];
+                if (t.h_ident[i]) { w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; } else xf_point(inst[i].transform, q, w);
+                for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], w[a]); hi[a] = std::fmax(hi[a], w[a]); }
+            }
+            if (!finite_box(lo, hi)) continue;                                                 // a NaN transform: nothing to hit
+            ensure_template(b);
+            tmpl[i] = &b.tmpl;
+            for (int a = 0; a < 3; ++a) { box[6 * (size_t)i + a] = lo[a]; box[6 * (size_t)i + 3 + a] = hi[a]; }
+        }
+        InstancedTree it;
+        assemble_instanced_bvh8(tmpl, box, it);
+        t.bvh = Bvh8();
+        t.bvh.nodes = std::move(it.nodes); t.bvh.prims = std::move(it.prims);
+        t.bvh.n_triangles = it.n_triangles; t.bvh.n_spheres = it.n_spheres; t.bvh.max_depth = it.max_depth;
+        t.bvh.node_box.assign(6 * t.bvh.nodes.size(), 0.0f);
+        t.bvh.node_ref.assign(2 * t.bvh.nodes.size(), 0.0f);
+        for (size_t i = 0; i < it.weight.size(); ++i) t.bvh.node_ref[2 * i] = it.weight[i];
+        order = std::move(it.order);
+        for (size_t h = 0; h + 1 < it.phase_begin.size(); ++h) t.phases.emplace_back(it.phase_begin[h], it.phase_begin[h + 1] - it.phase_begin[h]);
+    } else {
+        std::vector<BuildPrim> prims;
+        prims.reserve(total);
+        for (uint32_t i = 0; i < n; ++i) {
+            const Blas *b = refs[i].get();
+            const float *m = inst[i].transform;
+            const bool id = t.h_ident[i] != 0u;
+            if ((inst[i].visibilityMask & 1u) == 0) continue;       // the reference traces with mask 1 (Shader.cu:71)
+            for (uint32_t p = 0; p < b->n_prims; ++p) {
+                BuildPrim bp; std::memset(&bp, 0, sizeof bp);
+                if (b->kind == kPrimKindTriangle) {
+                    triangle_world(&b->verts[9 * (size_t)p], m, id, bp.rec.a, bp.rec.b, bp.rec.c, bp.lo, bp.hi);
+                    bp.rec.prim = p; bp.rec.inst = i; bp.rec.kind = kPrimKindTriangle;
+                } else {
+                    const float *c = &b->centers[3 * (size_t)p];
+                    bp.rec.a[0] = c[0]; bp.rec.a[1] = c[1]; bp.rec.a[2] = c[2]; bp.rec.prim = p;
+                    bp.rec.b[0] = b->radii[p]; bp.rec.inst = i; bp.rec.kind = kPrimKindSphere;
+                    sphere_world_bounds(c, b->radii[p], m, id, bp.lo, bp.hi);
+                }
+                // NaN / Inf geometry never hits anything; keep it out of the tree
+                if (!finite_box(bp.lo, bp.hi)) continue;
+                prims.push_back(bp);
+            }
+        }
+        build_bvh8(prims, t.bvh, 0, scene_scale);
+        for (size_t l = t.bvh.level_begin.size() - 1; l-- > 0;) t.phases.emplace_back(t.bvh.level_begin[l], t.bvh.level_begin[l + 1] - t.bvh.level_begin[l]);
+    }
     if (2 * t.bvh.max_depth + 2 > (uint32_t)(8 + 56))
         return fail(ctx, HRT_ERR_INVALID, "BVH depth %u exceeds the traversal stack", t.bvh.max_depth);
 
@@ -317,6 +390,7 @@ int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &in
     HIP_TRY(ctx, hipMalloc((void **)&t.d_node_box, sizeof(float) * std::max<size_t>(t.bvh.node_box.size(), 6)));
     HIP_TRY(ctx, hipMalloc((void **)&t.d_node_ref, sizeof(float) * std::max<size_t>(t.bvh.node_ref.size(), 2)));
     HIP_TRY(ctx, hipMalloc((void **)&t.d_area, sizeof(float)));
+    if (!order.empty()) HIP_TRY(ctx, hipMalloc((void **)&t.d_order, sizeof(uint32_t) * order.size()));
     if (!t.h_area) HIP_TRY(ctx, hipHostMalloc((void **)&t.h_area, sizeof(float), hipHostMallocDefault));
     if (!t.area_ready) HIP_TRY(ctx, hipEventCreateWithFlags(&t.area_ready, hipEventDisableTiming));
     if (t.node_stride == sizeof(Bvh8Node) && t.prim_stride == sizeof(PrimRecord)) {
@@ -339,7 +413,20 @@ int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &in
         HIP_TRY(ctx, hipMemcpyAsync(t.d_node_box, t.bvh.node_box.data(), sizeof(float) * t.bvh.node_box.size(), hipMemcpyHostToDevice, s));
     if (!t.bvh.node_ref.empty())
         HIP_TRY(ctx, hipMemcpyAsync(t.d_node_ref, t.bvh.node_ref.data(), sizeof(float) * t.bvh.node_ref.size(), hipMemcpyHostToDevice, s));
+    if (!order.empty()) HIP_TRY(ctx, hipMemcpyAsync(t.d_order, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice, s));
+    if (instanced && n_prims) {
+        // the device computes what the host left blank: world-space records, boxes, origins, exponents, quantised
+        // children, and the built areas the quality guard compares later refits with
+        RefitArgs ra{};
+        ra.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); ra.node_stride = t.node_stride;
+        ra.prims = reinterpret_cast<unsigned char *>(t.d_prims); ra.prim_stride = t.prim_stride;
+        ra.node_box = t.d_node_box; ra.node_ref = t.d_node_ref; ra.inst_xf = t.d_inst_xf; ra.inst_identity = t.d_inst_identity;
+        ra.inst_src = t.d_inst_src; ra.pad = 4e-6f * std::max(1.0f, scene_scale); ra.order = t.d_order; ra.write_reference = 1u;
+        launch_refit_phases(ra, t.phases, s);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     HIP_TRY(ctx, hipStreamSynchronize(s));
+    t.instanced = instanced;
     t.generation++;
     t.rebuilds++; ctx->tlas_rebuilds++;
     return HRT_OK;
@@ -412,6 +499,17 @@ void drain_spans(HrtContext *ctx) {
     ctx->events_used = 0;
 }
 
+// The phases of a refit, children before parents: wide phases get a launch each, the narrow ones at the end (the top
+// of the tree, or all of a small tree) run in one single-workgroup launch.
+void launch_refit_phases(RefitArgs ra, const std::vector<std::pair<uint32_t, uint32_t>> &phases, hipStream_t s) {
+    size_t tail = phases.size();
+    while (tail > 0 && phases.size() - tail < kRefitTopLevels && phases[tail - 1].second <= kRefitTopLevelNodes) --tail;
+    for (size_t i = 0; i < tail; ++i) { ra.first_node = phases[i].first; ra.n_nodes = phases[i].second; launch_refit_level(ra, s); }
+    RefitLevels top{};
+    for (size_t i = tail; i < phases.size(); ++i) { top.first[top.n_levels] = phases[i].first; top.count[top.n_levels] = phases[i].second; ++top.n_levels; }
+    launch_refit_top(ra, top, s);
+}
+
 // Device refit of a built tree under new instance transforms: upload the per-instance tables, then one
 // k_refit_level launch per tree level, deepest first.  Asynchronous on s.
 int refit_tlas(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s) {
@@ -426,21 +524,8 @@ int refit_tlas(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, h
     ra.node_box = t.d_node_box; ra.node_ref = t.d_node_ref; ra.inst_xf = t.d_inst_xf; ra.inst_identity = t.d_inst_identity; ra.inst_src = t.d_inst_src;
     ra.pad = 4e-6f * std::max(1.0f, scene_scale);
     ra.area_sum = t.d_area;
-    {
-        Timer tm(ctx, s, HRT_K_REFIT);
-        const std::vector<uint32_t> &lv = t.bvh.level_begin;
-        const size_t n_levels = lv.size() - 1;
-        // the narrow levels at the top go into one single-workgroup launch, the wide ones get a launch each
-        RefitLevels top{};
-        while (top.n_levels < kRefitTopLevels && top.n_levels < n_levels &&
-               lv[top.n_levels + 1] - lv[top.n_levels] <= kRefitTopLevelNodes) ++top.n_levels;
-        for (uint32_t l = 0; l <= top.n_levels; ++l) top.begin[l] = lv[l];
-        for (size_t l = n_levels; l-- > top.n_levels;) {
-            ra.first_node = lv[l]; ra.n_nodes = lv[l + 1] - lv[l];
-            launch_refit_level(ra, s);
-        }
-        launch_refit_top(ra, top, s);
-    }
+    ra.order = t.d_order;
+    { Timer tm(ctx, s, HRT_K_REFIT); launch_refit_phases(ra, t.phases, s); }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(t.h_area, t.d_area, sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipEventRecord(t.area_ready, s));
@@ -483,6 +568,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_NODE_STRIDE")) { const int v = std::atoi(e); if (v >= 80 && v <= 256 && v % 16 == 0) ctx->node_stride = v; }
     if (const char *e = std::getenv("HRT_PRIM_STRIDE")) { const int v = std::atoi(e); if (v >= 48 && v <= 256 && v % 16 == 0) ctx->prim_stride = v; }
     if (const char *e = std::getenv("HRT_FUSED")) ctx->fused = std::atoi(e);
+    if (const char *e = std::getenv("HRT_TLAS_INSTANCED")) ctx->tlas_instanced = std::atoi(e);
     if (const char *e = std::getenv("HRT_REFIT")) ctx->refit = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_REFIT_REBUILD_RATIO")) { const double v = std::atof(e); if (v >= 1.0) ctx->refit_rebuild_ratio = (float)v; }
     if (const char *e = std::getenv("HRT_FUSED_MAX_SPP")) { const int v = std::atoi(e); if (v >= 1) ctx->fused_max_spp = v; }
@@ -591,7 +677,7 @@ int hrt_tlas_build(HrtContext *ctx, const HrtInstance *d_instances, uint32_t n, 
     std::unique_ptr<Tlas> t(new Tlas());
     std::vector<HrtInstance> inst;
     int rc = download_instances(ctx, d_instances, n, (hipStream_t)stream, inst);
-    if (rc == HRT_OK) rc = build_tlas_into(ctx, *t, inst, (hipStream_t)stream);
+    if (rc == HRT_OK) rc = build_tlas_into(ctx, *t, inst, (hipStream_t)stream, ctx->tlas_instanced > 0);
     if (rc != HRT_OK) { free_tlas_device(*t); free_tlas_host(*t); return rc; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const uint64_t h = ctx->next_handle++;
@@ -631,7 +717,8 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
         return refit_tlas(ctx, *t, inst, s);
     }
     HIP_TRY(ctx, hipDeviceSynchronize());                 // launches on other streams may still read the old tree
-    return build_tlas_into(ctx, *t, inst, s);
+    // a rebuild in the middle of an animation: the tree over instances costs milliseconds instead of a full SAH build
+    return build_tlas_into(ctx, *t, inst, s, ctx->tlas_instanced >= 0 && n >= 2);
 }
 
 int hrt_pose_instances(HrtContext *ctx, HrtInstance *d_instances, uint32_t first_instance, uint32_t n_particles,

@@ -95,32 +95,43 @@ __device__ __forceinline__ void refit_slot(const RefitArgs &a, uint32_t node, ui
         if (empty_node) { for (int k = 0; k < 3; ++k) { b[k] = INFINITY; b[3 + k] = -INFINITY; } }
         else for (int k = 0; k < 3; ++k) { b[k] = nlo[k]; b[3 + k] = nhi[k]; }
     }
-    // tree quality: primitives-below weighted mean of area(node now) / area(node as built); 1.0 for the built tree
-    if (a.area_sum && slot == 0u && !empty_node) {
-        const float2 ref = reinterpret_cast<const float2 *>(a.node_ref)[node];
-        const float g = box_half_area(nlo, nhi) * ref.y;
-        if (ref.x > 0.0f && g < 3.0e38f) atomicAdd(a.area_sum, ref.x * g);
+    // tree quality: primitives-below weighted mean of area(node now) / area(node as built); 1.0 for the built tree.
+    // The refit that completes a build records the built areas instead (write_reference).
+    if (slot == 0u && !empty_node) {
+        float2 *ref = reinterpret_cast<float2 *>(a.node_ref) + node;
+        const float area = box_half_area(nlo, nhi);
+        if (a.write_reference) ref->y = (area > 0.0f && area < 3.0e38f) ? 1.0f / area : 0.0f;
+        else if (a.area_sum) {
+            const float2 r = *ref;
+            const float g = area * r.y;
+            if (r.x > 0.0f && g < 3.0e38f) atomicAdd(a.area_sum, r.x * g);
+        }
     }
 }
 
-// a wide level: one launch, eight lanes per node
+// node number k of a phase: the trees built breadth first are walked by index ranges, the instanced ones through `order`
+__device__ __forceinline__ uint32_t phase_node(const RefitArgs &a, uint32_t first, uint32_t k) {
+    return a.order ? a.order[first + k] : first + k;
+}
+
+// a wide phase: one launch, eight lanes per node
 __global__ __launch_bounds__(256) void k_refit_level(RefitArgs a) {
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t local = tid >> 3;
     const bool live = local < a.n_nodes;                       // whole 8-lane groups are live or not
-    refit_slot(a, a.first_node + (live ? local : 0u), tid & 7u, live);
+    refit_slot(a, phase_node(a, a.first_node, live ? local : 0u), tid & 7u, live);
 }
 
-// the narrow levels at the top of the tree (and all of a small tree): one workgroup walks them bottom-up
-// with a barrier between levels, instead of one launch per level
+// the narrow phases at the top of the tree (and all of a small tree): one workgroup walks them in order
+// with a barrier in between, instead of one launch per phase
 __global__ __launch_bounds__(1024) void k_refit_top(RefitArgs a, RefitLevels lv) {
     const uint32_t group = threadIdx.x >> 3, slot = threadIdx.x & 7u;
-    for (int l = (int)lv.n_levels - 1; l >= 0; --l) {
-        const uint32_t first = lv.begin[l], n = lv.begin[l + 1] - first;
+    for (uint32_t l = 0; l < lv.n_levels; ++l) {
+        const uint32_t first = lv.first[l], n = lv.count[l];
         for (uint32_t base = 0; base < n; base += 128u) {
             const uint32_t local = base + group;
             const bool live = local < n;
-            refit_slot(a, first + (live ? local : 0u), slot, live);
+            refit_slot(a, phase_node(a, first, live ? local : 0u), slot, live);
         }
         __threadfence_block();
         __syncthreads();                                       // the next level reads this level's node boxes

@@ -404,6 +404,75 @@ def test_real_data_time_mode_frames(hrt, oracle, renderer):
     assert np.array_equal(renderer.rng_states_numpy(), states)
 
 
+def test_tree_over_instances_parity(hrt, oracle, gpu_available, monkeypatch):
+    """HRT_TLAS_INSTANCED=1: hrt_tlas_build makes a top tree over the instances whose leaves are per-instance copies of
+    object-space template trees, and the device refit fills in every box and world-space record.  Same bits as the
+    oracle: rendered images, hit records against brute force, an animation refitted every frame; an update with
+    unchanged transforms rewrites the very bytes the build produced; BLASes shared by many instances."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    monkeypatch.setenv("HRT_TLAS_INSTANCED", "1")
+    r = hrt.Renderer(0, 0)
+    try:
+        for scene, (w, h, spp) in ((hrt.scenes.mixed_test_scene(2500, 50, 13, 120, 80, 2), (120, 80, 2)),
+                                   (hrt.scenes.cornell_box(96, 96, 2), (96, 96, 2)),
+                                   (hrt.scenes.particle_scene(40, 100, 70, 1, frame=2), (100, 70, 1))):
+            r.load_scene(scene)
+            _moved_scene_matches_oracle(hrt, oracle, r, scene, w, h, 31, spp)
+        # refit of a tree over instances: identical transforms -> identical bytes; moved -> oracle on the moved scene
+        n_p = 40
+        scene = hrt.scenes.particle_scene(n_p, 72, 48, 1, frame=0)
+        r.load_scene(scene)
+        nodes0, prims0 = _download_tree(hrt, r)
+        before = r.stats()
+        r.update_instances([it["transform"] for it in scene["instances"]])
+        nodes1, prims1 = _download_tree(hrt, r)
+        assert np.array_equal(nodes0, nodes1) and np.array_equal(prims0, prims1)
+        ground = scene["instances"][0]["transform"]
+        r.set_frame(72, 48, 5, linear=True)
+        states = oracle.rng_init(72, 48, 5)
+        for frame in (1, 2, 5):
+            poses = hrt.scenes.particle_poses(n_p, frame)
+            r.update_instances([ground] + poses)
+            for it, m in zip(scene["instances"][1:], poses):
+                it["transform"] = m
+            r.render(1)
+            ref = oracle.OracleScene(scene).render(72, 48, states, 1)
+            assert np.array_equal(r.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32)), frame
+        after = r.stats()
+        assert after.tlas_refits == before.tlas_refits + 4 and after.tlas_rebuilds == before.tlas_rebuilds
+    finally:
+        r.close()
+
+
+def test_rebuild_during_animation_uses_the_tree_over_instances(hrt, oracle, gpu_available, monkeypatch):
+    """The reference builds each file's IAS with identity transforms and poses it afterwards (RendererTime.cu:111-127):
+    all particles start on top of each other, the first refit degrades the tree, the guard rebuilds -- as a tree over
+    instances (milliseconds).  Image parity before and after, and the rebuilt tree is the instanced kind."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    r = hrt.Renderer(0, 0)
+    try:
+        n_p, w, h = 30, 72, 48
+        scene = hrt.scenes.particle_scene(n_p, w, h, 1, frame=0)
+        posed = [it["transform"].copy() for it in scene["instances"]]
+        for it in scene["instances"][1:]:
+            it["transform"] = hrt.scenes.IDENTITY.copy()
+        r.load_scene(scene)                                   # merged build over the overlapping particles
+        r.update_instances(posed)                             # refit: boxes explode
+        r.update_instances(posed)                             # guard -> rebuild
+        s = r.stats()
+        assert s.tlas_refits == 1 and s.tlas_rebuilds == 2 and s.tlas_refit_ratio > 1.5
+        for it, m in zip(scene["instances"], posed):
+            it["transform"] = m
+        _moved_scene_matches_oracle(hrt, oracle, r, scene, w, h, 11)
+        r.update_instances(posed)                             # and the rebuilt tree refits
+        assert r.stats().tlas_refits == 2
+        _moved_scene_matches_oracle(hrt, oracle, r, scene, w, h, 12)
+    finally:
+        r.close()
+
+
 def test_refit_quality_guard_rebuilds(hrt, oracle, monkeypatch):
     """A refit keeps the topology; when the instances have moved so far that the boxes' area sum passes
     HRT_REFIT_REBUILD_RATIO x the built tree's, the next update rebuilds -- and the image is still the oracle's."""

@@ -14,8 +14,12 @@ sys.path.insert(0, str(ROOT))
 hrt = importlib.import_module("nvidia-optix-ray-tracer_amd")
 
 
-def run(name, scene, poses_of, frames, refit):
+def run(name, scene, poses_of, frames, mode):
+    """mode: "refit" (device refit), "rebuild" (HRT_REFIT=0: tree over instances, the default for rebuilds during updates)
+    or "rebuild-merged" (HRT_TLAS_INSTANCED=-1: full SAH build over all primitives)."""
+    refit = mode == "refit"
     os.environ["HRT_REFIT"] = "1" if refit else "0"
+    os.environ["HRT_TLAS_INSTANCED"] = "-1" if mode == "rebuild-merged" else "0"
     import ctypes as C
     import torch
     r = hrt.Renderer(0, hrt.CTX_TIMING)
@@ -44,7 +48,7 @@ def run(name, scene, poses_of, frames, refit):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     s = r.stats()
-    out = {"scene": name, "mode": "refit" if refit else "rebuild", "instances": n,
+    out = {"scene": name, "mode": mode, "instances": n,
            "bvh_nodes": int(n_nodes), "triangles": int(n_tris), "frames": frames,
            "update_call_ms": round((t1 - t0) * 1e3 / frames, 4), "update_done_ms": round((t2 - t0) * 1e3 / frames, 4),
            "tlas_refits": int(s.tlas_refits), "tlas_rebuilds": int(s.tlas_rebuilds), "refit_ratio": round(s.tlas_refit_ratio, 3)}
@@ -70,16 +74,17 @@ def main():
         cached = lambda f, poses=poses, cache=cache: cache.setdefault(f, poses(f))               # noqa: E731
         for f in range(a.frames + 1):
             cached(f)
-        run("particles-%d" % n_p, sc, cached, a.frames, True)
-        run("particles-%d" % n_p, sc, cached, min(a.frames, 5), False)
+        run("particles-%d" % n_p, sc, cached, a.frames, "refit")
+        run("particles-%d" % n_p, sc, cached, min(a.frames, 5), "rebuild")
+        run("particles-%d" % n_p, sc, cached, min(a.frames, 5), "rebuild-merged")
     # one big static instance that moves as a whole (C4 geometry)
     sc = hrt.scenes.soup_1m(1920, 1080, 1)
     base = sc["instances"][0]["transform"]
     def poses(f, base=base):
         m = base.copy(); m[3] += 0.01 * f
         return [m]
-    run("soup-1m", sc, poses, a.frames, True)
-    run("soup-1m", sc, poses, 1, False)
+    run("soup-1m", sc, poses, a.frames, "refit")
+    run("soup-1m", sc, poses, 1, "rebuild")
 
 
 if __name__ == "__main__":

@@ -3,7 +3,7 @@
 per frame  pose kernel -> hrt_tlas_update (device refit) -> hrt_render_launch (1 spp) -> hrt_to_rgba8.
 Prints one JSON line per scene with ms per frame, frames/s and Mrays/s (window 1200x800 as files/config.json).
 Usage: python tools/time_mode_bench.py [--frames 200]"""
-import argparse, importlib, json, sys, time
+import argparse, importlib, json, os, sys, time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -46,5 +46,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=200)
     a = ap.parse_args()
-    run(25, 2, a.frames)
-    run(2000, 3, a.frames)
+    for instanced in ("0", "1"):                     # hrt_tlas_build: merged tree / tree over instances
+        os.environ["HRT_TLAS_INSTANCED"] = instanced
+        print("HRT_TLAS_INSTANCED=" + instanced, flush=True)
+        run(25, 2, a.frames)
+        run(2000, 3, a.frames)
