@@ -2,147 +2,12 @@
 // Entry points and the reference call sites they replace are documented in include/hrt.h.
 // There is deliberately no CPU fallback anywhere in this file: every compute path ends in a
 // HIP kernel launch, and context creation fails when no gfx950 device is present.
-#include "../../include/hrt.h"
-#include "bvh8.h"
-#include "bvh8_geom.h"
-#include "device_types.h"
+#include "hrt_internal.hpp"
 
-#include <hip/hip_runtime.h>
+namespace hrt {
 
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <memory>
-#include <mutex>
-#include <string>
-#include <unordered_map>
-#include <vector>
-
-using namespace hrt;
-
-namespace {
-
-thread_local std::string g_create_error;
-
-struct Blas {
-    uint32_t kind = kPrimKindTriangle;
-    uint32_t n_prims = 0;
-    std::vector<float> verts;        // triangles: 9 floats each (object space)
-    std::vector<float> centers;      // spheres: 3 floats each
-    std::vector<float> radii;
-    float *d_verts = nullptr;        // device copy of verts: the refit re-derives the world-space records from it
-                                     // (the caller may free its vertex buffer after the build, RendererMesh.cu:116)
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};   // object-space bounds
-    // object-space BVH8 of this geometry alone: the per-instance subtree of the trees over instances (built on first use)
-    std::mutex tmpl_mu; bool tmpl_built = false; Bvh8 tmpl;
-    ~Blas() { if (d_verts) (void)hipFree(d_verts); }
-};
-
-struct Tlas {
-    uint32_t n_instances = 0;
-    std::vector<uint32_t> sbt_offset;      // per instance
-    std::vector<uint32_t> kind;            // per instance: triangle / sphere BLAS
-    Bvh8 bvh;                               // host copy (download / stats)
-    void *d_nodes = nullptr, *d_prims = nullptr;
-    float *d_inst_inv = nullptr;
-    uint32_t *d_inst_identity = nullptr;
-    bool has_spheres = false;
-    uint32_t node_stride = 80, prim_stride = 48;
-    uint64_t generation = 0;
-    // refit (hrt_tlas_update): what must stay the same, and the device tables the refit kernel reads
-    std::vector<std::shared_ptr<Blas>> blas_refs;       // keeps the source geometry alive
-    std::vector<uint64_t> sig_handle; std::vector<uint32_t> sig_visibility;
-    std::vector<float> h_xf, h_inv; std::vector<uint32_t> h_ident;   // staging of the per-instance uploads
-    float *d_node_box = nullptr, *d_node_ref = nullptr, *d_inst_xf = nullptr, *d_area = nullptr;
-    uint32_t *d_order = nullptr;                         // trees over instances: refit order (NULL: breadth-first index ranges)
-    std::vector<std::pair<uint32_t, uint32_t>> phases;   // (first, count) in processing order, children before parents
-    bool instanced = false;
-    const void **d_inst_src = nullptr;
-    float *h_area = nullptr;                             // pinned: area sum of the last refit
-    hipEvent_t area_ready = nullptr; bool area_pending = false;
-    uint64_t refits = 0, rebuilds = 0;
-};
-
-// per-depth counters, zeroed once per sample: bin sizes + 8 slice counters on 128-byte lines of their own
-struct StageCounters { uint32_t bin_count[32]; uint32_t fetch[8 * 32]; };
-static_assert(sizeof(StageCounters) == 128 + 8 * 128, "stage counters layout");
-
-struct DeviceStats { uint64_t rays_closest, rays_any, nodes_closest, prims_closest, nodes_any, prims_any; uint64_t debug[4]; };
-
-// Everything one sample needs besides the per-pixel state.  Two sets (sample parity): the stages of
-// two consecutive samples overlap in time (hrt_render_launch), never more.
-struct SampleSet {
-    RayRec *rays[2] = {nullptr, nullptr};  // depth d reads rays[(d-1)&1], shade writes rays[d&1]
-    float4 *hit_tuvp = nullptr; uint32_t *hit_inst = nullptr;
-    uint32_t *bin_items = nullptr;          // kNumBins x n ray indices
-    uint32_t *chain = nullptr;              // 4 instance indices per tile pixel
-    float4 *result = nullptr;               // the sample's linear radiance per tile pixel
-    StageCounters *stages = nullptr;        // [sub-tile][kRayTraceDepth + 1]
-};
-struct Workspace {
-    uint32_t capacity = 0, rows_capacity = 0;
-    SampleSet set[2];
-    float4 *accum = nullptr;
-    uint32_t *rows = nullptr;
-};
-
-struct TimedSpan { int kind; hipEvent_t a, b; };
-
-}  // namespace
-
-struct HrtContext {
-    int device = 0;
-    uint32_t flags = 0;
-    int n_cu = 256;
-    std::string error;
-    std::mutex mu;
-    std::unordered_map<uint64_t, std::shared_ptr<Blas>> blas;
-    std::unordered_map<uint64_t, std::unique_ptr<Tlas>> tlas;
-    uint64_t next_handle = 0x1000;
-    // materials
-    std::vector<HrtSbtRecord> records;
-    HrtMissParams miss{{0.7f, 0.8f, 0.9f}};      // reference default, src/Global/RendererMesh.cu:262
-    bool have_records = false;
-    uint64_t materials_generation = 0;
-    // per-launch device tables derived from (tlas, records)
-    HitGroup *d_hitgroups = nullptr; uint32_t *d_inst_program = nullptr; uint32_t table_capacity = 0;
-    uint64_t table_tlas = 0, table_tlas_gen = 0, table_mat_gen = ~0ull;
-    bool program_present[kNumPrograms] = {false, false, false, false};
-    // rng
-    uint32_t *d_jump = nullptr;
-    // workspace + stats
-    Workspace ws;
-    std::vector<uint32_t> h_rows; HrtTile rows_tile{0, 0, 0, 0, 0}; uint32_t rows_w = 0, rows_h = 0;
-    DeviceStats *d_stats = nullptr;
-    uint64_t paths = 0;
-    uint64_t last_tlas = 0;
-    std::vector<TimedSpan> spans; std::vector<hipEvent_t> event_pool; size_t events_used = 0;
-    double kernel_ms[HRT_K_COUNT] = {0}; uint64_t kernel_launches[HRT_K_COUNT] = {0};
-    float4 *d_linear = nullptr;
-    int refill_threshold = 16;                  // wavefront mode; fused mode: fused_refill_threshold
-    int fused_refill_threshold = 24, fused_fetch_chunk = 16;   // measured optimum of the fused path mode (profiles/r01_sweep_fused_*.txt)
-    int traverse_blocks_per_cu = 16;            // one-wave workgroups of the traverse kernel per CU
-    bool traverse_blocks_auto = true;           // fused mode: fewer of them for small tiles (not when the env knob is set)
-    int postpone_pct = 25;
-    int tail_split = 1;
-    int node_stride = 80, prim_stride = 64;     // bytes between records in HBM (80/48 packed; 128/64 = one cache line each)
-    int fused = 1;                              // 1: fused persistent path mode (default), 0: wavefront kernels, -1: fused only for small tiles
-    int fused_max_pixels = 700000;
-    int fused_max_spp = 512;                    // samples per fused launch
-    int lds_gather = 0;                         // 1: cooperative LDS-DMA gathers, 0: per-lane register loads
-    int fetch_chunk = 64;
-    int substream_min_pixels = 32768;
-    int tlas_instanced = 0;                     // 1: hrt_tlas_build makes trees over instances too, 0: only rebuilds during updates do, -1: never
-    int refit = 1;                              // hrt_tlas_update: 1 = device refit when only transforms changed, 0 = always rebuild
-    float refit_rebuild_ratio = 1.5f;           // rebuild when the refitted tree's weighted mean node area has grown by this factor
-    uint64_t tlas_refits = 0, tlas_rebuilds = 0; double tlas_refit_ratio = 1.0;
-    int substreams = 0;                         // sub-tiles rendered on their own HIP streams so that one's tail overlaps another's bulk
-    std::vector<hipStream_t> sub_streams; std::vector<hipEvent_t> sub_done; hipEvent_t ev_begin = nullptr;
-};
-
-namespace {
+namespace { thread_local std::string g_create_error; }
+const char *create_error() { return g_create_error.c_str(); }
 
 int fail(HrtContext *ctx, int code, const char *fmt, ...) {
     char buf[512];
@@ -150,14 +15,6 @@ int fail(HrtContext *ctx, int code, const char *fmt, ...) {
     if (ctx) ctx->error = buf; else g_create_error = buf;
     return code;
 }
-
-#define HIP_TRY(ctx, expr)                                                                   \
-    do {                                                                                     \
-        hipError_t _e = (expr);                                                              \
-        if (_e != hipSuccess)                                                                \
-            return fail(ctx, _e == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP,          \
-                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-    } while (0)
 
 // ---- XORWOW sub-sequence jump matrices: T^(2^(67+k)), k = 0..31, 160 columns x 5 words ----
 struct Gf2m { uint32_t col[160][5]; };
@@ -192,257 +49,6 @@ std::vector<uint32_t> make_jump_tables() {
     return out;
 }
 
-// ---- transforms (fixed operation order; DESIGN.md "instances") ----
-bool is_identity(const float *m) {
-    static const float id[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    return std::memcmp(m, id, sizeof id) == 0;
-}
-void invert_affine(const float *m, float *o) {
-    const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
-    const double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
-    const double det = a * A + b * B + c * C;
-    const double r = 1.0 / det;
-    const double n00 = A * r, n01 = -(b * i - c * h) * r, n02 = (b * f - c * e) * r;
-    const double n10 = B * r, n11 = (a * i - c * g) * r, n12 = -(a * f - c * d) * r;
-    const double n20 = C * r, n21 = -(a * h - b * g) * r, n22 = (a * e - b * d) * r;
-    const double tx = m[3], ty = m[7], tz = m[11];
-    o[0] = (float)n00; o[1] = (float)n01; o[2] = (float)n02; o[3] = (float)(-(n00 * tx + n01 * ty + n02 * tz));
-    o[4] = (float)n10; o[5] = (float)n11; o[6] = (float)n12; o[7] = (float)(-(n10 * tx + n11 * ty + n12 * tz));
-    o[8] = (float)n20; o[9] = (float)n21; o[10] = (float)n22; o[11] = (float)(-(n20 * tx + n21 * ty + n22 * tz));
-}
-
-void free_tlas_device(Tlas &t) {
-    if (t.d_nodes) (void)hipFree(t.d_nodes);
-    if (t.d_prims) (void)hipFree(t.d_prims);
-    if (t.d_inst_inv) (void)hipFree(t.d_inst_inv);
-    if (t.d_inst_identity) (void)hipFree(t.d_inst_identity);
-    if (t.d_node_box) (void)hipFree(t.d_node_box);
-    if (t.d_node_ref) (void)hipFree(t.d_node_ref);
-    if (t.d_order) (void)hipFree(t.d_order);
-    if (t.d_inst_xf) (void)hipFree(t.d_inst_xf);
-    if (t.d_area) (void)hipFree(t.d_area);
-    if (t.d_inst_src) (void)hipFree((void *)t.d_inst_src);
-    t.d_nodes = t.d_prims = nullptr; t.d_inst_inv = nullptr; t.d_inst_identity = nullptr;
-    t.d_node_box = t.d_node_ref = t.d_inst_xf = t.d_area = nullptr; t.d_inst_src = nullptr; t.d_order = nullptr;
-    t.area_pending = false;
-}
-void free_tlas_host(Tlas &t) {
-    if (t.h_area) (void)hipHostFree(t.h_area);
-    if (t.area_ready) (void)hipEventDestroy(t.area_ready);
-    t.h_area = nullptr; t.area_ready = nullptr;
-}
-
-// Per-instance tables of a set of instances: object->world, world->object, identity flags, and the
-// largest |coordinate| of the transformed BLAS boxes (what the padding of the tree is derived from).
-float instance_tables(const std::vector<HrtInstance> &inst, const std::vector<std::shared_ptr<Blas>> &blas,
-                      std::vector<float> &xf, std::vector<float> &inv, std::vector<uint32_t> &ident) {
-    const size_t n = inst.size();
-    xf.assign(12 * std::max<size_t>(n, 1), 0.0f); inv.assign(12 * std::max<size_t>(n, 1), 0.0f); ident.assign(std::max<size_t>(n, 1), 1u);
-    float smax = 1.0f;
-    for (size_t i = 0; i < n; ++i) {
-        const float *m = inst[i].transform;
-        std::memcpy(&xf[12 * i], m, 12 * sizeof(float));
-        const bool id = is_identity(m);
-        ident[i] = id ? 1u : 0u;
-        invert_affine(m, &inv[12 * i]);
-        const Blas &b = *blas[i];
-        if ((inst[i].visibilityMask & 1u) == 0 || !(b.lo[0] <= b.hi[0])) continue;
-        for (int c = 0; c < 8; ++c) {
-            const float q[3] = {(c & 1) ? b.hi[0] : b.lo[0], (c & 2) ? b.hi[1] : b.lo[1], (c & 4) ? b.hi[2] : b.lo[2]};
-            float w[3];
-            if (id) { w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; } else xf_point(m, q, w);
-            for (int a = 0; a < 3; ++a) if (std::isfinite(w[a])) smax = std::max(smax, std::fabs(w[a]));
-        }
-    }
-    return smax;
-}
-
-void launch_refit_phases(RefitArgs ra, const std::vector<std::pair<uint32_t, uint32_t>> &phases, hipStream_t s);
-
-// Object-space BVH8 of one BLAS (built once): the subtree every instance of it gets in a tree over instances.
-void ensure_template(Blas &b) {
-    std::lock_guard<std::mutex> lk(b.tmpl_mu);
-    if (b.tmpl_built) return;
-    std::vector<BuildPrim> prims;
-    prims.reserve(b.n_prims);
-    for (uint32_t p = 0; p < b.n_prims; ++p) {
-        BuildPrim bp; std::memset(&bp, 0, sizeof bp);
-        if (b.kind == kPrimKindTriangle) {
-            triangle_world(&b.verts[9 * (size_t)p], nullptr, true, bp.rec.a, bp.rec.b, bp.rec.c, bp.lo, bp.hi);
-            bp.rec.kind = kPrimKindTriangle;
-        } else {
-            const float *c = &b.centers[3 * (size_t)p];
-            bp.rec.a[0] = c[0]; bp.rec.a[1] = c[1]; bp.rec.a[2] = c[2]; bp.rec.b[0] = b.radii[p]; bp.rec.kind = kPrimKindSphere;
-            sphere_world_bounds(c, b.radii[p], nullptr, true, bp.lo, bp.hi);
-        }
-        bp.rec.prim = p;
-        if (finite_box(bp.lo, bp.hi)) prims.push_back(bp);
-    }
-    build_bvh8(prims, b.tmpl, 0);
-    b.tmpl_built = true;
-}
-
-// Build a TLAS on the host and upload it together with the tables the device refit needs (hrt_tlas_update).
-//  * merged (default of hrt_tlas_build): every instance is flattened into world space and ONE tree is built over all
-//    primitives -- the best tree, at the price of a full SAH build;
-//  * instanced: a top tree over the instances' boxes whose leaves are per-instance copies of object-space template
-//    trees; only the topology comes from the host (milliseconds for thousands of instances), the device refit
-//    computes every box and world-space record.  The shape the reference's own scenes have (particles instancing a
-//    few shapes); used when a refitted tree has degraded and has to be rebuilt while frames are being rendered.
-// Either way the result is one world-space BVH8: the traversal kernels do not know the difference.
-int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s, bool instanced) {
-    const uint32_t n = (uint32_t)inst.size();
-    std::vector<std::shared_ptr<Blas>> refs(n);
-    size_t total = 0;
-    {
-        std::lock_guard<std::mutex> lk(ctx->mu);
-        for (uint32_t i = 0; i < n; ++i) {
-            auto it = ctx->blas.find(inst[i].traversableHandle);
-            if (it == ctx->blas.end()) return fail(ctx, HRT_ERR_INVALID, "instance %u: unknown BLAS handle 0x%llx", i, (unsigned long long)inst[i].traversableHandle);
-            refs[i] = it->second;
-            total += it->second->n_prims;
-        }
-    }
-    const float scene_scale = instance_tables(inst, refs, t.h_xf, t.h_inv, t.h_ident);
-    t.sbt_offset.assign(n, 0); t.kind.assign(n, 0); t.has_spheres = false;
-    t.sig_handle.assign(n, 0); t.sig_visibility.assign(n, 0);
-    for (uint32_t i = 0; i < n; ++i) {
-        t.sbt_offset[i] = inst[i].sbtOffset;
-        t.kind[i] = refs[i]->kind;
-        t.sig_handle[i] = inst[i].traversableHandle; t.sig_visibility[i] = inst[i].visibilityMask & 1u;
-        if ((inst[i].visibilityMask & 1u) != 0 && refs[i]->kind == kPrimKindSphere && refs[i]->n_prims) t.has_spheres = true;
-    }
-    std::vector<uint32_t> order;
-    t.phases.clear();
-    if (instanced) {
-        std::vector<const Bvh8 *> tmpl(n, nullptr);
-        std::vector<float> box(6 * (size_t)std::max(n, 1u), 0.0f);
-        for (uint32_t i = 0; i < n; ++i) {
-            Blas &b = *refs[i];
-            if ((inst[i].visibilityMask & 1u) == 0 || !(b.lo[0] <= b.hi[0])) continue;      // the reference traces with mask 1 (Shader.cu:71)
-            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-            for (int c = 0; c < 8; ++c) {
-                const float q[3] = {(c & 1) ? b.hi[0] : b.lo[0], (c & 2) ? b.hi[1] : b.lo[1], (c & 4) ? b.hi[2] : b.lo[2]};
-                float w[3];
-                if (t.h_ident[i]) { w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; } else xf_point(inst[i].transform, q, w);
-                for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], w[a]); hi[a] = std::fmax(hi[a], w[a]); }
-            }
-            if (!finite_box(lo, hi)) continue;                                                 // a NaN transform: nothing to hit
-            ensure_template(b);
-            tmpl[i] = &b.tmpl;
-            for (int a = 0; a < 3; ++a) { box[6 * (size_t)i + a] = lo[a]; box[6 * (size_t)i + 3 + a] = hi[a]; }
-        }
-        InstancedTree it;
-        assemble_instanced_bvh8(tmpl, box, it);
-        t.bvh = Bvh8();
-        t.bvh.nodes = std::move(it.nodes); t.bvh.prims = std::move(it.prims);
-        t.bvh.n_triangles = it.n_triangles; t.bvh.n_spheres = it.n_spheres; t.bvh.max_depth = it.max_depth;
-        t.bvh.node_box.assign(6 * t.bvh.nodes.size(), 0.0f);
-        t.bvh.node_ref.assign(2 * t.bvh.nodes.size(), 0.0f);
-        for (size_t i = 0; i < it.weight.size(); ++i) t.bvh.node_ref[2 * i] = it.weight[i];
-        order = std::move(it.order);
-        for (size_t h = 0; h + 1 < it.phase_begin.size(); ++h) t.phases.emplace_back(it.phase_begin[h], it.phase_begin[h + 1] - it.phase_begin[h]);
-    } else {
-        std::vector<BuildPrim> prims;
-        prims.reserve(total);
-        for (uint32_t i = 0; i < n; ++i) {
-            const Blas *b = refs[i].get();
-            const float *m = inst[i].transform;
-            const bool id = t.h_ident[i] != 0u;
-            if ((inst[i].visibilityMask & 1u) == 0) continue;       // the reference traces with mask 1 (Shader.cu:71)
-            for (uint32_t p = 0; p < b->n_prims; ++p) {
-                BuildPrim bp; std::memset(&bp, 0, sizeof bp);
-                if (b->kind == kPrimKindTriangle) {
-                    triangle_world(&b->verts[9 * (size_t)p], m, id, bp.rec.a, bp.rec.b, bp.rec.c, bp.lo, bp.hi);
-                    bp.rec.prim = p; bp.rec.inst = i; bp.rec.kind = kPrimKindTriangle;
-                } else {
-                    const float *c = &b->centers[3 * (size_t)p];
-                    bp.rec.a[0] = c[0]; bp.rec.a[1] = c[1]; bp.rec.a[2] = c[2]; bp.rec.prim = p;
-                    bp.rec.b[0] = b->radii[p]; bp.rec.inst = i; bp.rec.kind = kPrimKindSphere;
-                    sphere_world_bounds(c, b->radii[p], m, id, bp.lo, bp.hi);
-                }
-                // NaN / Inf geometry never hits anything; keep it out of the tree
-                if (!finite_box(bp.lo, bp.hi)) continue;
-                prims.push_back(bp);
-            }
-        }
-        build_bvh8(prims, t.bvh, 0, scene_scale);
-        for (size_t l = t.bvh.level_begin.size() - 1; l-- > 0;) t.phases.emplace_back(t.bvh.level_begin[l], t.bvh.level_begin[l + 1] - t.bvh.level_begin[l]);
-    }
-    if (2 * t.bvh.max_depth + 2 > (uint32_t)(8 + 56))
-        return fail(ctx, HRT_ERR_INVALID, "BVH depth %u exceeds the traversal stack", t.bvh.max_depth);
-
-    free_tlas_device(t);
-    t.n_instances = n;
-    t.blas_refs = std::move(refs);
-    t.node_stride = (uint32_t)ctx->node_stride; t.prim_stride = (uint32_t)ctx->prim_stride;
-    const size_t n_nodes = t.bvh.nodes.size(), n_prims = t.bvh.prims.size();
-    const size_t nb = (size_t)t.node_stride * n_nodes;
-    const size_t pb = (size_t)t.prim_stride * std::max<size_t>(n_prims, 1);
-    std::vector<const void *> src(std::max(n, 1u), nullptr);
-    for (uint32_t i = 0; i < n; ++i) src[i] = t.blas_refs[i]->d_verts;
-    HIP_TRY(ctx, hipMalloc(&t.d_nodes, nb));
-    HIP_TRY(ctx, hipMalloc(&t.d_prims, pb));
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_inv, sizeof(float) * t.h_inv.size()));
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_xf, sizeof(float) * t.h_xf.size()));
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_identity, sizeof(uint32_t) * t.h_ident.size()));
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_src, sizeof(void *) * src.size()));
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_node_box, sizeof(float) * std::max<size_t>(t.bvh.node_box.size(), 6)));
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_node_ref, sizeof(float) * std::max<size_t>(t.bvh.node_ref.size(), 2)));
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_area, sizeof(float)));
-    if (!order.empty()) HIP_TRY(ctx, hipMalloc((void **)&t.d_order, sizeof(uint32_t) * order.size()));
-    if (!t.h_area) HIP_TRY(ctx, hipHostMalloc((void **)&t.h_area, sizeof(float), hipHostMallocDefault));
-    if (!t.area_ready) HIP_TRY(ctx, hipEventCreateWithFlags(&t.area_ready, hipEventDisableTiming));
-    if (t.node_stride == sizeof(Bvh8Node) && t.prim_stride == sizeof(PrimRecord)) {
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, t.bvh.nodes.data(), nb, hipMemcpyHostToDevice, s));
-        if (n_prims) HIP_TRY(ctx, hipMemcpyAsync(t.d_prims, t.bvh.prims.data(), sizeof(PrimRecord) * n_prims, hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
-    } else {
-        std::vector<unsigned char> hn(nb, 0), hp(pb, 0);
-        for (size_t i = 0; i < n_nodes; ++i) std::memcpy(&hn[i * t.node_stride], &t.bvh.nodes[i], sizeof(Bvh8Node));
-        for (size_t i = 0; i < n_prims; ++i) std::memcpy(&hp[i * t.prim_stride], &t.bvh.prims[i], sizeof(PrimRecord));
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, hn.data(), nb, hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_prims, hp.data(), pb, hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
-    }
-    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_inv, t.h_inv.data(), sizeof(float) * t.h_inv.size(), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_xf, t.h_xf.data(), sizeof(float) * t.h_xf.size(), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_identity, t.h_ident.data(), sizeof(uint32_t) * t.h_ident.size(), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync((void *)t.d_inst_src, src.data(), sizeof(void *) * src.size(), hipMemcpyHostToDevice, s));
-    if (!t.bvh.node_box.empty())
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_node_box, t.bvh.node_box.data(), sizeof(float) * t.bvh.node_box.size(), hipMemcpyHostToDevice, s));
-    if (!t.bvh.node_ref.empty())
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_node_ref, t.bvh.node_ref.data(), sizeof(float) * t.bvh.node_ref.size(), hipMemcpyHostToDevice, s));
-    if (!order.empty()) HIP_TRY(ctx, hipMemcpyAsync(t.d_order, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice, s));
-    if (instanced && n_prims) {
-        // the device computes what the host left blank: world-space records, boxes, origins, exponents, quantised
-        // children, and the built areas the quality guard compares later refits with
-        RefitArgs ra{};
-        ra.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); ra.node_stride = t.node_stride;
-        ra.prims = reinterpret_cast<unsigned char *>(t.d_prims); ra.prim_stride = t.prim_stride;
-        ra.node_box = t.d_node_box; ra.node_ref = t.d_node_ref; ra.inst_xf = t.d_inst_xf; ra.inst_identity = t.d_inst_identity;
-        ra.inst_src = t.d_inst_src; ra.pad = 4e-6f * std::max(1.0f, scene_scale); ra.order = t.d_order; ra.write_reference = 1u;
-        launch_refit_phases(ra, t.phases, s);
-        HIP_TRY(ctx, hipGetLastError());
-    }
-    HIP_TRY(ctx, hipStreamSynchronize(s));
-    t.instanced = instanced;
-    t.generation++;
-    t.rebuilds++; ctx->tlas_rebuilds++;
-    return HRT_OK;
-}
-
-int download_instances(HrtContext *ctx, const HrtInstance *d_instances, uint32_t n, hipStream_t s, std::vector<HrtInstance> &inst) {
-    inst.resize(n);
-    if (n) {
-        HIP_TRY(ctx, hipMemcpyAsync(inst.data(), d_instances, sizeof(HrtInstance) * (size_t)n, hipMemcpyDeviceToHost, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
-    }
-    return HRT_OK;
-}
-
-constexpr int kMaxSubTiles = 8;
-
 int ensure_workspace(HrtContext *ctx, uint32_t n, uint32_t height) {
     Workspace &w = ctx->ws;
     if (n > w.capacity) {
@@ -476,20 +82,6 @@ int ensure_workspace(HrtContext *ctx, uint32_t n, uint32_t height) {
     return HRT_OK;
 }
 
-struct Timer {
-    HrtContext *ctx; hipStream_t s; bool on; TimedSpan span{};
-    Timer(HrtContext *c, hipStream_t st, int kind) : ctx(c), s(st), on((c->flags & HRT_CTX_TIMING) != 0) {
-        if (!on) { ctx->kernel_launches[kind]++; return; }
-        span.kind = kind; span.a = next(); span.b = next();
-        (void)hipEventRecord(span.a, s);
-    }
-    ~Timer() { if (on) { (void)hipEventRecord(span.b, s); ctx->spans.push_back(span); } }
-    hipEvent_t next() {
-        if (ctx->events_used == ctx->event_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ctx->event_pool.push_back(e); }
-        return ctx->event_pool[ctx->events_used++];
-    }
-};
-
 void drain_spans(HrtContext *ctx) {
     for (const TimedSpan &sp : ctx->spans) {
         float ms = 0.0f;
@@ -499,49 +91,15 @@ void drain_spans(HrtContext *ctx) {
     ctx->events_used = 0;
 }
 
-// The phases of a refit, children before parents: wide phases get a launch each, the narrow ones at the end (the top
-// of the tree, or all of a small tree) run in one single-workgroup launch.
-void launch_refit_phases(RefitArgs ra, const std::vector<std::pair<uint32_t, uint32_t>> &phases, hipStream_t s) {
-    size_t tail = phases.size();
-    while (tail > 0 && phases.size() - tail < kRefitTopLevels && phases[tail - 1].second <= kRefitTopLevelNodes) --tail;
-    for (size_t i = 0; i < tail; ++i) { ra.first_node = phases[i].first; ra.n_nodes = phases[i].second; launch_refit_level(ra, s); }
-    RefitLevels top{};
-    for (size_t i = tail; i < phases.size(); ++i) { top.first[top.n_levels] = phases[i].first; top.count[top.n_levels] = phases[i].second; ++top.n_levels; }
-    launch_refit_top(ra, top, s);
-}
+}  // namespace hrt
 
-// Device refit of a built tree under new instance transforms: upload the per-instance tables, then one
-// k_refit_level launch per tree level, deepest first.  Asynchronous on s.
-int refit_tlas(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s) {
-    const float scene_scale = instance_tables(inst, t.blas_refs, t.h_xf, t.h_inv, t.h_ident);
-    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_inv, t.h_inv.data(), sizeof(float) * t.h_inv.size(), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_xf, t.h_xf.data(), sizeof(float) * t.h_xf.size(), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_identity, t.h_ident.data(), sizeof(uint32_t) * t.h_ident.size(), hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemsetAsync(t.d_area, 0, sizeof(float), s));
-    RefitArgs ra{};
-    ra.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); ra.node_stride = t.node_stride;
-    ra.prims = reinterpret_cast<unsigned char *>(t.d_prims); ra.prim_stride = t.prim_stride;
-    ra.node_box = t.d_node_box; ra.node_ref = t.d_node_ref; ra.inst_xf = t.d_inst_xf; ra.inst_identity = t.d_inst_identity; ra.inst_src = t.d_inst_src;
-    ra.pad = 4e-6f * std::max(1.0f, scene_scale);
-    ra.area_sum = t.d_area;
-    ra.order = t.d_order;
-    { Timer tm(ctx, s, HRT_K_REFIT); launch_refit_phases(ra, t.phases, s); }
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(t.h_area, t.d_area, sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipEventRecord(t.area_ready, s));
-    t.area_pending = true;
-    t.refits++; ctx->tlas_refits++;
-    return HRT_OK;
-}
-
-}  // namespace
 
 // ======================================================================================
 extern "C" {
 
 const char *hrt_version(void) { return "hrt 0.1 (gfx950 wavefront path tracer)"; }
 
-const char *hrt_last_error(const HrtContext *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+const char *hrt_last_error(const HrtContext *ctx) { return ctx ? ctx->error.c_str() : hrt::create_error(); }
 
 int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (!out_ctx) return fail(nullptr, HRT_ERR_INVALID, "out_ctx is NULL");
@@ -609,146 +167,6 @@ int hrt_ctx_destroy(HrtContext *ctx) {
     for (hipStream_t st : ctx->sub_streams) (void)hipStreamDestroy(st);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
     delete ctx;
-    return HRT_OK;
-}
-
-// ---- acceleration structures ---------------------------------------------------------
-int hrt_blas_build_triangles(HrtContext *ctx, const HrtFloat3 *d_vertices, uint32_t n_vertices, void *stream, HrtTraversable *out_blas) {
-    if (!ctx || !out_blas) return HRT_ERR_INVALID;
-    if (n_vertices % 3 != 0) return fail(ctx, HRT_ERR_INVALID, "n_vertices (%u) is not a multiple of 3", n_vertices);
-    if (n_vertices && !d_vertices) return fail(ctx, HRT_ERR_INVALID, "d_vertices is NULL");
-    (void)hipSetDevice(ctx->device);
-    std::shared_ptr<Blas> b(new Blas());
-    b->kind = kPrimKindTriangle; b->n_prims = n_vertices / 3;
-    b->verts.resize(3 * (size_t)n_vertices);
-    if (n_vertices) {
-        const size_t bytes = sizeof(float) * 3 * (size_t)n_vertices;
-        HIP_TRY(ctx, hipMalloc((void **)&b->d_verts, bytes));
-        HIP_TRY(ctx, hipMemcpyAsync(b->d_verts, d_vertices, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-        HIP_TRY(ctx, hipMemcpyAsync(b->verts.data(), d_vertices, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
-        HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
-        for (size_t v = 0; v < n_vertices; ++v) {
-            const float *q = &b->verts[3 * v];
-            if (!(std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2]))) continue;
-            for (int a = 0; a < 3; ++a) { b->lo[a] = std::fmin(b->lo[a], q[a]); b->hi[a] = std::fmax(b->hi[a], q[a]); }
-        }
-    }
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    const uint64_t h = ctx->next_handle++;
-    ctx->blas[h] = std::move(b);
-    *out_blas = h;
-    return HRT_OK;
-}
-
-int hrt_blas_build_spheres(HrtContext *ctx, const HrtFloat3 *d_centers, const float *d_radii, uint32_t n, void *stream, HrtTraversable *out_blas) {
-    if (!ctx || !out_blas) return HRT_ERR_INVALID;
-    if (n && (!d_centers || !d_radii)) return fail(ctx, HRT_ERR_INVALID, "sphere arrays are NULL");
-    (void)hipSetDevice(ctx->device);
-    std::shared_ptr<Blas> b(new Blas());
-    b->kind = kPrimKindSphere; b->n_prims = n;
-    b->centers.resize(3 * (size_t)n); b->radii.resize(n);
-    if (n) {
-        HIP_TRY(ctx, hipMemcpyAsync(b->centers.data(), d_centers, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, (hipStream_t)stream));
-        HIP_TRY(ctx, hipMemcpyAsync(b->radii.data(), d_radii, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, (hipStream_t)stream));
-        HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
-        for (size_t p = 0; p < n; ++p) {
-            const float *c = &b->centers[3 * p]; const float rr = std::fabs(b->radii[p]);
-            if (!(std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(rr))) continue;
-            for (int a = 0; a < 3; ++a) { b->lo[a] = std::fmin(b->lo[a], c[a] - rr); b->hi[a] = std::fmax(b->hi[a], c[a] + rr); }
-        }
-    }
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    const uint64_t h = ctx->next_handle++;
-    ctx->blas[h] = std::move(b);
-    *out_blas = h;
-    return HRT_OK;
-}
-
-int hrt_blas_destroy(HrtContext *ctx, HrtTraversable blas) {
-    if (!ctx) return HRT_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    return ctx->blas.erase(blas) ? HRT_OK : fail(ctx, HRT_ERR_INVALID, "unknown BLAS handle");
-}
-
-int hrt_tlas_build(HrtContext *ctx, const HrtInstance *d_instances, uint32_t n, void *stream, HrtTraversable *out_tlas) {
-    if (!ctx || !out_tlas) return HRT_ERR_INVALID;
-    if (n && !d_instances) return fail(ctx, HRT_ERR_INVALID, "d_instances is NULL");
-    (void)hipSetDevice(ctx->device);
-    std::unique_ptr<Tlas> t(new Tlas());
-    std::vector<HrtInstance> inst;
-    int rc = download_instances(ctx, d_instances, n, (hipStream_t)stream, inst);
-    if (rc == HRT_OK) rc = build_tlas_into(ctx, *t, inst, (hipStream_t)stream, ctx->tlas_instanced > 0);
-    if (rc != HRT_OK) { free_tlas_device(*t); free_tlas_host(*t); return rc; }
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    const uint64_t h = ctx->next_handle++;
-    ctx->tlas[h] = std::move(t);
-    *out_tlas = h;
-    return HRT_OK;
-}
-
-// updateIAS (RendererImpl.cu:210-242): the instance transforms changed.  When nothing else did, the tree
-// keeps its topology and is refitted on the device (refit.hip), asynchronously on `stream`; a change of
-// BLAS handle / visibility, or a refitted tree that has degraded past refit_rebuild_ratio, rebuilds.
-int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_instances, uint32_t n, void *stream) {
-    if (!ctx) return HRT_ERR_INVALID;
-    (void)hipSetDevice(ctx->device);
-    hipStream_t s = (hipStream_t)stream;
-    Tlas *t;
-    { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->tlas.find(tlas); if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle"); t = it->second.get(); }
-    if (n != t->n_instances) return fail(ctx, HRT_ERR_INVALID, "update must keep the instance count (%u != %u)", n, t->n_instances);
-    if (n && !d_instances) return fail(ctx, HRT_ERR_INVALID, "d_instances is NULL");
-    std::vector<HrtInstance> inst;
-    const int rc = download_instances(ctx, d_instances, n, s, inst);
-    if (rc != HRT_OK) return rc;
-    bool same = ctx->refit != 0 && !t->bvh.prims.empty();
-    for (uint32_t i = 0; i < n && same; ++i)
-        same = inst[i].traversableHandle == t->sig_handle[i] && (inst[i].visibilityMask & 1u) == t->sig_visibility[i];
-    if (same && t->area_pending) {
-        HIP_TRY(ctx, hipEventSynchronize(t->area_ready));
-        t->area_pending = false;
-        // a refit keeps the topology: once the boxes have grown this much, a fresh build pays for itself
-        ctx->tlas_refit_ratio = (double)*t->h_area;
-        if (!(ctx->tlas_refit_ratio <= (double)ctx->refit_rebuild_ratio)) same = false;
-    }
-    if (same) {
-        bool sbt_changed = false;
-        for (uint32_t i = 0; i < n; ++i) if (inst[i].sbtOffset != t->sbt_offset[i]) { t->sbt_offset[i] = inst[i].sbtOffset; sbt_changed = true; }
-        if (sbt_changed) t->generation++;                 // the material tables are re-derived at the next launch
-        return refit_tlas(ctx, *t, inst, s);
-    }
-    HIP_TRY(ctx, hipDeviceSynchronize());                 // launches on other streams may still read the old tree
-    // a rebuild in the middle of an animation: the tree over instances costs milliseconds instead of a full SAH build
-    return build_tlas_into(ctx, *t, inst, s, ctx->tlas_instanced >= 0 && n >= 2);
-}
-
-int hrt_pose_instances(HrtContext *ctx, HrtInstance *d_instances, uint32_t first_instance, uint32_t n_particles,
-                       const HrtParticleState *d_current, const HrtParticleState *d_next, const HrtPoseParams *h_params, void *stream) {
-    if (!ctx) return HRT_ERR_INVALID;
-    if (n_particles == 0) return HRT_OK;
-    if (!d_instances || !d_current || !d_next || !h_params) return fail(ctx, HRT_ERR_INVALID, "hrt_pose_instances: NULL argument");
-    if (h_params->frame_count == 0) return fail(ctx, HRT_ERR_INVALID, "hrt_pose_instances: frame_count is 0");
-    if ((reinterpret_cast<uintptr_t>(d_instances) & 15u) || (reinterpret_cast<uintptr_t>(d_current) & 15u) || (reinterpret_cast<uintptr_t>(d_next) & 15u))
-        return fail(ctx, HRT_ERR_INVALID, "hrt_pose_instances: arrays must be 16-byte aligned");
-    (void)hipSetDevice(ctx->device);
-    PoseArgs a{};
-    a.instances = d_instances; a.first_instance = first_instance; a.n = n_particles;
-    a.current = reinterpret_cast<const float4 *>(d_current); a.next = reinterpret_cast<const float4 *>(d_next);
-    a.duration = h_params->duration; a.frame = h_params->frame; a.frame_count = h_params->frame_count;
-    std::memcpy(a.offset, &h_params->particle_offset, 12); std::memcpy(a.scale, &h_params->particle_scale, 12);
-    launch_pose_instances(a, (hipStream_t)stream);
-    HIP_TRY(ctx, hipGetLastError());
-    return HRT_OK;
-}
-
-int hrt_tlas_destroy(HrtContext *ctx, HrtTraversable tlas) {
-    if (!ctx) return HRT_ERR_INVALID;
-    (void)hipSetDevice(ctx->device);
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    auto it = ctx->tlas.find(tlas);
-    if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle");
-    (void)hipDeviceSynchronize();
-    free_tlas_device(*it->second); free_tlas_host(*it->second);
-    ctx->tlas.erase(it);
     return HRT_OK;
 }
 
@@ -1158,59 +576,6 @@ int hrt_debug_set_linear_output(HrtContext *ctx, HrtFloat4 *d_linear) {
     if (!ctx) return HRT_ERR_INVALID;
     ctx->d_linear = reinterpret_cast<float4 *>(d_linear);
     return HRT_OK;
-}
-
-static int fill_blob(const Bvh8 &b, HrtBvhBlob *out) {
-    std::memset(out, 0, sizeof *out);
-    out->n_nodes = b.nodes.size(); out->n_triangles = b.prims.size();
-    out->nodes = std::malloc(std::max<size_t>(1, sizeof(Bvh8Node) * b.nodes.size()));
-    out->triangles = std::malloc(std::max<size_t>(1, sizeof(PrimRecord) * b.prims.size()));
-    if (!out->nodes || !out->triangles) { std::free(out->nodes); std::free(out->triangles); std::memset(out, 0, sizeof *out); return HRT_ERR_OOM; }
-    std::memcpy(out->nodes, b.nodes.data(), sizeof(Bvh8Node) * b.nodes.size());
-    std::memcpy(out->triangles, b.prims.data(), sizeof(PrimRecord) * b.prims.size());
-    for (int a = 0; a < 3; ++a) { out->bounds[a] = b.lo[a]; out->bounds[3 + a] = b.hi[a]; }
-    return HRT_OK;
-}
-
-int hrt_host_build_bvh8(const float *h_triangles, uint32_t n_triangles, HrtBvhBlob *out) {
-    if (!out || (n_triangles && !h_triangles)) return HRT_ERR_INVALID;
-    std::vector<BuildPrim> prims(n_triangles);
-    for (uint32_t p = 0; p < n_triangles; ++p) {
-        BuildPrim &bp = prims[p]; std::memset(&bp, 0, sizeof bp);
-        const float *v = h_triangles + 9 * (size_t)p;
-        for (int a = 0; a < 3; ++a) {
-            bp.rec.a[a] = v[a]; bp.rec.b[a] = v[3 + a] - v[a]; bp.rec.c[a] = v[6 + a] - v[a];
-            bp.lo[a] = std::fmin(v[a], std::fmin(v[3 + a], v[6 + a]));
-            bp.hi[a] = std::fmax(v[a], std::fmax(v[3 + a], v[6 + a]));
-        }
-        bp.rec.prim = p; bp.rec.inst = 0; bp.rec.kind = kPrimKindTriangle;
-    }
-    Bvh8 b;
-    build_bvh8(prims, b, 0);
-    const char *err = validate_bvh8(b);
-    if (err[0]) { g_create_error = std::string("bvh8 validation: ") + err; return HRT_ERR_STATE; }
-    return fill_blob(b, out);
-}
-
-int hrt_tlas_download(HrtContext *ctx, HrtTraversable tlas, HrtBvhBlob *out) {
-    if (!ctx || !out) return HRT_ERR_INVALID;
-    (void)hipSetDevice(ctx->device);
-    Tlas *t;
-    { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->tlas.find(tlas); if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle"); t = it->second.get(); }
-    const int rc = fill_blob(t->bvh, out);
-    if (rc != HRT_OK) return rc;
-    // the device copy is the truth: a refit rewrites it in place
-    HIP_TRY(ctx, hipDeviceSynchronize());
-    const size_t n_nodes = t->bvh.nodes.size(), n_prims = t->bvh.prims.size();
-    HIP_TRY(ctx, hipMemcpy2D(out->nodes, sizeof(Bvh8Node), t->d_nodes, t->node_stride, sizeof(Bvh8Node), n_nodes, hipMemcpyDeviceToHost));
-    if (n_prims) HIP_TRY(ctx, hipMemcpy2D(out->triangles, sizeof(PrimRecord), t->d_prims, t->prim_stride, sizeof(PrimRecord), n_prims, hipMemcpyDeviceToHost));
-    return HRT_OK;
-}
-
-void hrt_host_free(HrtBvhBlob *blob) {
-    if (!blob) return;
-    std::free(blob->nodes); std::free(blob->triangles);
-    std::memset(blob, 0, sizeof *blob);
 }
 
 }  // extern "C"

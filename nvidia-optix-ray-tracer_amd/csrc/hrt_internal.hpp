@@ -1,0 +1,181 @@
+// hrt_internal.hpp -- what the translation units of libhrt.so share: the objects behind the opaque handles of
+// include/hrt.h (context, BLAS, TLAS, workspace), error plumbing and the helpers that cross file boundaries.
+// hrt_api.cpp: context, materials, RNG, the launch, measurement.  hrt_accel.cpp: acceleration structures
+// (build, per-frame refit, trees over instances, poses, download).
+#pragma once
+#include "../../include/hrt.h"
+#include "bvh8.h"
+#include "bvh8_geom.h"
+#include "device_types.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+
+namespace hrt {
+
+struct Blas {
+    uint32_t kind = kPrimKindTriangle;
+    uint32_t n_prims = 0;
+    std::vector<float> verts;        // triangles: 9 floats each (object space)
+    std::vector<float> centers;      // spheres: 3 floats each
+    std::vector<float> radii;
+    float *d_verts = nullptr;        // device copy of verts: the refit re-derives the world-space records from it
+                                     // (the caller may free its vertex buffer after the build, RendererMesh.cu:116)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};   // object-space bounds
+    // object-space BVH8 of this geometry alone: the per-instance subtree of the trees over instances (built on first use)
+    std::mutex tmpl_mu; bool tmpl_built = false; Bvh8 tmpl;
+    ~Blas() { if (d_verts) (void)hipFree(d_verts); }
+};
+
+struct Tlas {
+    uint32_t n_instances = 0;
+    std::vector<uint32_t> sbt_offset;      // per instance
+    std::vector<uint32_t> kind;            // per instance: triangle / sphere BLAS
+    Bvh8 bvh;                               // host copy (download / stats)
+    void *d_nodes = nullptr, *d_prims = nullptr;
+    float *d_inst_inv = nullptr;
+    uint32_t *d_inst_identity = nullptr;
+    bool has_spheres = false;
+    uint32_t node_stride = 80, prim_stride = 48;
+    uint64_t generation = 0;
+    // refit (hrt_tlas_update): what must stay the same, and the device tables the refit kernel reads
+    std::vector<std::shared_ptr<Blas>> blas_refs;       // keeps the source geometry alive
+    std::vector<uint64_t> sig_handle; std::vector<uint32_t> sig_visibility;
+    std::vector<float> h_xf, h_inv; std::vector<uint32_t> h_ident;   // staging of the per-instance uploads
+    float *d_node_box = nullptr, *d_node_ref = nullptr, *d_inst_xf = nullptr, *d_area = nullptr;
+    uint32_t *d_order = nullptr;                         // trees over instances: refit order (NULL: breadth-first index ranges)
+    std::vector<std::pair<uint32_t, uint32_t>> phases;   // (first, count) in processing order, children before parents
+    bool instanced = false;
+    const void **d_inst_src = nullptr;
+    float *h_area = nullptr;                             // pinned: area sum of the last refit
+    hipEvent_t area_ready = nullptr; bool area_pending = false;
+    uint64_t refits = 0, rebuilds = 0;
+};
+
+// per-depth counters, zeroed once per sample: bin sizes + 8 slice counters on 128-byte lines of their own
+struct StageCounters { uint32_t bin_count[32]; uint32_t fetch[8 * 32]; };
+static_assert(sizeof(StageCounters) == 128 + 8 * 128, "stage counters layout");
+
+struct DeviceStats { uint64_t rays_closest, rays_any, nodes_closest, prims_closest, nodes_any, prims_any; uint64_t debug[4]; };
+
+// Everything one sample needs besides the per-pixel state.  Two sets (sample parity): the stages of
+// two consecutive samples overlap in time (hrt_render_launch), never more.
+struct SampleSet {
+    RayRec *rays[2] = {nullptr, nullptr};  // depth d reads rays[(d-1)&1], shade writes rays[d&1]
+    float4 *hit_tuvp = nullptr; uint32_t *hit_inst = nullptr;
+    uint32_t *bin_items = nullptr;          // kNumBins x n ray indices
+    uint32_t *chain = nullptr;              // 4 instance indices per tile pixel
+    float4 *result = nullptr;               // the sample's linear radiance per tile pixel
+    StageCounters *stages = nullptr;        // [sub-tile][kRayTraceDepth + 1]
+};
+struct Workspace {
+    uint32_t capacity = 0, rows_capacity = 0;
+    SampleSet set[2];
+    float4 *accum = nullptr;
+    uint32_t *rows = nullptr;
+};
+
+struct TimedSpan { int kind; hipEvent_t a, b; };
+
+}  // namespace hrt
+
+using namespace hrt;
+
+struct HrtContext {
+    int device = 0;
+    uint32_t flags = 0;
+    int n_cu = 256;
+    std::string error;
+    std::mutex mu;
+    std::unordered_map<uint64_t, std::shared_ptr<hrt::Blas>> blas;
+    std::unordered_map<uint64_t, std::unique_ptr<hrt::Tlas>> tlas;
+    uint64_t next_handle = 0x1000;
+    // materials
+    std::vector<HrtSbtRecord> records;
+    HrtMissParams miss{{0.7f, 0.8f, 0.9f}};      // reference default, src/Global/RendererMesh.cu:262
+    bool have_records = false;
+    uint64_t materials_generation = 0;
+    // per-launch device tables derived from (tlas, records)
+    HitGroup *d_hitgroups = nullptr; uint32_t *d_inst_program = nullptr; uint32_t table_capacity = 0;
+    uint64_t table_tlas = 0, table_tlas_gen = 0, table_mat_gen = ~0ull;
+    bool program_present[kNumPrograms] = {false, false, false, false};
+    // rng
+    uint32_t *d_jump = nullptr;
+    // workspace + stats
+    Workspace ws;
+    std::vector<uint32_t> h_rows; HrtTile rows_tile{0, 0, 0, 0, 0}; uint32_t rows_w = 0, rows_h = 0;
+    DeviceStats *d_stats = nullptr;
+    uint64_t paths = 0;
+    uint64_t last_tlas = 0;
+    std::vector<TimedSpan> spans; std::vector<hipEvent_t> event_pool; size_t events_used = 0;
+    double kernel_ms[HRT_K_COUNT] = {0}; uint64_t kernel_launches[HRT_K_COUNT] = {0};
+    float4 *d_linear = nullptr;
+    int refill_threshold = 16;                  // wavefront mode; fused mode: fused_refill_threshold
+    int fused_refill_threshold = 24, fused_fetch_chunk = 16;   // measured optimum of the fused path mode (profiles/r01_sweep_fused_*.txt)
+    int traverse_blocks_per_cu = 16;            // one-wave workgroups of the traverse kernel per CU
+    bool traverse_blocks_auto = true;           // fused mode: fewer of them for small tiles (not when the env knob is set)
+    int postpone_pct = 25;
+    int tail_split = 1;
+    int node_stride = 80, prim_stride = 64;     // bytes between records in HBM (80/48 packed; 128/64 = one cache line each)
+    int fused = 1;                              // 1: fused persistent path mode (default), 0: wavefront kernels, -1: fused only for small tiles
+    int fused_max_pixels = 700000;
+    int fused_max_spp = 512;                    // samples per fused launch
+    int lds_gather = 0;                         // 1: cooperative LDS-DMA gathers, 0: per-lane register loads
+    int fetch_chunk = 64;
+    int substream_min_pixels = 32768;
+    int tlas_instanced = 0;                     // 1: hrt_tlas_build makes trees over instances too, 0: only rebuilds during updates do, -1: never
+    int refit = 1;                              // hrt_tlas_update: 1 = device refit when only transforms changed, 0 = always rebuild
+    float refit_rebuild_ratio = 1.5f;           // rebuild when the refitted tree's weighted mean node area has grown by this factor
+    uint64_t tlas_refits = 0, tlas_rebuilds = 0; double tlas_refit_ratio = 1.0;
+    int substreams = 0;                         // sub-tiles rendered on their own HIP streams so that one's tail overlaps another's bulk
+    std::vector<hipStream_t> sub_streams; std::vector<hipEvent_t> sub_done; hipEvent_t ev_begin = nullptr;
+};
+
+namespace hrt {
+
+// formats the message into ctx->error (or the creating thread's error when ctx is NULL) and returns code
+int fail(HrtContext *ctx, int code, const char *fmt, ...);
+const char *create_error();
+
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return fail(ctx, _e == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP,          \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int kMaxSubTiles = 8;
+
+struct Timer {
+    HrtContext *ctx; hipStream_t s; bool on; TimedSpan span{};
+    Timer(HrtContext *c, hipStream_t st, int kind) : ctx(c), s(st), on((c->flags & HRT_CTX_TIMING) != 0) {
+        if (!on) { ctx->kernel_launches[kind]++; return; }
+        span.kind = kind; span.a = next(); span.b = next();
+        (void)hipEventRecord(span.a, s);
+    }
+    ~Timer() { if (on) { (void)hipEventRecord(span.b, s); ctx->spans.push_back(span); } }
+    hipEvent_t next() {
+        if (ctx->events_used == ctx->event_pool.size()) { hipEvent_t e; (void)hipEventCreate(&e); ctx->event_pool.push_back(e); }
+        return ctx->event_pool[ctx->events_used++];
+    }
+};
+
+void drain_spans(HrtContext *ctx);
+
+// hrt_accel.cpp
+void free_tlas_device(Tlas &t);
+void free_tlas_host(Tlas &t);
+
+}  // namespace hrt
