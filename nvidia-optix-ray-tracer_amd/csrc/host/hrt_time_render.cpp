@@ -41,7 +41,7 @@ int main(int argc, char **argv) {
     const uint32_t H = argc > 6 ? (uint32_t)std::atoi(argv[6]) : (uint32_t)cfg.window_height;
 
     HrtContext *ctx = createContext(0, false);
-    hrtCheckError(ctx, hrt_ctx_set_flags(ctx, HRT_CTX_TIMING));
+    if (std::getenv("HRT_TIME_RENDER_KERNEL_TIMES")) hrtCheckError(ctx, hrt_ctx_set_flags(ctx, HRT_CTX_TIMING));   // per-kernel HIP events
 
     // extra geometry first (buildAddDataGAS, RendererTime.cu:73-84), then one GAS per STL shape in name order (:183-190)
     std::vector<GAS> gasAll;
@@ -165,6 +165,8 @@ int main(int argc, char **argv) {
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     HrtStats st{};
     hrtCheckError(ctx, hrt_stats_get(ctx, &st));
+    for (int k = 0; k < HRT_K_COUNT; ++k)
+        if (st.kernel_launches[k] && st.kernel_ms[k] > 0.0) std::printf("  kernel class %d: %.3f ms in %llu launches\n", k, st.kernel_ms[k], (unsigned long long)st.kernel_launches[k]);
     std::printf("%ld frames %ux%u: %.3f ms/frame (%.0f frames/s), %.1f Mrays/s, refits %llu rebuilds %llu\n", frames, W, H, ms / std::max(1l, frames),
                 frames / ms * 1e3, st.rays / ms * 1e-3, (unsigned long long)st.tlas_refits, (unsigned long long)st.tlas_rebuilds);
 

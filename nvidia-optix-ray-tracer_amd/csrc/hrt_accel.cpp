@@ -240,6 +240,7 @@ int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &in
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
     t.instanced = instanced;
+    t.refits_since_build = 0;
     t.generation++;
     t.rebuilds++; ctx->tlas_rebuilds++;
     return HRT_OK;
@@ -285,7 +286,7 @@ int refit_tlas(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, h
     HIP_TRY(ctx, hipMemcpyAsync(t.h_area, t.d_area, sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(ctx, hipEventRecord(t.area_ready, s));
     t.area_pending = true;
-    t.refits++; ctx->tlas_refits++;
+    t.refits++; t.refits_since_build++; ctx->tlas_refits++;
     return HRT_OK;
 }
 
@@ -395,7 +396,17 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
         bool sbt_changed = false;
         for (uint32_t i = 0; i < n; ++i) if (inst[i].sbtOffset != t->sbt_offset[i]) { t->sbt_offset[i] = inst[i].sbtOffset; sbt_changed = true; }
         if (sbt_changed) t->generation++;                 // the material tables are re-derived at the next launch
-        return refit_tlas(ctx, *t, inst, s);
+        const bool first_after_build = t->refits_since_build == 0;
+        const int rc = refit_tlas(ctx, *t, inst, s);
+        if (rc != HRT_OK || !first_after_build) return rc;
+        // The first refit after a build is checked on the spot (one stream synchronisation per build): the reference builds
+        // every file's IAS with identity transforms and poses it afterwards (RendererTime.cu:111-127), so this is the refit
+        // that turns a tree built over coinciding particles into the real scene -- and the frame that follows would be
+        // traced through boxes that span everything.  Later refits are checked asynchronously, at the next update.
+        HIP_TRY(ctx, hipEventSynchronize(t->area_ready));
+        t->area_pending = false;
+        ctx->tlas_refit_ratio = (double)*t->h_area;
+        if (ctx->tlas_refit_ratio <= (double)ctx->refit_rebuild_ratio) return HRT_OK;
     }
     HIP_TRY(ctx, hipDeviceSynchronize());                 // launches on other streams may still read the old tree
     // a rebuild in the middle of an animation: the tree over instances costs milliseconds instead of a full SAH build

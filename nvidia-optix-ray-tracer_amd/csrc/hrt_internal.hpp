@@ -60,7 +60,7 @@ struct Tlas {
     const void **d_inst_src = nullptr;
     float *h_area = nullptr;                             // pinned: area sum of the last refit
     hipEvent_t area_ready = nullptr; bool area_pending = false;
-    uint64_t refits = 0, rebuilds = 0;
+    uint64_t refits = 0, rebuilds = 0, refits_since_build = 0;
 };
 
 // per-depth counters, zeroed once per sample: bin sizes + 8 slice counters on 128-byte lines of their own
