@@ -415,6 +415,9 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     float px_ax = 0.0f, px_ay = 0.0f, px_az = 0.0f;
     Xorwow px_rng{};
     uint32_t px_rays_closest = 0u, px_rays_any = 0u;
+#ifdef HRT_LANE_STATS
+    unsigned long long ls_iter = 0, ls_alive = 0, ls_node = 0, ls_prim = 0, ls_ppass = 0, ls_regen = 0;
+#endif
 
     // what the next iteration gathers for this lane
     bool has_node = false, has_prim = false;
@@ -461,6 +464,9 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
         if (FUSED) {
             // ---- regenerate: shade finished rays in place, start the next sample / pixel ----
             if (n_idle >= (uint32_t)a.refill_threshold || idle == ~0ull) {
+#ifdef HRT_LANE_STATS
+                ++ls_regen;
+#endif
                 auto start_ray = [&](V3 o, V3 d) {
                     s.ox = o.x; s.oy = o.y; s.oz = o.z; s.dx = d.x; s.dy = d.y; s.dz = d.z;
                     s.idx = safe_rcp_dir(s.dx); s.idy = safe_rcp_dir(s.dy); s.idz = safe_rcp_dir(s.dz);
@@ -665,6 +671,9 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
             bool done = false;
             if (any && alive && shared && s_mb_prim[home] != kMissPrim) done = true;   // another piece already found a hit
 
+#ifdef HRT_LANE_STATS
+            { const uint64_t mp = __ballot(alive && has_prim), mn = __ballot(alive && has_node); ++ls_iter; ls_alive += __popcll(__ballot(alive)); ls_node += __popcll(mn); ls_prim += __popcll(mp); ls_ppass += mp != 0ull; }
+#endif
             // ---- C. leaf test: waits for the primitive pieces only ----
             if (DMA) wait_prim_gather(); else wait_prim_loads(rpa, rpb, rpc);
             if (!COUNT && alive && !done && has_prim) {
@@ -813,6 +822,12 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
             if ((FUSED || !exhausted) && (64u - (uint32_t)__popcll(act)) >= (uint32_t)a.refill_threshold) break;
         }
     }
+#ifdef HRT_LANE_STATS
+    if (FUSED && tx == 0u) {
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(a.path.rays_closest);
+        atomicAdd(d + 6, ls_iter); atomicAdd(d + 7, ls_alive); atomicAdd(d + 8, ls_node); atomicAdd(d + 9, ls_prim); atomicAdd(d + 2, ls_ppass); atomicAdd(d + 3, ls_regen);
+    }
+#endif
     if (FUSED) {
         for (int off = 32; off > 0; off >>= 1) {
             px_rays_closest += (uint32_t)__shfl_down((int)px_rays_closest, off);
