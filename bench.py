@@ -42,10 +42,12 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(hrt, scene, target_seconds):
+def cpu_baseline(hrt, scene, target_seconds, renderer=None):
     """The CPU oracle (kind "port": the reference has no CPU path to build) on a bounded sample of
     the same workload: the same frame at a reduced number of samples per pixel (or a subset of its
-    rows when even 1 spp would take too long), all host threads, sized for ~target_seconds."""
+    rows when even 1 spp would take too long), all host threads, sized for ~target_seconds.
+    With a renderer, the GPU renders the very same sample afterwards and the two images are compared
+    (the metric's "image L-inf vs ref"): returns (cpu_baseline, parity)."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_py
     W, H = scene["width"], scene["height"]
@@ -62,14 +64,29 @@ def cpu_baseline(hrt, scene, target_seconds):
         rows, spp = np.arange(0, H, step, dtype=np.uint32), 1
     else:
         rows, spp = None, int(np.clip(target_seconds / frame_seconds, 1, scene["spp"]))
+    states = oracle_py.rng_init(W, H, hrt.scenes.SEED_SALT)                # the timed sample starts from the seeded streams
     t0 = time.perf_counter()
-    r = osc.render(W, H, states, spp, rows=rows, want_linear=False)
+    r = osc.render(W, H, states, spp, rows=rows, want_linear=renderer is not None)
     dt = max(time.perf_counter() - t0, 1e-6)
     osc.close()
     n_rows = H if rows is None else len(rows)
-    return {"value": round(r["rays"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": int(threads), "kind": "port",
+    base = {"value": round(r["rays"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": int(threads), "kind": "port",
             "sample": f"{n_rows} of {H} rows x {W} px, {spp} spp, {r['rays']} rays in {dt:.1f} s, "
                       f"oracle/oracle.c (own BVH2) OpenMP x{threads}"}
+    if renderer is None:
+        return base, None
+    # the same sample on the GPU, from the same seeded streams
+    renderer.set_frame(W, H, hrt.scenes.SEED_SALT, aov=False, linear=True)
+    renderer.reset_stats()
+    tile = None if rows is None else hrt.Tile(0, H, 1, int(rows[1] - rows[0]) if len(rows) > 1 else H, 0)
+    renderer.render(spp, tile=tile)
+    sel = slice(None) if rows is None else rows
+    g_lin, g_col = renderer.linear.cpu().numpy()[sel], renderer.color.cpu().numpy()[sel]
+    parity = {"against": "oracle/oracle.c on the cpu_baseline sample", "pixels": int(g_lin.shape[0] * g_lin.shape[1]), "spp": int(spp),
+              "linear_radiance_bit_exact": bool(np.array_equal(g_lin.view(np.uint32), r["linear"][sel].view(np.uint32))),
+              "linf_color": float(np.abs(g_col - r["color"][sel]).max()),
+              "rays_equal": bool(renderer.stats().rays == r["rays"])}
+    return base, parity
 
 
 def main():
@@ -212,7 +229,8 @@ def main():
             "kernel_ms": {hrt.KERNEL_NAMES[k]: round(st.kernel_ms[k], 3) for k in range(hrt.K_COUNT)},
         }
         if not args.no_cpu_baseline and world == 1:             # the CPU leg is timed at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(hrt, scene, args.cpu_seconds)
+            r.set_flags(0)                                      # production kernels for the parity render
+            out["cpu_baseline"], out["parity"] = cpu_baseline(hrt, scene, args.cpu_seconds, r)
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()
