@@ -536,6 +536,29 @@ def test_full_size_properties_1080p(hrt, renderer):
     assert np.array_equal(a, renderer.color.cpu().numpy())
 
 
+def test_full_size_c3_frame_against_the_oracle(hrt, oracle, gpu_available):
+    """BASELINE configs[2] geometry at its full size (100 000 triangles, 1920x1080), one sample per pixel, production
+    kernels: every one of the 2 073 600 pixels' linear radiance, the final RNG states and the ray count are bit-exact
+    against the oracle (a few seconds of CPU on the box's host threads)."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    r = hrt.Renderer(0, 0)
+    try:
+        w, h = 1920, 1080
+        scene = hrt.scenes.soup_100k(w, h, 1)
+        r.load_scene(scene)
+        r.set_frame(w, h, hrt.scenes.SEED_SALT, aov=False, linear=True)
+        r.render(1)
+        states = oracle.rng_init(w, h, hrt.scenes.SEED_SALT)
+        ref = oracle.OracleScene(scene).render(w, h, states, 1)
+        assert np.array_equal(r.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32))
+        assert np.abs(r.color.cpu().numpy() - ref["color"]).max() <= 1e-6
+        assert np.array_equal(r.rng_states_numpy(), states)
+        assert r.stats().rays == ref["rays"]
+    finally:
+        r.close()
+
+
 def test_full_size_c4_c5_properties(hrt, gpu_available):
     """BASELINE configs[3] / [4] geometry at full size (1 M triangles, 1920x1080; spp reduced to 2): size-independent
     properties with the production kernels -- determinism, 1..5 rays per path, at most one any-hit ray per path, the
