@@ -142,6 +142,66 @@ def test_oracle_bvh_equals_bruteforce(oracle, hrt):
     assert 0.3 < (rb[3] != 0xFFFFFFFF).mean() < 1.0
 
 
+def test_canonical_intersector_against_a_numpy_restatement(oracle, hrt):
+    """A second, independent statement of the canonical intersector in numpy float32 -- every
+    operation rounded separately, sums left to right -- against oracle/oracle.c on single-primitive scenes: the
+    accepted hits and their (t, u, v) agree bit for bit.  Triangles: Moller-Trumbore on (v0, e1, e2), reject det == 0,
+    0 <= u <= 1, v >= 0, u + v <= 1, tmin < t < tmax.  Spheres: first root of |o + t d - c|^2 = r^2 in (tmin, tmax)."""
+    f = np.float32
+    n = 20000
+    o, d = oracle.random_rays(n, 12)            # aimed at the middle of the scene, some axis-parallel
+    tmin, tmax = f(1e-6), f(1e16)
+
+    def dot(a, b):
+        return ((a[:, 0] * b[:, 0]).astype(f) + (a[:, 1] * b[:, 1]).astype(f)).astype(f) + (a[:, 2] * b[:, 2]).astype(f)
+
+    def cross(a, b):
+        return np.stack([(a[:, 1] * b[:, 2]).astype(f) - (a[:, 2] * b[:, 1]).astype(f),
+                         (a[:, 2] * b[:, 0]).astype(f) - (a[:, 0] * b[:, 2]).astype(f),
+                         (a[:, 0] * b[:, 1]).astype(f) - (a[:, 1] * b[:, 0]).astype(f)], axis=1).astype(f)
+
+    # one big triangle
+    tri = np.array([[[-1.3, -0.9, 0.1], [1.1, -1.0, -0.2], [0.2, 1.4, 0.3]]], f)
+    scene = {"instances": [hrt.scenes._tri_instance(tri, hrt.scenes.WHITE)], "background": hrt.scenes.BACKGROUND, "camera": hrt.scenes._soup_camera()}
+    t, u, v, prim, inst = oracle.OracleScene(scene, force_brute=True).trace(o, d)
+    v0 = np.broadcast_to(tri[0, 0], (n, 3))
+    e1 = np.broadcast_to((tri[0, 1] - tri[0, 0]).astype(f), (n, 3))
+    e2 = np.broadcast_to((tri[0, 2] - tri[0, 0]).astype(f), (n, 3))
+    with np.errstate(all="ignore"):
+        pvec = cross(d, e2)
+        det = dot(e1, pvec)
+        inv = (f(1.0) / det).astype(f)
+        tvec = (o - v0).astype(f)
+        uu = (dot(tvec, pvec) * inv).astype(f)
+        qvec = cross(tvec, e1)
+        vv = (dot(d, qvec) * inv).astype(f)
+        tt = (dot(e2, qvec) * inv).astype(f)
+        hit = (det != 0) & (uu >= 0) & (uu <= 1) & (vv >= 0) & ((uu + vv).astype(f) <= 1) & (tt > tmin) & (tt < tmax)
+    assert np.array_equal(hit, prim != 0xFFFFFFFF) and 0.05 < hit.mean() < 0.95
+    assert np.array_equal(tt[hit].view(np.uint32), t[hit].view(np.uint32))
+    assert np.array_equal(uu[hit].view(np.uint32), u[hit].view(np.uint32)) and np.array_equal(vv[hit].view(np.uint32), v[hit].view(np.uint32))
+
+    # one sphere (identity instance transform)
+    c, r = np.array([0.2, -0.1, 0.3], f), f(0.9)
+    scene = {"instances": [hrt.scenes._sphere_instance([c], [r], hrt.scenes.WHITE)], "background": hrt.scenes.BACKGROUND, "camera": hrt.scenes._soup_camera()}
+    t, u, v, prim, inst = oracle.OracleScene(scene, force_brute=True).trace(o, d)
+    with np.errstate(all="ignore"):
+        oc = (o - c).astype(f)
+        a = dot(d, d)
+        b = dot(oc, d)
+        cc = (dot(oc, oc) - (r * r).astype(f)).astype(f)
+        disc = ((b * b).astype(f) - (a * cc).astype(f)).astype(f)
+        sq = np.sqrt(disc).astype(f)
+        t0 = (((-b) - sq).astype(f) / a).astype(f)
+        t1 = (((-b) + sq).astype(f) / a).astype(f)
+        ok0 = (t0 > tmin) & (t0 < tmax)
+        ok1 = (t1 > tmin) & (t1 < tmax)
+        hit = (a != 0) & (disc >= 0) & (ok0 | ok1)
+        ts = np.where(ok0, t0, t1)
+    assert np.array_equal(hit, prim != 0xFFFFFFFF) and 0.05 < hit.mean() < 0.95
+    assert np.array_equal(ts[hit].view(np.uint32), t[hit].view(np.uint32))
+
+
 def test_closest_hit_tie_break_lowest_instance_then_primitive(oracle, hrt):
     """Two coincident triangles in two instances, and twice in one instance: the canonical
     intersector reports the lowest (instance, primitive)."""
