@@ -139,6 +139,11 @@ typedef struct HrtPoseParams {
     uint32_t  frame_count;      /* frameCountThisFile                                             */
     HrtFloat3 particle_offset;  /* loopData.particleOffset                                        */
     HrtFloat3 particle_scale;   /* loopData.particleScale                                         */
+    uint32_t  mesh_mode;        /* 0: Time mode (position + velocity, slerp of the quaternions);
+                                   1: Mesh mode, src/Global/RendererMesh.cu:379-391 -- the geometry of
+                                   a file is already posed, the instance only drifts:
+                                   constructTransformMatrix(offset + (velocity * duration / frame_count)
+                                   * frame, {0,0,0}, scale); position and quat are not read          */
 } HrtPoseParams;
 
 #ifdef __cplusplus

@@ -57,7 +57,7 @@ class Instance(C.Structure):
 class PoseParams(C.Structure):
     """HrtPoseParams: frame-loop scalars of the Time-mode pose update (src/Global/RendererTime.cu:425-470)."""
     _fields_ = [("duration", C.c_float), ("frame", C.c_uint32), ("frame_count", C.c_uint32),
-                ("particle_offset", C.c_float * 3), ("particle_scale", C.c_float * 3)]
+                ("particle_offset", C.c_float * 3), ("particle_scale", C.c_float * 3), ("mesh_mode", C.c_uint32)]
 
 
 PARTICLE_STATE_FLOATS = 12      # HrtParticleState as floats: quat.xyzw, position.xyz, velocity.xyz, 2 pad

@@ -147,6 +147,7 @@ struct PoseArgs {
     const float4 *current, *next;  // HrtParticleState[] as 3 float4 each
     float duration; uint32_t frame, frame_count;
     float offset[3], scale[3];
+    uint32_t mesh_mode;            // RendererMesh's drift-only update (no rotation, position not added)
 };
 void launch_pose_instances(const PoseArgs &a, hipStream_t s);
 

@@ -427,6 +427,7 @@ int hrt_pose_instances(HrtContext *ctx, HrtInstance *d_instances, uint32_t first
     a.current = reinterpret_cast<const float4 *>(d_current); a.next = reinterpret_cast<const float4 *>(d_next);
     a.duration = h_params->duration; a.frame = h_params->frame; a.frame_count = h_params->frame_count;
     std::memcpy(a.offset, &h_params->particle_offset, 12); std::memcpy(a.scale, &h_params->particle_scale, 12);
+    a.mesh_mode = h_params->mesh_mode ? 1u : 0u;
     launch_pose_instances(a, (hipStream_t)stream);
     HIP_TRY(ctx, hipGetLastError());
     return HRT_OK;

@@ -111,7 +111,16 @@ __global__ __launch_bounds__(256) void k_pose_instances(PoseArgs a) {
     for (int k = 0; k < 3; ++k) {
         const float total = vel[k] * a.duration;
         const float per_frame = total / fcount;
-        shift[k] = a.offset[k] + (pos[k] + per_frame * fframe);
+        shift[k] = a.mesh_mode ? a.offset[k] + per_frame * fframe : a.offset[k] + (pos[k] + per_frame * fframe);
+    }
+    float4 *out = reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(a.instances) + (size_t)(a.first_instance + i) * 80u);
+    if (a.mesh_mode) {
+        // Mesh mode (RendererMesh.cu:379-391): rotation (0,0,0) -- the rotation matrices are exact identities (cos 0 = 1,
+        // sin 0 = 0), so the product Shift * R * Scale is the scale on the diagonal and the shift in the last column
+        out[0] = make_float4(a.scale[0], 0.0f, 0.0f, shift[0]);
+        out[1] = make_float4(0.0f, a.scale[1], 0.0f, shift[1]);
+        out[2] = make_float4(0.0f, 0.0f, a.scale[2], shift[2]);
+        return;
     }
     const Quat q = slerp(Quat{qc.x, qc.y, qc.z, qc.w}, Quat{qn.x, qn.y, qn.z, qn.w}, factor);
     float deg[3];
@@ -121,7 +130,6 @@ __global__ __launch_bounds__(256) void k_pose_instances(PoseArgs a) {
     sc.m[0][0] = a.scale[0]; sc.m[1][1] = a.scale[1]; sc.m[2][2] = a.scale[2];
     const Mat4 r = mul(mul(rotation(deg[0], 0), rotation(deg[1], 1)), rotation(deg[2], 2));
     const Mat4 t = mul(mul(s, r), sc);
-    float4 *out = reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(a.instances) + (size_t)(a.first_instance + i) * 80u);
     out[0] = make_float4(t.m[0][0], t.m[0][1], t.m[0][2], t.m[0][3]);
     out[1] = make_float4(t.m[1][0], t.m[1][1], t.m[1][2], t.m[1][3]);
     out[2] = make_float4(t.m[2][0], t.m[2][1], t.m[2][2], t.m[2][3]);

@@ -187,7 +187,7 @@ class Renderer:
                     "hrt_tlas_update")
 
     def pose_instances(self, current, nxt, duration, frame, frame_count, first_instance=0,
-                       offset=(0.0, 0.0, 0.0), scale=(1.0, 1.0, 1.0), update=True):
+                       offset=(0.0, 0.0, 0.0), scale=(1.0, 1.0, 1.0), update=True, mesh_mode=False):
         """Time mode's per-frame pose step on the device (src/Global/RendererTime.cu:436-480): ``current`` / ``nxt`` are
         (n, 12) float32 particle states (quat.xyzw, position, velocity, 2 pad) of this and the next time step; writes the
         transforms of instances [first_instance, first_instance + n) in device memory, then updateIAS."""
@@ -196,7 +196,7 @@ class Renderer:
         nx = nxt if hasattr(nxt, "data_ptr") else self._dev(np.ascontiguousarray(nxt, dtype=np.float32))
         n = cur.shape[0]
         pp = PoseParams(float(duration), int(frame), int(frame_count),
-                        (C.c_float * 3)(*[float(x) for x in offset]), (C.c_float * 3)(*[float(x) for x in scale]))
+                        (C.c_float * 3)(*[float(x) for x in offset]), (C.c_float * 3)(*[float(x) for x in scale]), 1 if mesh_mode else 0)
         self._check(self.lib.hrt_pose_instances(self.ctx, self._d_inst.data_ptr(), first_instance, n, cur.data_ptr(), nx.data_ptr(),
                                                 C.byref(pp), self._stream()), "hrt_pose_instances")
         if update:

@@ -353,6 +353,26 @@ def test_pose_instances_matches_oracle(hrt, oracle, renderer):
     assert identical / total > 0.8, identical / total        # measured: 85 % of the entries are the same bits
 
 
+def test_pose_instances_mesh_mode(hrt, oracle, renderer):
+    """Mesh mode's per-frame update (RendererMesh.cu:379-391): every particle drifts by velocity * duration / frames per
+    frame, no rotation, the particle's position is not added (its geometry is already posed).  Bit-exact against
+    constructTransformMatrix(offset + shift * frame, {0,0,0}, scale) of the oracle."""
+    n = 64
+    scene = hrt.scenes.particle_scene(n, 32, 32, 1, subdiv=0)
+    renderer.load_scene(scene)
+    st = hrt.scenes.particle_states(n, 0)
+    st[:, 7:10] = np.random.default_rng(3).uniform(-2, 2, (n, 3)).astype(np.float32)
+    f = np.float32
+    for dur, frame, count, off, sc in ((0.01, 0, 9, (0, 0, 0), (1, 1, 1)), (0.01, 8, 9, (0.5, -1, 2), (1, 1, 1)), (0.25, 77, 120, (0, 0, 0), (2, 0.5, 1.5))):
+        renderer.pose_instances(st, st, dur, frame, count, first_instance=1, offset=off, scale=sc, update=False, mesh_mode=True)
+        got = renderer.instance_transforms()[1:]
+        for i in range(n):
+            per_frame = ((st[i, 7:10] * f(dur)).astype(f) / f(count)).astype(f)
+            shift = (np.asarray(off, f) + (per_frame * f(frame)).astype(f)).astype(f)
+            want = oracle.construct_transform(shift, (0, 0, 0), sc)
+            assert np.array_equal(got[i].view(np.uint32), want.view(np.uint32)), (i, frame)
+
+
 def test_time_mode_frames_pose_refit_render(hrt, oracle, renderer):
     """The whole Time-mode frame on the device: pose kernel -> updateIAS (refit) -> launch, several frames across two
     time steps; every frame's image is bit-exact against the oracle rendering the scene with the transforms the

@@ -164,6 +164,19 @@ def test_pose_transforms_frame_loop(oracle, hrt):
     assert np.array_equal(one[0], oracle.construct_transform(cur[0, 4:7], oracle.quat_to_euler(q), (1, 1, 1)))
 
 
+def test_mesh_mode_drift_is_scale_and_shift_exactly(oracle):
+    """Mesh mode (RendererMesh.cu:379-391) poses with rotation (0,0,0): the rotation matrices are exact identities, so
+    constructTransformMatrix(shift, 0, scale) is the scale on the diagonal and the shift in the last column, with +0
+    everywhere else -- which is what hrt_pose_instances writes in mesh_mode without running the matrix products."""
+    rng = np.random.default_rng(9)
+    for _ in range(200):
+        shift = rng.uniform(-5, 5, 3).astype(np.float32)
+        scale = rng.uniform(-2, 2, 3).astype(np.float32)
+        m = oracle.construct_transform(shift, (0, 0, 0), scale)
+        want = np.array([scale[0], 0, 0, shift[0], 0, scale[1], 0, shift[1], 0, 0, scale[2], shift[2]], np.float32)
+        assert np.array_equal(m.view(np.uint32), want.view(np.uint32))          # bit patterns: the zeros are +0
+
+
 def test_pose_golden_vectors(oracle):
     """Committed outputs of the oracle (tests/golden/make_golden.py): a change of the restatement shows up here."""
     g = json.loads(GOLDEN.read_text())
