@@ -119,6 +119,14 @@ def load_library():
         return _lib
     if not LIB_PATH.exists():
         raise HrtError(f"{LIB_PATH} is missing: run `make lib` (or __graft_entry__.build()); there is no CPU fallback")
+    # Load order matters in a Python process: PyTorch ships its own copy of the HIP runtime.  If libhrt.so came first it
+    # would pull in /opt/rocm's libamdhip64, and the process would end up with two runtimes (observed: hipGetDeviceCount
+    # then reports no device).  Importing torch first makes libhrt.so bind to the runtime torch has already loaded --
+    # the same one the tensors that carry the device memory live in.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
     lib.hrt_last_error.restype = C.c_char_p
     lib.hrt_last_error.argtypes = [C.c_void_p]
