@@ -83,6 +83,15 @@ int main(int argc, char **argv) {
     // materials: config roughs, then the baked ramp, one colour per particle id (RendererTime.cu:246-256)
     std::vector<float> ramp(3 * maxParticles);
     ioCheck(hrt_io_bake_color_ramp(cfg.particle_material_preset, maxParticles, ramp.data()));
+    RendererMaterial materials;
+    for (uint64_t i = 0; i < cfg.n_roughs; ++i) materials.roughs.push_back({cfg.roughs[3 * i], cfg.roughs[3 * i + 1], cfg.roughs[3 * i + 2]});
+    for (uint64_t i = 0; i < cfg.n_metals; ++i) materials.metals.push_back({{cfg.metals[4 * i], cfg.metals[4 * i + 1], cfg.metals[4 * i + 2]}, cfg.metals[4 * i + 3]});
+    const size_t materialOffset = materials.roughs.size();
+    for (uint64_t i = 0; i < maxParticles; ++i) materials.roughs.push_back({ramp[3 * i], ramp[3 * i + 1], ramp[3 * i + 2]});
+    std::vector<RendererSphere> addSpheres;
+    for (uint64_t i = 0; i < cfg.n_spheres; ++i)
+        addSpheres.push_back({cfg.spheres[i].metal ? METAL : ROUGH, (size_t)cfg.spheres[i].material_index, sphereCenters[i], sphereRadii[i], 1});
+    const std::vector<HitGroupSbtRecord> addGeoRecord = createAddSphereTriangleSBTRecord(ctx, addSpheres, {}, materials);
 
     // per file: instances (identity until the first frame), IAS, SBT records (:96-140, :258-288), particle states on the device
     struct FileData { HrtInstance *dev_instances; IAS ias; std::vector<HrtSbtRecord> records; HrtParticleState *dev_states; size_t instanceCount; };
@@ -92,35 +101,27 @@ int main(int argc, char **argv) {
         const HrtIoParticles &p = files[f];
         const size_t count = addGeoCount + p.n;
         std::vector<HrtInstance> inst(count);
-        std::vector<HrtSbtRecord> rec(count);
+        std::vector<std::pair<size_t, HrtFloat3 *>> particleSBTData;
         for (size_t i = 0; i < count; ++i) {
-            std::memset(&inst[i], 0, sizeof inst[i]); std::memset(&rec[i], 0, sizeof rec[i]);
+            std::memset(&inst[i], 0, sizeof inst[i]);
             std::memcpy(inst[i].transform, i < addGeoCount ? cfg.spheres[i].transform : identity, sizeof identity);
             inst[i].sbtOffset = (uint32_t)i; inst[i].visibilityMask = 1;
-            if (i < addGeoCount) {
-                const HrtIoSphere &s = cfg.spheres[i];
-                inst[i].traversableHandle = gasAll[i].first;
-                hrtCheckError(ctx, hrt_sbt_record_pack_header(s.metal ? HRT_PROGRAM_SPHERE_METAL : HRT_PROGRAM_SPHERE_ROUGH, &rec[i]));
-                rec[i].data.sphere.centers = sphereCenters[i]; rec[i].data.sphere.radii = sphereRadii[i];
-                const float *m = s.metal ? cfg.metals + 4 * s.material_index : cfg.roughs + 3 * s.material_index;
-                rec[i].data.rough.albedo = {m[0], m[1], m[2]};
-                if (s.metal) rec[i].data.metal.fuzz = m[3];
-            } else {
+            if (i < addGeoCount) inst[i].traversableHandle = gasAll[i].first;
+            else {
                 const size_t k = i - addGeoCount;
                 inst[i].traversableHandle = gasAll[addGeoCount + p.shape_ids[k]].first;
-                hrtCheckError(ctx, hrt_sbt_record_pack_header(HRT_PROGRAM_TRIANGLE_ROUGH, &rec[i]));
-                rec[i].data.triangles.vertexNormals = shapeNormals[p.shape_ids[k]];
-                rec[i].data.rough.albedo = {ramp[3 * p.ids[k]], ramp[3 * p.ids[k] + 1], ramp[3 * p.ids[k] + 2]};
+                particleSBTData.emplace_back(p.ids[k] + materialOffset, shapeNormals[p.shape_ids[k]]);
             }
         }
+        std::vector<HitGroupSbtRecord> rec = createVTKParticleSBTRecord(ctx, particleSBTData, materials);
+        rec.insert(rec.begin(), addGeoRecord.begin(), addGeoRecord.end());
         perFile[f].dev_instances = toDevice(inst.data(), count);
         perFile[f].ias = buildIAS(ctx, perFile[f].dev_instances, count);
         perFile[f].records = std::move(rec);
         perFile[f].dev_states = toDevice(p.states, p.n);
         perFile[f].instanceCount = count;
     }
-    const HrtMissParams miss{{0.7f, 0.8f, 0.9f}};
-    hrtCheckError(ctx, hrt_miss_set(ctx, &miss));
+    createMissSBTRecord(ctx, {0.7f, 0.8f, 0.9f});
 
     HrtRngState *dev_stateArray = nullptr;
     RandomGenerator::initDeviceRandomGenerators(ctx, dev_stateArray, W, H, 0x5EED0000C0FFEEull);

@@ -66,6 +66,63 @@ inline void updateIAS(HrtContext *ctx, IAS &ias, const HrtInstance *dev_instance
 inline void cleanupAccelerationStructure(HrtContext *ctx, GAS &g) { hrt_blas_destroy(ctx, g.first); g = {}; }
 inline void cleanupAccelerationStructure(HrtContext *ctx, IAS &i) { hrt_tlas_destroy(ctx, std::get<0>(i)); i = {}; }
 
+// SBT records, src/Global/RendererImpl.cu:472-575.  The four OptixProgramGroup arguments of the reference become the
+// HrtProgram ids hrt_sbt_record_pack_header takes; the records keep their layout and are handed to hrt_materials_set
+// (record i <-> instance with sbtOffset i) where the reference copies them to the device (RendererMesh.cu:283-305).
+enum MaterialType { ROUGH = 0, METAL = 1 };                                   // include/Global/Shader.cuh:16-18
+struct RendererMaterial { std::vector<HrtFloat3> roughs; std::vector<std::pair<HrtFloat3, float>> metals; };   // RendererImpl.cuh:109-112
+typedef HrtSbtRecord HitGroupSbtRecord;
+
+inline void packMaterial(HrtContext *ctx, HitGroupSbtRecord &record, bool sphere, int materialType, size_t materialIndex,
+                         const RendererMaterial &globalMaterials) {
+    if (materialType == ROUGH) {
+        hrtCheckError(ctx, hrt_sbt_record_pack_header(sphere ? HRT_PROGRAM_SPHERE_ROUGH : HRT_PROGRAM_TRIANGLE_ROUGH, &record));
+        record.data.rough.albedo = globalMaterials.roughs.at(materialIndex);
+    } else {
+        hrtCheckError(ctx, hrt_sbt_record_pack_header(sphere ? HRT_PROGRAM_SPHERE_METAL : HRT_PROGRAM_TRIANGLE_METAL, &record));
+        record.data.metal.albedo = globalMaterials.metals.at(materialIndex).first;
+        record.data.metal.fuzz = globalMaterials.metals.at(materialIndex).second;
+    }
+}
+// createAddSphereTriangleSBTRecord, RendererImpl.cu:494-552: spheres first, then triangles
+inline std::vector<HitGroupSbtRecord> createAddSphereTriangleSBTRecord(HrtContext *ctx, const std::vector<RendererSphere> &spheres,
+                                                                       const std::vector<RendererTriangle> &triangles,
+                                                                       const RendererMaterial &globalMaterials) {
+    std::vector<HitGroupSbtRecord> records;
+    records.reserve(spheres.size() + triangles.size());
+    for (const auto &sphere : spheres) {
+        HitGroupSbtRecord record = {};
+        record.data.sphere.centers = sphere.dev_centers; record.data.sphere.radii = sphere.dev_radii;
+        packMaterial(ctx, record, true, sphere.materialType, sphere.materialIndex, globalMaterials);
+        records.push_back(record);
+    }
+    for (const auto &triangle : triangles) {
+        HitGroupSbtRecord record = {};
+        record.data.triangles.vertexNormals = triangle.dev_normals;
+        packMaterial(ctx, record, false, triangle.materialType, triangle.materialIndex, globalMaterials);
+        records.push_back(record);
+    }
+    return records;
+}
+// createVTKParticleSBTRecord, RendererImpl.cu:554-575: (rough material index, vertex normals) per particle, all ROUGH
+inline std::vector<HitGroupSbtRecord> createVTKParticleSBTRecord(HrtContext *ctx, const std::vector<std::pair<size_t, HrtFloat3 *>> &particles,
+                                                                 const RendererMaterial &globalMaterials) {
+    std::vector<HitGroupSbtRecord> records;
+    records.reserve(particles.size());
+    for (const auto &particle : particles) {
+        HitGroupSbtRecord record = {};
+        record.data.triangles.vertexNormals = particle.second;
+        packMaterial(ctx, record, false, ROUGH, particle.first, globalMaterials);
+        records.push_back(record);
+    }
+    return records;
+}
+// the miss half of createRaygenMissSBTRecord, RendererImpl.cu:472-492 (the raygen record's payload is HrtRayGenParams, passed per launch)
+inline void createMissSBTRecord(HrtContext *ctx, const HrtFloat3 &backgroundColor) {
+    const HrtMissParams miss{backgroundColor};
+    hrtCheckError(ctx, hrt_miss_set(ctx, &miss));
+}
+
 // RandomGenerator::initDeviceRandomGenerators, src/Global/HostFunctions.cu:128-140 (seedSalt pins clock64())
 struct RandomGenerator {
     static void initDeviceRandomGenerators(HrtContext *ctx, HrtRngState *&dev_stateArray, size_t x, size_t y,
