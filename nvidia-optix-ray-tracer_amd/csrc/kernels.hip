@@ -413,6 +413,7 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
     uint32_t px_local = 0u, px_tid = 0u, px_sample = 0u, px_depth = 1u;
     uint32_t px_chain[4] = {0u, 0u, 0u, 0u};
     float px_ax = 0.0f, px_ay = 0.0f, px_az = 0.0f;
+    float px_pdx = 0.0f, px_pdy = 0.0f, px_pdz = 1.0f;      // the pixel's primary direction: the same for every sample (no jitter, Shader.cu:249-261)
     Xorwow px_rng{};
     uint32_t px_rays_closest = 0u, px_rays_any = 0u;
 #ifdef HRT_LANE_STATS
@@ -543,14 +544,19 @@ __global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
                             px_first = a.path.continue_sum == 0u;         // later launches of a long render continue the pixel's sum
                             if (!px_first) { const float4 acc = a.path.accum[px_local]; px_ax = acc.x; px_ay = acc.y; px_az = acc.z; }
                             have_pixel = true; want_primary = true;
+                            const V3 pd = primary_direction(ix, iy, a.path.width, a.path.height, a.path.U, a.path.V, a.path.W);
+                            px_pdx = pd.x; px_pdy = pd.y; px_pdz = pd.z;
                         }
                     }
                 }
                 if (!alive && want_primary) {
-                    const uint32_t iy = px_tid / a.path.width, ix = px_tid - iy * a.path.width;
                     px_depth = 1u;
-                    start_ray(mk3(a.path.center[0], a.path.center[1], a.path.center[2]),
-                              primary_direction(ix, iy, a.path.width, a.path.height, a.path.U, a.path.V, a.path.W));
+                    V3 pd = mk3(px_pdx, px_pdy, px_pdz);
+                    if (HAS_SPHERES) {      // the sphere build is at its register limit (4 waves per SIMD): recompute instead of keeping
+                        const uint32_t iy = px_tid / a.path.width, ix = px_tid - iy * a.path.width;
+                        pd = primary_direction(ix, iy, a.path.width, a.path.height, a.path.U, a.path.V, a.path.W);
+                    }
+                    start_ray(mk3(a.path.center[0], a.path.center[1], a.path.center[2]), pd);
                 }
             }
         } else
