@@ -121,7 +121,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
         hipMalloc((void **)&ctx->d_stats, sizeof(DeviceStats)) != hipSuccess ||
         hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)) != hipSuccess)
         return fail(nullptr, HRT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(hipGetLastError()));
-    if (const char *e = std::getenv("HRT_TRAVERSE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) { ctx->traverse_blocks_per_cu = v; ctx->traverse_blocks_auto = false; } }
+    if (const char *e = std::getenv("HRT_TRAVERSE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) { ctx->traverse_blocks_per_cu = v; ctx->fused_blocks_per_cu = v; ctx->traverse_blocks_auto = false; } }
     if (const char *e = std::getenv("HRT_FETCH_CHUNK")) { const int v = std::atoi(e); if (v >= 8 && v <= 4096) { ctx->fetch_chunk = v; ctx->fused_fetch_chunk = v; } }
     if (const char *e = std::getenv("HRT_NODE_STRIDE")) { const int v = std::atoi(e); if (v >= 80 && v <= 256 && v % 16 == 0) ctx->node_stride = v; }
     if (const char *e = std::getenv("HRT_PRIM_STRIDE")) { const int v = std::atoi(e); if (v >= 48 && v <= 256 && v % 16 == 0) ctx->prim_stride = v; }
@@ -318,8 +318,10 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         // Waves per CU: a lane runs its pixel's samples one after the other, so a small tile (the multi-GPU split) ends
         // with its slowest pixels; about 1.4 pixels per lane lets the lanes that drew cheap pixels take a second one
         // while fewer waves share each SIMD (measured, profiles/r01_sweep_tile_waves.txt: 1/8 of the C4 frame takes
-        // 172 ms on 12 waves per CU, 210 ms on 16).  A full frame has many pixels per lane and keeps the maximum.
-        uint32_t blocks_per_cu = (uint32_t)ctx->traverse_blocks_per_cu;
+        // 172 ms on 12 waves per CU, 210 ms on 16).  A full frame has many pixels per lane and keeps the maximum:
+        // 20 waves per CU = 5 per SIMD, for which k_traverse is compiled (__launch_bounds__(64, 5): 96 VGPRs, a few
+        // spills; 2905 Mrays/s on C4 against 2835 with 4 waves of 101 VGPRs, 6 waves of 80 VGPRs spill too much: 2801).
+        uint32_t blocks_per_cu = (uint32_t)ctx->fused_blocks_per_cu;
         if (ctx->traverse_blocks_auto) {
             const uint32_t fit = (uint32_t)((10ull * n + 14ull * 64ull * (uint64_t)ctx->n_cu - 1ull) / (14ull * 64ull * (uint64_t)ctx->n_cu));
             blocks_per_cu = std::min(blocks_per_cu, std::max(fit, 4u));

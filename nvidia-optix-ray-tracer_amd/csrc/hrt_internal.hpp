@@ -123,7 +123,8 @@ struct HrtContext {
     float4 *d_linear = nullptr;
     int refill_threshold = 16;                  // wavefront mode; fused mode: fused_refill_threshold
     int fused_refill_threshold = 24, fused_fetch_chunk = 16;   // measured optimum of the fused path mode (profiles/r01_sweep_fused_*.txt)
-    int traverse_blocks_per_cu = 16;            // one-wave workgroups of the traverse kernel per CU
+    int traverse_blocks_per_cu = 16;            // one-wave workgroups of the wavefront traverse kernel per CU
+    int fused_blocks_per_cu = 20;               // ... of the fused path kernel: 5 waves per SIMD (the kernel is compiled for 96 VGPRs)
     bool traverse_blocks_auto = true;           // fused mode: fewer of them for small tiles (not when the env knob is set)
     int postpone_pct = 25;
     int tail_split = 1;

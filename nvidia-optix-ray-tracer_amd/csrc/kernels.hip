@@ -367,7 +367,9 @@ __device__ __forceinline__ void wait_prim_gather() { asm volatile("s_waitcnt vmc
 __device__ __forceinline__ void wait_node_gather() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <bool COUNT, bool HAS_SPHERES, bool DMA, bool FUSED>
-__global__ __launch_bounds__(kTraverseBlock) void k_traverse(TraverseArgs a) {
+// 5 waves per SIMD: the register allocator is held to 96 VGPRs (the fused instantiations spill 27 / 71 dwords to scratch,
+// which costs less than the fifth wave gives: profiles/r01_sweep_occupancy.txt)
+__global__ __launch_bounds__(kTraverseBlock, 5) void k_traverse(TraverseArgs a) {
     static_assert(kTraverseBlock == 64, "one wave per workgroup: staging images and mailboxes are per wave");
     __shared__ uint2 s_stack[kLdsStack][kTraverseBlock];
     __shared__ uint4 s_node_stage[DMA ? 5 * 64 : 1];          // 64 node slots x 80 B, filled by LDS-DMA
