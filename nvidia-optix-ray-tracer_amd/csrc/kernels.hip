@@ -236,10 +236,14 @@ struct TravState {
     uint32_t slot;
 };
 
+// 1 / d for the slab test.  The counting build divides exactly, so that its node / primitive counts equal the CPU walk of
+// the same bytes (tests); the production build takes v_rcp_f32 (1 ULP, one instruction instead of the ~10 of the IEEE
+// sequence, three times per ray): the slab test only culls, and its boxes are padded by far more than an ULP.
+template <bool EXACT>
 __device__ __forceinline__ float safe_rcp_dir(float d) {
     const float lim = 1e-20f;
     const float dd = fabsf(d) < lim ? copysignf(lim, d) : d;
-    return 1.0f / dd;
+    return EXACT ? 1.0f / dd : __builtin_amdgcn_rcpf(dd);
 }
 
 // canonical primitive test (DESIGN.md "canonical intersector"); updates the best hit.
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(kTraverseBlock, 5) void k_traverse(TraverseArgs a) 
 #endif
                 auto start_ray = [&](V3 o, V3 d) {
                     s.ox = o.x; s.oy = o.y; s.oz = o.z; s.dx = d.x; s.dy = d.y; s.dz = d.z;
-                    s.idx = safe_rcp_dir(s.dx); s.idy = safe_rcp_dir(s.dy); s.idz = safe_rcp_dir(s.dz);
+                    s.idx = safe_rcp_dir<COUNT>(s.dx); s.idy = safe_rcp_dir<COUNT>(s.dy); s.idz = safe_rcp_dir<COUNT>(s.dz);
                     const uint32_t oct = (s.dx < 0.0f ? 4u : 0u) | (s.dy < 0.0f ? 2u : 0u) | (s.dz < 0.0f ? 1u : 0u);
                     s.oct_inv4 = (7u - oct) * 0x01010101u;
                     s.bt = tmax_ray; s.bu = 0.0f; s.bv = 0.0f; s.bprim = kMissPrim; s.binst = kMissPrim;
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(kTraverseBlock, 5) void k_traverse(TraverseArgs a) 
                     const RayRec r = in_b ? a.seg[1].rays[mine - n_a] : a.seg[0].rays[mine];
                     s.ox = r.o.x; s.oy = r.o.y; s.oz = r.o.z;
                     s.dx = r.d.x; s.dy = r.d.y; s.dz = r.d.z;
-                    s.idx = safe_rcp_dir(s.dx); s.idy = safe_rcp_dir(s.dy); s.idz = safe_rcp_dir(s.dz);
+                    s.idx = safe_rcp_dir<COUNT>(s.dx); s.idy = safe_rcp_dir<COUNT>(s.dy); s.idz = safe_rcp_dir<COUNT>(s.dz);
                     const uint32_t oct = (s.dx < 0.0f ? 4u : 0u) | (s.dy < 0.0f ? 2u : 0u) | (s.dz < 0.0f ? 1u : 0u);
                     s.oct_inv4 = (7u - oct) * 0x01010101u;
                     s.bt = tmax_ray; s.bu = 0.0f; s.bv = 0.0f; s.bprim = kMissPrim; s.binst = kMissPrim;
