@@ -297,7 +297,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
     const bool count = (ctx->flags & HRT_CTX_COUNT) != 0;
 
     // ---- fused path mode: ONE launch, every lane owns a pixel and runs all its samples (generate,
-    //      traverse, shade, accumulate in place).  No stage barriers: the choice for small tiles. ----
+    //      traverse, shade, accumulate in place).  No stage barriers.  The default (HRT_FUSED=1). ----
     const bool use_fused = !count && (ctx->fused > 0 || (ctx->fused < 0 && n <= (uint32_t)ctx->fused_max_pixels));
     if (use_fused) {
         StageCounters *stg = w.set[0].stages;

@@ -414,7 +414,7 @@ __global__ __launch_bounds__(kTraverseBlock, 5) void k_traverse(TraverseArgs a) 
 
     // FUSED (path mode): the lane owns a pixel and carries its path state; a finished ray is shaded in
     // place and the next ray (bounce, next sample, next pixel) starts in the same lane -- no queues, no
-    // per-stage launches, no stage barriers.  Used for small tiles where per-stage latency dominates.
+    // per-stage launches, no stage barriers.  The default mode of the production build.
     bool have_pixel = false, waiting = false, px_first = true;
     uint32_t px_local = 0u, px_tid = 0u, px_sample = 0u, px_depth = 1u;
     uint32_t px_chain[4] = {0u, 0u, 0u, 0u};
