@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--config", default="C4", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--spp", type=int, default=0, help="override the config's samples per pixel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=24.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
 
