@@ -60,6 +60,8 @@ struct PathArgs {
     const uint32_t *rows; uint32_t first_pixel, n_tile_pixels, width, height;
     uint32_t spp;                  // samples taken by THIS launch
     uint32_t continue_sum;         // 1: accum already holds the sum of earlier samples of this render
+    uint32_t *slice_cost;          // probe launch: per slice of fetch_chunk pixels, the time its pixels' samples took (clock / 16); else NULL
+    const uint32_t *slice_order;   // order in which the slices are handed out (most expensive first); NULL: as they lie
     float center[3], U[3], V[3], W[3], bg[3];
     RngState *states;
     const HitGroup *hitgroups; const uint32_t *inst_program;

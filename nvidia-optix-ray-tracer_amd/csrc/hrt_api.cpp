@@ -129,6 +129,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_TLAS_INSTANCED")) ctx->tlas_instanced = std::atoi(e);
     if (const char *e = std::getenv("HRT_REFIT")) ctx->refit = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_REFIT_REBUILD_RATIO")) { const double v = std::atof(e); if (v >= 1.0) ctx->refit_rebuild_ratio = (float)v; }
+    if (const char *e = std::getenv("HRT_FUSED_LPT")) { const int v = std::atoi(e); if (v >= 0 && v <= 64) ctx->fused_lpt = v; }
     if (const char *e = std::getenv("HRT_FUSED_MAX_SPP")) { const int v = std::atoi(e); if (v >= 1) ctx->fused_max_spp = v; }
     if (const char *e = std::getenv("HRT_FUSED_MAX_PIXELS")) { const int v = std::atoi(e); if (v > 0) ctx->fused_max_pixels = v; }
     if (const char *e = std::getenv("HRT_LDS_GATHER")) ctx->lds_gather = std::atoi(e) != 0;
@@ -160,7 +161,7 @@ int hrt_ctx_destroy(HrtContext *ctx) {
         void *sp[] = {st.rays[0], st.rays[1], st.hit_tuvp, st.hit_inst, st.bin_items, st.chain, st.result, st.stages};
         for (void *p : sp) if (p) (void)hipFree(p);
     }
-    void *ptrs[] = {w.accum, w.rows, ctx->d_jump, ctx->d_stats, ctx->d_hitgroups, ctx->d_inst_program};
+    void *ptrs[] = {w.accum, w.slice_cost, w.slice_order, w.rows, ctx->d_jump, ctx->d_stats, ctx->d_hitgroups, ctx->d_inst_program};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->sub_done) (void)hipEventDestroy(e);
@@ -327,9 +328,40 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
             blocks_per_cu = std::min(blocks_per_cu, std::max(fit, 4u));
         }
         const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * blocks_per_cu, (n + 63u) / 64u);
+        // Longest-processing-time-first: a pixel's samples run one after the other in one lane, so a render ends with
+        // whatever pixels were started last.  For renders of many samples the first sample is a probe launch of its own
+        // that records how long each slice's pixels took over their sample; the slices are then handed out slowest first,
+        // and the render ends on pixels whose paths leave the scene at once.  (The image does not depend on the order.)
+        uint32_t done_spp = 0;
+        const uint32_t n_slices = (n + ta.fetch_chunk - 1u) / ta.fetch_chunk;
+        // Worth it when a lane gets only a few pixels (the tiles of the multi-GPU split: 1/4 of the C4 frame 238 -> 219 ms);
+        // a full frame has ~6 pixels per lane, a tail of a few percent, and keeps its single launch.
+        if (ctx->fused_lpt && spp >= 16u && n_slices >= 4096u && (uint64_t)n < 4ull * 64ull * (uint64_t)grid) {
+            if (n_slices > w.slice_capacity) {
+                for (uint32_t *p : {w.slice_cost, w.slice_order}) if (p) (void)hipFree(p);
+                w.slice_cost = w.slice_order = nullptr; w.slice_capacity = 0;
+                HIP_TRY(ctx, hipMalloc((void **)&w.slice_cost, sizeof(uint32_t) * n_slices));
+                HIP_TRY(ctx, hipMalloc((void **)&w.slice_order, sizeof(uint32_t) * n_slices));
+                w.slice_capacity = n_slices;
+            }
+            HIP_TRY(ctx, hipMemsetAsync(w.slice_cost, 0, sizeof(uint32_t) * n_slices, s));
+            HIP_TRY(ctx, hipMemsetAsync(stg, 0, sizeof(StageCounters), s));
+            const uint32_t probe_spp = (uint32_t)std::min<int>(std::max(ctx->fused_lpt, 1), (int)spp / 4);
+            pa.spp = probe_spp; pa.continue_sum = 0u; pa.slice_cost = w.slice_cost; pa.slice_order = nullptr;
+            { Timer tm(ctx, s, HRT_K_PATHS); launch_paths(ta, t->has_spheres, grid, s); }
+            ctx->h_slice_cost.resize(n_slices); ctx->h_slice_order.resize(n_slices);
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_slice_cost.data(), w.slice_cost, sizeof(uint32_t) * n_slices, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            for (uint32_t i = 0; i < n_slices; ++i) ctx->h_slice_order[i] = i;
+            std::stable_sort(ctx->h_slice_order.begin(), ctx->h_slice_order.end(),
+                             [&](uint32_t x, uint32_t y) { return ctx->h_slice_cost[x] > ctx->h_slice_cost[y]; });
+            HIP_TRY(ctx, hipMemcpyAsync(w.slice_order, ctx->h_slice_order.data(), sizeof(uint32_t) * n_slices, hipMemcpyHostToDevice, s));
+            pa.slice_cost = nullptr; pa.slice_order = w.slice_order;
+            done_spp = probe_spp;
+        }
         // very long renders are cut into launches of at most fused_max_spp samples (a launch should stay in the
         // range of seconds); the RNG states and the running sums carry over, so the result is the same bits
-        for (uint32_t done_spp = 0; done_spp < spp;) {
+        while (done_spp < spp) {
             const uint32_t now = std::min<uint32_t>(spp - done_spp, (uint32_t)ctx->fused_max_spp);
             pa.spp = now; pa.continue_sum = done_spp > 0 ? 1u : 0u;
             HIP_TRY(ctx, hipMemsetAsync(stg, 0, sizeof(StageCounters), s));

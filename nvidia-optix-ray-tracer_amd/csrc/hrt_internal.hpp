@@ -84,6 +84,7 @@ struct Workspace {
     SampleSet set[2];
     float4 *accum = nullptr;
     uint32_t *rows = nullptr;
+    uint32_t *slice_cost = nullptr, *slice_order = nullptr; uint32_t slice_capacity = 0;   // fused mode: cost-ordered slices
 };
 
 struct TimedSpan { int kind; hipEvent_t a, b; };
@@ -114,6 +115,7 @@ struct HrtContext {
     uint32_t *d_jump = nullptr;
     // workspace + stats
     Workspace ws;
+    std::vector<uint32_t> h_slice_cost, h_slice_order;
     std::vector<uint32_t> h_rows; HrtTile rows_tile{0, 0, 0, 0, 0}; uint32_t rows_w = 0, rows_h = 0;
     DeviceStats *d_stats = nullptr;
     uint64_t paths = 0;
@@ -131,6 +133,7 @@ struct HrtContext {
     int node_stride = 80, prim_stride = 64;     // bytes between records in HBM (80/48 packed; 128/64 = one cache line each)
     int fused = 1;                              // 1: fused persistent path mode (default), 0: wavefront kernels, -1: fused only for small tiles
     int fused_max_pixels = 700000;
+    int fused_lpt = 2;                          // samples of the probe launch that orders the slices by cost for the rest of the render (0: off)
     int fused_max_spp = 512;                    // samples per fused launch
     int lds_gather = 0;                         // 1: cooperative LDS-DMA gathers, 0: per-lane register loads
     int fetch_chunk = 64;

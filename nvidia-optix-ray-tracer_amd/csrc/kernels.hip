@@ -419,6 +419,7 @@ __global__ __launch_bounds__(kTraverseBlock, 5) void k_traverse(TraverseArgs a) 
     uint32_t px_local = 0u, px_tid = 0u, px_sample = 0u, px_depth = 1u;
     uint32_t px_chain[4] = {0u, 0u, 0u, 0u};
     float px_ax = 0.0f, px_ay = 0.0f, px_az = 0.0f;
+    uint32_t px_t0 = 0u;                                    // probe launch: clock at the pixel's start
     float px_pdx = 0.0f, px_pdy = 0.0f, px_pdz = 1.0f;      // the pixel's primary direction: the same for every sample (no jitter, Shader.cu:249-261)
     Xorwow px_rng{};
     uint32_t px_rays_closest = 0u, px_rays_any = 0u;
@@ -497,6 +498,8 @@ __global__ __launch_bounds__(kTraverseBlock, 5) void k_traverse(TraverseArgs a) 
                         if (px_first) { px_ax = r.x; px_ay = r.y; px_az = r.z; px_first = false; }
                         else { px_ax += r.x; px_ay += r.y; px_az += r.z; }
                         ++px_sample;
+                        if (a.path.slice_cost)     // probe launch: how long this pixel's sample took, start of its primary ray to here
+                            atomicAdd(a.path.slice_cost + px_local / a.fetch_chunk, ((uint32_t)__builtin_amdgcn_s_memtime() - px_t0) >> 4);
                         if (px_sample >= a.path.spp) {
                             a.path.accum[px_local] = make_float4(px_ax, px_ay, px_az, 0.0f);
                             rng_store(a.path.states + px_tid, px_rng);
@@ -526,8 +529,11 @@ __global__ __launch_bounds__(kTraverseBlock, 5) void k_traverse(TraverseArgs a) 
                             uint32_t c = 0;
                             if (tx == 0u) c = atomicAdd(a.fetch_counter + shard * kFetchShardStride, 1u);
                             c = (uint32_t)__shfl((int)c, 0);
-                            const uint64_t beg = ((uint64_t)c * kFetchShards + shard) * (uint64_t)a.fetch_chunk;
-                            if (beg < (uint64_t)n_rays) {
+                            const uint64_t q = (uint64_t)c * kFetchShards + shard;          // the q-th slice handed out ...
+                            if (q * (uint64_t)a.fetch_chunk < (uint64_t)n_rays) {
+                                // ... is slice slice_order[q] of the tile: the expensive slices first, so that the render
+                                // ends on cheap pixels (longest-processing-time-first; a pixel's samples run one after the other)
+                                const uint64_t beg = (a.path.slice_order ? (uint64_t)a.path.slice_order[q] : q) * (uint64_t)a.fetch_chunk;
                                 wbeg = (uint32_t)beg;
                                 wend = (uint32_t)(beg + a.fetch_chunk < (uint64_t)n_rays ? beg + a.fetch_chunk : (uint64_t)n_rays);
                             } else kstart = k + 1;
@@ -550,6 +556,7 @@ __global__ __launch_bounds__(kTraverseBlock, 5) void k_traverse(TraverseArgs a) 
                             px_first = a.path.continue_sum == 0u;         // later launches of a long render continue the pixel's sum
                             if (!px_first) { const float4 acc = a.path.accum[px_local]; px_ax = acc.x; px_ay = acc.y; px_az = acc.z; }
                             have_pixel = true; want_primary = true;
+                            if (a.path.slice_cost) px_t0 = (uint32_t)__builtin_amdgcn_s_memtime();
                             const V3 pd = primary_direction(ix, iy, a.path.width, a.path.height, a.path.U, a.path.V, a.path.W);
                             px_pdx = pd.x; px_pdy = pd.y; px_pdz = pd.z;
                         }

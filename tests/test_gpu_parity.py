@@ -705,6 +705,7 @@ MODES = {
     "wavefront-substreams": {"HRT_FUSED": "0", "HRT_SUBSTREAMS": "3", "HRT_SUBSTREAM_MIN_PIXELS": "1024"},
     "wavefront-no-tail-split-small-slices": {"HRT_FUSED": "0", "HRT_TAIL_SPLIT": "0", "HRT_FETCH_CHUNK": "16", "HRT_REFILL_THRESHOLD": "4"},
     "fused-two-samples-per-launch": {"HRT_FUSED_MAX_SPP": "2"},
+    "fused-cost-ordered-slices-off": {"HRT_FUSED_LPT": "0"},
     "fused-small-slices": {"HRT_FETCH_CHUNK": "16", "HRT_REFILL_THRESHOLD": "4", "HRT_TRAVERSE_BLOCKS_PER_CU": "3"},
     "aligned-records": {"HRT_NODE_STRIDE": "128", "HRT_PRIM_STRIDE": "64"},
 }
@@ -740,6 +741,30 @@ def test_every_execution_mode_is_bit_exact(hrt, oracle, gpu_available, monkeypat
             r.render(1)
             ref2 = osc.render(w, h, states, 1)
             assert np.array_equal(r.linear.cpu().numpy().view(np.uint32), ref2["linear"].view(np.uint32)), mode
+    finally:
+        r.close()
+
+
+def test_cost_ordered_slices_bit_exact(hrt, oracle, gpu_available):
+    """Few pixels per lane and many samples: the first samples run as a probe launch that measures the slices, the rest
+    of the render hands the slices out slowest first.  The order is free -- image, RNG states and ray count are those of
+    the oracle -- and the render did take the two launches."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    r = hrt.Renderer(0, 0)
+    try:
+        w, h, spp = 512, 288, 16
+        scene = hrt.scenes.random_soup(30000, 0.05, 8, w, h, spp)
+        r.load_scene(scene)
+        r.set_frame(w, h, hrt.scenes.SEED_SALT, aov=False, linear=True)
+        r.reset_stats()
+        r.render(spp)
+        s = r.stats()
+        assert s.kernel_launches[hrt.K_PATHS] == 2          # probe + the rest
+        states = oracle.rng_init(w, h, hrt.scenes.SEED_SALT)
+        ref = oracle.OracleScene(scene).render(w, h, states, spp)
+        assert np.array_equal(r.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32))
+        assert np.array_equal(r.rng_states_numpy(), states) and s.rays == ref["rays"]
     finally:
         r.close()
 
