@@ -65,7 +65,12 @@ int  hrt_blas_build_spheres(HrtContext *ctx, const HrtFloat3 *d_centers, const f
 int  hrt_blas_destroy(HrtContext *ctx, HrtTraversable blas);
 
 /* replaces buildIAS / updateIAS, src/Global/RendererImpl.cu:174-242.  d_instances lives in
- * device memory (reference: cudaMemcpy H2D then build, src/Global/RendererMesh.cu:151-160). */
+ * device memory (reference: cudaMemcpy H2D then build, src/Global/RendererMesh.cu:151-160).
+ * hrt_tlas_build flattens the instances into one world-space BVH8 (host SAH build).  hrt_tlas_update takes
+ * the same number of instances: when only transforms (and sbtOffsets) changed, the tree is refitted on the
+ * device, asynchronously on `stream` after one small read-back of the instance array; a changed BLAS handle
+ * or visibility mask, or a refitted tree whose boxes have grown too far, rebuilds it (as a tree over
+ * instances, which costs milliseconds).  A BLAS may be destroyed while a TLAS still instances it. */
 int  hrt_tlas_build(HrtContext *ctx, const HrtInstance *d_instances, uint32_t n_instances,
                     void *stream, HrtTraversable *out_tlas);
 int  hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_instances,
@@ -104,7 +109,8 @@ int  hrt_rng_free(HrtContext *ctx, HrtRngState *d_states, void *stream);
  * RNG streams; the colour written is colorToFloat4(mean of the samples), which for spp = 1
  * is exactly the reference's frame.  tile == NULL renders the whole frame; rows outside the
  * tile are left untouched.  The call returns after the work has been ENQUEUED on stream;
- * hrt_sync (or any stream sync) completes it. */
+ * hrt_sync (or any stream sync) completes it.  (Renders of >= 16 samples on small tiles synchronise
+ * the stream once in the middle: a probe launch orders the pixel slices by cost for the rest.) */
 int  hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params,
                        const HrtRayGenParams *h_raygen, uint32_t spp,
                        const HrtTile *tile, void *stream);
