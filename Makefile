@@ -17,7 +17,7 @@ all: lib oracle tools
 
 lib: $(LIBDIR)/libhrt.so $(LIBDIR)/libhrt_io.so
 
-$(LIBDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/device_types.h
+$(LIBDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/device_types.h $(CSRC)/srgb_pow.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -121,6 +121,12 @@ int  hrt_sync(HrtContext *ctx, void *stream);
 int  hrt_to_rgba8(HrtContext *ctx, const HrtFloat4 *d_src, HrtUchar4 *d_dst,
                   uint32_t width, uint32_t height, void *stream);
 
+/* colorToFloat4 (include/Global/DeviceFunctions.cuh:188-209) over n colours: the conversion raygen applies to its
+ * result (shader/Shader.cu:270), as a call of its own.  Both conversions pin the shader's powf(c, 1/2.4f) as the
+ * correctly rounded float of c^y, y = (double)(1.0f/2.4f) (csrc/srgb_pow.h), so the float image and the byte image are
+ * bit-exact against the oracle. */
+int  hrt_color_to_float4(HrtContext *ctx, const HrtFloat4 *d_src, HrtFloat4 *d_dst, uint32_t n, void *stream);
+
 /* ---- measurement (no reference counterpart: the reference has no timers) ------------- */
 enum { HRT_K_GENERATE = 0, HRT_K_TRAVERSE, HRT_K_TRAVERSE_ANY, HRT_K_BIN, HRT_K_SHADE,
        HRT_K_ACCUMULATE, HRT_K_FINALIZE, HRT_K_PATHS /* fused path mode */, HRT_K_REFIT /* hrt_tlas_update */, HRT_K_COUNT };

@@ -99,7 +99,7 @@ EXPORTS = [
     "hrt_blas_build_triangles", "hrt_blas_build_spheres", "hrt_blas_destroy",
     "hrt_tlas_build", "hrt_tlas_update", "hrt_tlas_destroy", "hrt_pose_instances",
     "hrt_sbt_record_pack_header", "hrt_materials_set", "hrt_miss_set",
-    "hrt_rng_init", "hrt_rng_free", "hrt_render_launch", "hrt_sync", "hrt_to_rgba8",
+    "hrt_rng_init", "hrt_rng_free", "hrt_render_launch", "hrt_sync", "hrt_to_rgba8", "hrt_color_to_float4",
     "hrt_stats_reset", "hrt_stats_get", "hrt_trace_rays", "hrt_debug_set_linear_output",
     "hrt_host_build_bvh8", "hrt_tlas_download", "hrt_host_free",
 ]
@@ -154,6 +154,7 @@ def load_library():
                                       C.POINTER(Tile), C.c_void_p]
     lib.hrt_sync.argtypes = [C.c_void_p, C.c_void_p]
     lib.hrt_to_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.hrt_color_to_float4.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     lib.hrt_stats_reset.argtypes = [C.c_void_p]
     lib.hrt_stats_get.argtypes = [C.c_void_p, C.POINTER(Stats)]
     lib.hrt_trace_rays.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float,

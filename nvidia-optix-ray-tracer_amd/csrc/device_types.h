@@ -164,6 +164,7 @@ void launch_shade(const ShadeArgs &a, int program, uint32_t grid_blocks, hipStre
 void launch_accumulate(const AccumArgs &a, uint32_t grid_blocks, hipStream_t s);
 void launch_finalize(const FinalizeArgs &a, hipStream_t s);
 void launch_to_rgba8(const float4 *src, uchar4 *dst, uint32_t n, hipStream_t s);
+void launch_color_to_float4(const float4 *src, float4 *dst, uint32_t n, hipStream_t s);
 void launch_pack_rays(const float *o, const float *d, uint32_t n, RayRec *rays, hipStream_t s);
 void launch_unpack_hits(const float4 *tuvp, const uint32_t *inst, uint32_t n, float *t, float *u, float *v,
                         uint32_t *prim, uint32_t *oinst, hipStream_t s);

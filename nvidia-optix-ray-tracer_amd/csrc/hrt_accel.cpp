@@ -103,7 +103,7 @@ void ensure_template(Blas &b) {
 //    computes every box and world-space record.  The shape the reference's own scenes have (particles instancing a
 //    few shapes); used when a refitted tree has degraded and has to be rebuilt while frames are being rendered.
 // Either way the result is one world-space BVH8: the traversal kernels do not know the difference.
-int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s, bool instanced) {
+static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s, bool instanced) {
     const uint32_t n = (uint32_t)inst.size();
     std::vector<std::shared_ptr<Blas>> refs(n);
     size_t total = 0;
@@ -241,8 +241,21 @@ int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &in
     HIP_TRY(ctx, hipStreamSynchronize(s));
     t.instanced = instanced;
     t.refits_since_build = 0;
-    t.generation++;
-    t.rebuilds++; ctx->tlas_rebuilds++;
+    return HRT_OK;
+}
+
+// (Re)build the tree of a TLAS.  The new tree is built on the side and takes the place of the old one only when
+// everything has succeeded: a failed rebuild (depth limit, out of memory) leaves the registered TLAS as it was --
+// valid and traceable -- instead of half overwritten.
+int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s, bool instanced) {
+    Tlas fresh;
+    const int rc = build_tlas_fresh(ctx, fresh, inst, s, instanced);
+    if (rc != HRT_OK) { free_tlas_device(fresh); free_tlas_host(fresh); return rc; }
+    fresh.generation = t.generation + 1;
+    fresh.refits = t.refits; fresh.rebuilds = t.rebuilds + 1;
+    std::swap(t, fresh);
+    free_tlas_device(fresh); free_tlas_host(fresh);        // the old tree
+    ctx->tlas_rebuilds++;
     return HRT_OK;
 }
 

@@ -196,6 +196,7 @@ int hrt_materials_set(HrtContext *ctx, const HrtSbtRecord *h_records, uint32_t n
 
 int hrt_miss_set(HrtContext *ctx, const HrtMissParams *h_miss) {
     if (!ctx || !h_miss) return HRT_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->miss = *h_miss;
     return HRT_OK;
 }
@@ -278,6 +279,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         return fail(ctx, HRT_ERR_INVALID, "bad tile");
     const bool same_rows = ctx->rows_w == rg->width && ctx->rows_h == rg->height && std::memcmp(&ctx->rows_tile, &tl, sizeof tl) == 0 && ctx->ws.rows;
     if (!same_rows) {
+        ctx->rows_w = ctx->rows_h = 0;       // the cached row list is being replaced: its key is valid again only once the upload below has succeeded
         ctx->h_rows.clear();
         for (uint32_t y = tl.y_begin; y < tl.y_end; ++y)
             if ((y / tl.stripe_rows) % tl.stripe_period == tl.stripe_phase) ctx->h_rows.push_back(y);
@@ -534,6 +536,14 @@ int hrt_to_rgba8(HrtContext *ctx, const HrtFloat4 *d_src, HrtUchar4 *d_dst, uint
     return HRT_OK;
 }
 
+int hrt_color_to_float4(HrtContext *ctx, const HrtFloat4 *d_src, HrtFloat4 *d_dst, uint32_t n, void *stream) {
+    if (!ctx || (n && (!d_src || !d_dst))) return HRT_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    launch_color_to_float4(reinterpret_cast<const float4 *>(d_src), reinterpret_cast<float4 *>(d_dst), n, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return HRT_OK;
+}
+
 // ---- measurement ----------------------------------------------------------------------
 int hrt_stats_reset(HrtContext *ctx) {
     if (!ctx) return HRT_ERR_INVALID;
@@ -580,6 +590,8 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
     Tlas *t;
     { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->tlas.find(tlas); if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle"); t = it->second.get(); }
     RayRec *rays = nullptr; float4 *tuvp = nullptr; uint32_t *inst = nullptr, *fetch = nullptr;
+    struct Scratch { void **p[4]; ~Scratch() { for (void **q : p) if (*q) (void)hipFree(*q); } }
+        scratch{{(void **)&rays, (void **)&tuvp, (void **)&inst, (void **)&fetch}};     // freed on every way out
     HIP_TRY(ctx, hipMalloc((void **)&rays, sizeof(RayRec) * (size_t)n_rays));
     HIP_TRY(ctx, hipMalloc((void **)&tuvp, sizeof(float4) * (size_t)n_rays));
     HIP_TRY(ctx, hipMalloc((void **)&inst, sizeof(uint32_t) * (size_t)n_rays));
@@ -600,7 +612,6 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
       launch_traverse(ta, (ctx->flags & HRT_CTX_COUNT) != 0, t->has_spheres, ctx->lds_gather != 0, grid, s); }
     launch_unpack_hits(tuvp, inst, n_rays, d_t, d_u, d_v, d_prim, d_inst, s);
     hipError_t e = hipStreamSynchronize(s);
-    (void)hipFree(rays); (void)hipFree(tuvp); (void)hipFree(inst); (void)hipFree(fetch);
     if (e != hipSuccess) return fail(ctx, HRT_ERR_HIP, "hrt_trace_rays: %s", hipGetErrorString(e));
     ctx->last_tlas = tlas;
     return HRT_OK;

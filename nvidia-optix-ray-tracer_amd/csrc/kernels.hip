@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "device_types.h"
+#include "srgb_pow.h"
 
 #pragma clang fp contract(off)
 
@@ -1020,41 +1021,7 @@ __global__ __launch_bounds__(256) void k_sum(float4 *accum, const float4 *result
 // ---------------------------------------------------------------------------------------
 // finalize: colorToFloat4(mean) and the (always zero, quirk Q3) AOVs, Shader.cu:270-272
 // ---------------------------------------------------------------------------------------
-// x^(1/2.4f) evaluated in double with +,-,*,/ only (no libm, no contraction), rounded to float
-// once: the same bits on every platform.  Replaces powf of DeviceFunctions.cuh:196-198.
-__device__ __forceinline__ float pow_inv_gamma(float xf) {
-    if (!(xf > 0.0f)) return 0.0f;
-    const double y = (double)(1.0f / 2.4f);
-    double x = (double)xf;
-    // x = m * 2^e with m in [sqrt(1/2), sqrt(2))
-    long long bits = __double_as_longlong(x);
-    int e = (int)((bits >> 52) & 0x7ff) - 1023;
-    bits = (bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL;
-    double m = __longlong_as_double(bits);
-    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
-    // ln(m) = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716
-    const double s = (m - 1.0) / (m + 1.0);
-    const double s2 = s * s;
-    double p = 1.0 / 27.0;
-    p = p * s2 + 1.0 / 25.0; p = p * s2 + 1.0 / 23.0; p = p * s2 + 1.0 / 21.0; p = p * s2 + 1.0 / 19.0;
-    p = p * s2 + 1.0 / 17.0; p = p * s2 + 1.0 / 15.0; p = p * s2 + 1.0 / 13.0; p = p * s2 + 1.0 / 11.0;
-    p = p * s2 + 1.0 / 9.0;  p = p * s2 + 1.0 / 7.0;  p = p * s2 + 1.0 / 5.0;  p = p * s2 + 1.0 / 3.0;
-    p = p * s2 + 1.0;
-    const double ln_m = 2.0 * s * p;
-    const double log2x = (double)e + ln_m * 1.4426950408889634;
-    const double z = y * log2x;                           // <= 0
-    const double zr = z < 0.0 ? (double)(long long)(z - 0.5) : (double)(long long)(z + 0.5);
-    const double f = (z - zr) * 0.6931471805599453;       // |f| <= 0.347
-    double q = 1.0 / 6227020800.0;                        // 1/13!
-    q = q * f + 1.0 / 479001600.0; q = q * f + 1.0 / 39916800.0; q = q * f + 1.0 / 3628800.0;
-    q = q * f + 1.0 / 362880.0;    q = q * f + 1.0 / 40320.0;    q = q * f + 1.0 / 5040.0;
-    q = q * f + 1.0 / 720.0;       q = q * f + 1.0 / 120.0;      q = q * f + 1.0 / 24.0;
-    q = q * f + 1.0 / 6.0;         q = q * f + 0.5;              q = q * f + 1.0;
-    q = q * f + 1.0;
-    const long long eb = (long long)((int)zr + 1023) << 52;
-    const double r = q * __longlong_as_double(eb);
-    return (float)r;
-}
+// powf(cx, 1/2.4f) of DeviceFunctions.cuh:196-198 is pinned as the correctly rounded float of cx^y: srgb_pow.h
 __device__ __forceinline__ float srgb_channel(float c) {
     const float cx = fmaxf(0.0f, fminf(c, 1.0f));
     const float px = pow_inv_gamma(cx);
@@ -1089,6 +1056,14 @@ __global__ __launch_bounds__(256) void k_to_rgba8(const float4 *src, uchar4 *dst
     q = (uint32_t)(s[2] * 256.0f); o.z = (unsigned char)(q < 255u ? q : 255u);
     o.w = 255u;
     dst[i] = o;
+}
+
+// colorToFloat4 over an array (DeviceFunctions.cuh:188-209): what raygen applies to its result (Shader.cu:270)
+__global__ __launch_bounds__(256) void k_color_to_float4(const float4 *src, float4 *dst, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = src[i];
+    dst[i] = make_float4(srgb_channel(c.x), srgb_channel(c.y), srgb_channel(c.z), 1.0f);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1164,6 +1139,9 @@ void launch_finalize(const FinalizeArgs &a, hipStream_t s) {
 }
 void launch_to_rgba8(const float4 *src, uchar4 *dst, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_to_rgba8, dim3(ceil_div(n, 256)), dim3(256), 0, s, src, dst, n);
+}
+void launch_color_to_float4(const float4 *src, float4 *dst, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_color_to_float4, dim3(ceil_div(n, 256)), dim3(256), 0, s, src, dst, n);
 }
 void launch_pack_rays(const float *o, const float *d, uint32_t n, RayRec *rays, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_pack_rays, dim3(ceil_div(n, 256)), dim3(256), 0, s, o, d, n, rays);

@@ -21,13 +21,15 @@
  *          algebra is pinned against rocRAND's host-callable xorwow engine in
  *          tests/test_oracle_cpu.py (same recurrence, different scramble constants).
  *   - device rsqrtf / powf and nvcc's FMA contraction
- *       -> pinned as 1.0f/sqrtf(x), libm powf, and NO contraction (-ffp-contract=off).
+ *       -> pinned as 1.0f/sqrtf(x), the correctly rounded powf (libm double pow + __float128 near ties,
+ *          see pow_inv_gamma_cr), and NO contraction (-ffp-contract=off).
  * Everything else follows the reference source line by line; each function cites it.
  * Paths are relative to the reference tree.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
  */
 #include <math.h>
+#include <quadmath.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -70,12 +72,57 @@ static inline int float_value_equals(float v1, float v2) { return fabsf(v1 - v2)
 /* ------------------------------------------------------------------------------------ */
 /* colour conversion: include/Global/DeviceFunctions.cuh:153-212                        */
 /* ------------------------------------------------------------------------------------ */
+/* powf(cx, 1.0f / 2.4f) of :161-163 / :196-198.  CUDA's powf is third-party arithmetic that is not in the tree
+ * (SURVEY.md 8c); it is pinned here as the CORRECTLY ROUNDED float of cx^y, y = (double)(1.0f / 2.4f) -- the one
+ * definition that libm, this file and the HIP kernels can all reproduce bit for bit.  libm's double pow is rounded to
+ * float; where that double lies within 2^-45 (relative) of the midpoint of two adjacent floats (733 of the 1 065 353 217
+ * floats in [0, 1]) the decision is taken in __float128 (libquadmath).  Over all floats in [0, 1] this differs from
+ * (float)pow(double) in exactly ONE input (cx = 0x1.20eb96p-20, a double-rounding case) and from libm's powf in
+ * 672 423 (all by 1 ULP); tests/test_oracle_cpu.py pins both counts' bounds. */
+static float pow_inv_gamma_cr(float xf) {
+    if (!(xf > 0.0f)) return 0.0f;
+    const double y = (double)(1.0f / 2.4f);                          /* invGamma :195, widened exactly */
+    const double r = pow((double)xf, y);
+    const float c = (float)r;
+    uint32_t cb; memcpy(&cb, &c, 4);
+    uint32_t ub = cb + 1u, db = cb - 1u;
+    float cu, cd; memcpy(&cu, &ub, 4); memcpy(&cd, &db, 4);
+    const double mu = 0.5 * ((double)c + (double)cu), md = 0.5 * ((double)c + (double)cd), tol = r * 0x1p-45;
+    if (fabs(r - mu) < tol || fabs(r - md) < tol) {
+        const __float128 q = powq((__float128)xf, (__float128)y);
+        float best = c; __float128 bd = fabsq(q - (__float128)c);
+        if (fabsq(q - (__float128)cu) < bd) { bd = fabsq(q - (__float128)cu); best = cu; }
+        if (fabsq(q - (__float128)cd) < bd) { bd = fabsq(q - (__float128)cd); best = cd; }
+        return best;
+    }
+    return c;
+}
+float oracle_pow_inv_gamma(float x) { return pow_inv_gamma_cr(x); }
+float oracle_pow_inv_gamma_libm_powf(float x) { return powf(x, 1.0f / 2.4f); }      /* tolerance cross-check only */
+
 static inline float srgb_channel(float c) {
     const float cx = fmaxf(0.0f, fminf(c, 1.0f));                    /* :190 */
-    const float invGamma = 1.0f / 2.4f;                              /* :195 */
-    const float px = powf(cx, invGamma);                             /* :196 */
+    const float px = pow_inv_gamma_cr(cx);                           /* :195-196, pinned as above */
     const float sx = cx < 0.0031308f ? 12.92f * cx : 1.055f * px - 0.055f;   /* :199 */
     return fmaxf(0.0f, fminf(sx, 1.0f));                             /* :204 */
+}
+/* n colours (float4 in, float4 out): colorToFloat4 over an array, for the exhaustive sweeps of the tests */
+void oracle_color_to_float4_n(const float *src4, float *dst4, uint64_t n) {
+#pragma omp parallel for schedule(static)
+    for (uint64_t i = 0; i < n; ++i) {
+        dst4[4 * i + 0] = srgb_channel(src4[4 * i + 0]);
+        dst4[4 * i + 1] = srgb_channel(src4[4 * i + 1]);
+        dst4[4 * i + 2] = srgb_channel(src4[4 * i + 2]);
+        dst4[4 * i + 3] = 1.0f;
+    }
+}
+/* pow_inv_gamma over the floats whose bit patterns are first, first + 1, ... (count of them) */
+void oracle_pow_inv_gamma_bits(uint32_t first, uint64_t count, float *out) {
+#pragma omp parallel for schedule(static)
+    for (uint64_t i = 0; i < count; ++i) {
+        const uint32_t b = first + (uint32_t)i; float x; memcpy(&x, &b, 4);
+        out[i] = pow_inv_gamma_cr(x);
+    }
 }
 void oracle_color_to_float4(const float *rgb, float *out4) {        /* colorToFloat4 :188-209 */
     out4[0] = srgb_channel(rgb[0]);

@@ -33,10 +33,13 @@ def gpu_available():
     return torch.cuda.is_available()
 
 
-@pytest.fixture()
-def renderer(hrt, gpu_available):
+@pytest.fixture(params=["production", "counting"])
+def renderer(hrt, gpu_available, request):
+    """Every scenario test runs twice: on the production kernels (context flags 0: the default fused path mode, v_rcp_f32
+    in the slab test, postponed leaf passes -- what bench.py times) and on the counting build (HRT_CTX_COUNT: wavefront
+    kernels, exact division, canonical walk order)."""
     if not gpu_available:
         pytest.skip("no GPU in this container")
-    r = hrt.Renderer(0, hrt.CTX_COUNT)
+    r = hrt.Renderer(0, 0 if request.param == "production" else hrt.CTX_COUNT)
     yield r
     r.close()

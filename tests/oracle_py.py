@@ -50,6 +50,12 @@ def lib():
     L.oracle_color_to_float4.argtypes = [C.c_void_p, C.c_void_p]
     L.oracle_color_to_uchar4.argtypes = [C.c_void_p, C.c_void_p]
     L.oracle_to_rgba8.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    L.oracle_color_to_float4_n.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.oracle_pow_inv_gamma_bits.argtypes = [C.c_uint32, C.c_uint64, C.c_void_p]
+    L.oracle_pow_inv_gamma.restype = C.c_float
+    L.oracle_pow_inv_gamma.argtypes = [C.c_float]
+    L.oracle_pow_inv_gamma_libm_powf.restype = C.c_float
+    L.oracle_pow_inv_gamma_libm_powf.argtypes = [C.c_float]
     L.oracle_configure_camera.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.oracle_construct_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.oracle_slerp.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]

@@ -116,6 +116,43 @@ def test_color_edge_cases(oracle):
     assert list(b) == [255, 0, 188, 255]          # min(u32(s * 256), 255), DeviceFunctions.cuh:178
 
 
+def test_pow_pin_correctly_rounded_all_floats(oracle):
+    """The shader's powf(c, 1/2.4f) is pinned as the correctly rounded float of c^y (oracle.c pow_inv_gamma_cr).  Sweep ALL
+    1 065 353 217 floats in [0, 1]: (1) a host compile of the product's csrc/srgb_pow.h (double-double arithmetic, no
+    libm) gives the oracle's bits for every one of them; (2) the oracle differs from (float)pow(double) in exactly the one
+    known double-rounding input; (3) libm's powf -- what a g++ build of the reference header would call -- is within
+    1 ULP everywhere sampled (tolerance cross-check)."""
+    src = Path(__file__).resolve().parent / "helpers" / "srgb_pow_host.cpp"
+    so = src.with_name("libsrgb_pow_host.so")
+    hdr = src.parents[2] / "nvidia-optix-ray-tracer_amd" / "csrc" / "srgb_pow.h"
+    if not so.exists() or so.stat().st_mtime < max(src.stat().st_mtime, hdr.stat().st_mtime):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", str(src), "-o", str(so)])
+    H = C.CDLL(str(so))
+    H.host_pow_inv_gamma_bits.argtypes = [C.c_uint32, C.c_uint64, C.c_void_p]
+    L = oracle.lib()
+    one = 0x3F800000
+    chunk = 1 << 24
+    a = np.empty(chunk, np.float32); b = np.empty(chunk, np.float32)
+    double_rounding = []
+    y = np.float64(np.float32(1.0) / np.float32(2.4))
+    for first in range(0, one + 1, chunk):
+        n = min(chunk, one + 1 - first)
+        L.oracle_pow_inv_gamma_bits(first, n, a.ctypes.data)
+        H.host_pow_inv_gamma_bits(first, n, b.ctypes.data)
+        assert np.array_equal(a[:n].view(np.uint32), b[:n].view(np.uint32)), hex(first)
+        if first in (0x35000000, 0x3F000000):              # the chunk with the known case, and one more for good measure
+            x = np.arange(first, first + n, dtype=np.uint32).view(np.float32)
+            via_double = np.power(x.astype(np.float64), y).astype(np.float32)
+            double_rounding += [float(v) for v in x[via_double != a[:n]]]
+    assert double_rounding == [float.fromhex("0x1.20eb96p-20")]
+    rng = np.random.default_rng(1)
+    xs = rng.integers(0, one + 1, 200000, dtype=np.uint32).view(np.float32)
+    got = np.array([L.oracle_pow_inv_gamma(float(v)) for v in xs[:20000]], np.float32)
+    libm = np.array([L.oracle_pow_inv_gamma_libm_powf(float(v)) for v in xs[:20000]], np.float32)
+    assert np.abs(got.view(np.int32).astype(np.int64) - libm.view(np.int32).astype(np.int64)).max() <= 1
+    assert L.oracle_pow_inv_gamma(0.0) == 0.0 and L.oracle_pow_inv_gamma(1.0) == 1.0
+
+
 def test_camera_matches_host_mirror(oracle, hrt):
     """Oracle camera basis == the product's host-side restatement, bit for bit, GL and non-GL."""
     for opengl in (True, False):
