@@ -17,7 +17,11 @@ all: lib oracle tools
 
 lib: $(LIBDIR)/libhrt.so $(LIBDIR)/libhrt_io.so
 
-$(LIBDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/device_types.h $(CSRC)/srgb_pow.h
+$(LIBDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/device_types.h $(CSRC)/srgb_pow.h $(CSRC)/trav_common.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/paths.o: $(CSRC)/paths.hip $(CSRC)/device_types.h $(CSRC)/trav_common.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -43,7 +47,7 @@ $(LIBDIR)/bvh8_build.o: $(CSRC)/bvh8_build.cpp $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
-$(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o
+$(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/paths.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -pthread
 
 # host-side readers of the reference's input formats (include/hrt_io.h): plain C++, no GPU
@@ -67,3 +71,19 @@ clean:
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib oracle tools clean
+
+# instrumented build for tools/lane_stats.py: lane-utilisation counters compiled into the path kernels
+stats: $(LIBDIR)/libhrt_stats.so
+$(LIBDIR)/libhrt_stats.so: $(CSRC)/kernels.hip $(CSRC)/paths.hip $(CSRC)/trav_common.h $(LIBDIR)/libhrt.so
+	$(HIPCC) $(HIPFLAGS) -DHRT_LANE_STATS -c $(CSRC)/kernels.hip -o $(LIBDIR)/kernels_stats.o
+	$(HIPCC) $(HIPFLAGS) -DHRT_LANE_STATS -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_stats.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LIBDIR)/kernels_stats.o $(LIBDIR)/paths_stats.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
+
+# bound-finding experiments on k_paths (tools only, never shipped): twice the slab arithmetic / twice the node loads
+exp: $(LIBDIR)/libhrt.so
+	$(HIPCC) $(HIPFLAGS) -DHRT_EXP_VALU2 -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_valu2.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_valu2.so $(LIBDIR)/kernels.o $(LIBDIR)/paths_valu2.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
+	$(HIPCC) $(HIPFLAGS) -DHRT_EXP_LOAD2 -DHRT_EXP_LOAD2_SAME -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_load2s.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_load2s.so $(LIBDIR)/kernels.o $(LIBDIR)/paths_load2s.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
+	$(HIPCC) $(HIPFLAGS) -DHRT_EXP_LOAD2 -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_load2.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_load2.so $(LIBDIR)/kernels.o $(LIBDIR)/paths_load2.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread

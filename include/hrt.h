@@ -152,9 +152,10 @@ int  hrt_stats_get(HrtContext *ctx, HrtStats *out);       /* synchronises the de
 
 /* ---- introspection used by the parity tests ------------------------------------------ */
 /* Trace n rays (origin/direction float3 arrays on the device, tmin/tmax as in the shader)
- * through a TLAS with the closest-hit kernel and write t,u,v (float) and prim,inst (u32;
- * 0xffffffff on miss) per ray.  This is the traverse kernel of hrt_render_launch run on a
- * caller-supplied queue. */
+ * through a TLAS and write t,u,v (float) and prim,inst (u32; 0xffffffff on miss) per ray.
+ * The rays go through the kernel hrt_render_launch itself runs in the context's configuration: the
+ * fused path kernel by default (each ray stands in for a pixel that is traced once and not shaded),
+ * the wavefront traverse kernel under HRT_CTX_COUNT or HRT_FUSED=0. */
 int  hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_origins,
                     const HrtFloat3 *d_directions, uint32_t n_rays, float tmin, float tmax,
                     int any_hit, float *d_t, float *d_u, float *d_v,

@@ -16,7 +16,7 @@ import os
 from pathlib import Path
 
 _PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = _PKG_DIR / "lib" / "libhrt.so"
+LIB_PATH = Path(os.environ["HRT_LIB"]) if os.environ.get("HRT_LIB") else _PKG_DIR / "lib" / "libhrt.so"   # HRT_LIB: an instrumented build (tools/lane_stats.py)
 
 # ---- struct mirrors (include/hrt_params.h) ---------------------------------------------
 

@@ -126,6 +126,12 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_NODE_STRIDE")) { const int v = std::atoi(e); if (v >= 80 && v <= 256 && v % 16 == 0) ctx->node_stride = v; }
     if (const char *e = std::getenv("HRT_PRIM_STRIDE")) { const int v = std::atoi(e); if (v >= 48 && v <= 256 && v % 16 == 0) ctx->prim_stride = v; }
     if (const char *e = std::getenv("HRT_FUSED")) ctx->fused = std::atoi(e);
+    if (const char *e = std::getenv("HRT_PATHS_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 20) ctx->paths_blocks_per_cu = v; }
+    if (const char *e = std::getenv("HRT_PATHS_SLOTS")) { const int v = std::atoi(e); if (v >= 65 && v <= 128) ctx->paths_slots = v; }
+    if (const char *e = std::getenv("HRT_PATHS_EXCHANGE")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->paths_exchange_threshold = v; }
+    if (const char *e = std::getenv("HRT_PATHS_LOW_WATER")) { const int v = std::atoi(e); if (v >= 0 && v <= 64) ctx->paths_low_water = v; }
+    if (const char *e = std::getenv("HRT_PATHS_MIN_BATCH")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->paths_min_batch = v; }
+    if (const char *e = std::getenv("HRT_PATHS_SHADE")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->paths_shade_threshold = v; }
     if (const char *e = std::getenv("HRT_TLAS_INSTANCED")) ctx->tlas_instanced = std::atoi(e);
     if (const char *e = std::getenv("HRT_REFIT")) ctx->refit = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_REFIT_REBUILD_RATIO")) { const double v = std::atof(e); if (v >= 1.0) ctx->refit_rebuild_ratio = (float)v; }
@@ -161,7 +167,7 @@ int hrt_ctx_destroy(HrtContext *ctx) {
         void *sp[] = {st.rays[0], st.rays[1], st.hit_tuvp, st.hit_inst, st.bin_items, st.chain, st.result, st.stages};
         for (void *p : sp) if (p) (void)hipFree(p);
     }
-    void *ptrs[] = {w.accum, w.slice_cost, w.slice_order, w.rows, ctx->d_jump, ctx->d_stats, ctx->d_hitgroups, ctx->d_inst_program};
+    void *ptrs[] = {w.accum, w.slice_cost, w.slice_order, w.slots, w.rows, ctx->d_jump, ctx->d_stats, ctx->d_hitgroups, ctx->d_inst_program};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->sub_done) (void)hipEventDestroy(e);
@@ -324,12 +330,25 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         // 172 ms on 12 waves per CU, 210 ms on 16).  A full frame has many pixels per lane and keeps the maximum:
         // 20 waves per CU = 5 per SIMD, for which k_traverse is compiled (__launch_bounds__(64, 5): 96 VGPRs, a few
         // spills; 2905 Mrays/s on C4 against 2835 with 4 waves of 101 VGPRs, 6 waves of 80 VGPRs spill too much: 2801).
-        uint32_t blocks_per_cu = (uint32_t)ctx->fused_blocks_per_cu;
-        if (ctx->traverse_blocks_auto) {
+        const bool v1 = ctx->fused != 3;            // 3: the slot pipeline k_paths (paths.hip); otherwise the fused kernel of kernels.hip
+        uint32_t blocks_per_cu = v1 ? (uint32_t)ctx->fused_blocks_per_cu : std::min<uint32_t>((uint32_t)ctx->paths_blocks_per_cu, paths_blocks_that_fit(ctx->paths_slots));
+        if (!v1) { ta.refill_threshold = ctx->paths_exchange_threshold; pa.shade_threshold = ctx->paths_shade_threshold; pa.low_water = ctx->paths_low_water; pa.min_batch = ctx->paths_min_batch; }
+        if (ctx->traverse_blocks_auto && v1) {
             const uint32_t fit = (uint32_t)((10ull * n + 14ull * 64ull * (uint64_t)ctx->n_cu - 1ull) / (14ull * 64ull * (uint64_t)ctx->n_cu));
             blocks_per_cu = std::min(blocks_per_cu, std::max(fit, 4u));
         }
         const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * blocks_per_cu, (n + 63u) / 64u);
+        if (!v1) {
+            const uint32_t need = grid * (uint32_t)kMaxPipeSlots;
+            if (need > w.slots_capacity) {
+                if (w.slots) (void)hipFree(w.slots);
+                w.slots = nullptr; w.slots_capacity = 0;
+                HIP_TRY(ctx, hipMalloc((void **)&w.slots, sizeof(PathSlot) * (size_t)need));
+                w.slots_capacity = need;
+            }
+            pa.slots = w.slots;
+        }
+        auto launch = [&]() { if (v1) launch_paths_v1(ta, t->has_spheres, grid, s); else launch_paths(ta, t->has_spheres, ctx->paths_slots, grid, s); };
         // Longest-processing-time-first: a pixel's samples run one after the other in one lane, so a render ends with
         // whatever pixels were started last.  For renders of many samples the first sample is a probe launch of its own
         // that records how long each slice's pixels took over their sample; the slices are then handed out slowest first,
@@ -350,7 +369,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
             HIP_TRY(ctx, hipMemsetAsync(stg, 0, sizeof(StageCounters), s));
             const uint32_t probe_spp = (uint32_t)std::min<int>(std::max(ctx->fused_lpt, 1), (int)spp / 4);
             pa.spp = probe_spp; pa.continue_sum = 0u; pa.slice_cost = w.slice_cost; pa.slice_order = nullptr;
-            { Timer tm(ctx, s, HRT_K_PATHS); launch_paths(ta, t->has_spheres, grid, s); }
+            { Timer tm(ctx, s, HRT_K_PATHS); launch(); }
             ctx->h_slice_cost.resize(n_slices); ctx->h_slice_order.resize(n_slices);
             HIP_TRY(ctx, hipMemcpyAsync(ctx->h_slice_cost.data(), w.slice_cost, sizeof(uint32_t) * n_slices, hipMemcpyDeviceToHost, s));
             HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -367,7 +386,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
             const uint32_t now = std::min<uint32_t>(spp - done_spp, (uint32_t)ctx->fused_max_spp);
             pa.spp = now; pa.continue_sum = done_spp > 0 ? 1u : 0u;
             HIP_TRY(ctx, hipMemsetAsync(stg, 0, sizeof(StageCounters), s));
-            { Timer tm(ctx, s, HRT_K_PATHS); launch_paths(ta, t->has_spheres, grid, s); }
+            { Timer tm(ctx, s, HRT_K_PATHS); launch(); }
             done_spp += now;
         }
         FinalizeArgs fa{};
@@ -600,16 +619,30 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
     launch_pack_rays(reinterpret_cast<const float *>(d_origins), reinterpret_cast<const float *>(d_directions), n_rays, rays, s);
     TraverseArgs ta{};
     ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.node_stride = t->node_stride; ta.prim_stride = t->prim_stride;
-    ta.seg[0].rays = rays; ta.seg[0].n_ptr = nullptr; ta.seg[0].n = n_rays; ta.seg[0].any_hit = any_hit ? 1u : 0u;
-    ta.seg[0].hit_tuvp = tuvp; ta.seg[0].hit_inst = inst;
-    ta.seg[0].count_nodes = any_hit ? &ctx->d_stats->nodes_any : &ctx->d_stats->nodes_closest;
-    ta.seg[0].count_prims = any_hit ? &ctx->d_stats->prims_any : &ctx->d_stats->prims_closest;
     ta.fetch_counter = fetch; ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
-    ta.tmin = tmin; ta.tmax = tmax; ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct;
-    ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fetch_chunk;
-    const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (n_rays + 63u) / 64u);
-    { Timer tm(ctx, s, any_hit ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
-      launch_traverse(ta, (ctx->flags & HRT_CTX_COUNT) != 0, t->has_spheres, ctx->lds_gather != 0, grid, s); }
+    ta.tmin = tmin; ta.tmax = tmax; ta.postpone_pct = ctx->postpone_pct;
+    const bool count = (ctx->flags & HRT_CTX_COUNT) != 0;
+    if (!count && ctx->fused > 0) {
+        // the production configuration: the rays go through the very kernel hrt_render_launch runs (fused path kernel, v_rcp_f32
+        // slab test, regeneration thresholds), each ray standing in for a pixel that is traced once and not shaded
+        ta.refill_threshold = ctx->fused_refill_threshold; ta.tail_split = 0; ta.fetch_chunk = (uint32_t)ctx->fused_fetch_chunk;
+        PathArgs &pa = ta.path;
+        pa.n_tile_pixels = n_rays; pa.first_pixel = 0; pa.width = n_rays; pa.height = 1; pa.spp = 1;
+        pa.trace_rays = rays; pa.trace_tuvp = tuvp; pa.trace_inst = inst; pa.trace_any = any_hit ? 1u : 0u;
+        pa.rays_closest = &ctx->d_stats->rays_closest; pa.rays_any = &ctx->d_stats->rays_any;
+        const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->fused_blocks_per_cu, (n_rays + 63u) / 64u);
+        Timer tm(ctx, s, HRT_K_PATHS);
+        launch_paths_v1(ta, t->has_spheres, grid, s);
+    } else {
+        ta.seg[0].rays = rays; ta.seg[0].n_ptr = nullptr; ta.seg[0].n = n_rays; ta.seg[0].any_hit = any_hit ? 1u : 0u;
+        ta.seg[0].hit_tuvp = tuvp; ta.seg[0].hit_inst = inst;
+        ta.seg[0].count_nodes = any_hit ? &ctx->d_stats->nodes_any : &ctx->d_stats->nodes_closest;
+        ta.seg[0].count_prims = any_hit ? &ctx->d_stats->prims_any : &ctx->d_stats->prims_closest;
+        ta.refill_threshold = ctx->refill_threshold; ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fetch_chunk;
+        const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (n_rays + 63u) / 64u);
+        Timer tm(ctx, s, any_hit ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
+        launch_traverse(ta, count, t->has_spheres, ctx->lds_gather != 0, grid, s);
+    }
     launch_unpack_hits(tuvp, inst, n_rays, d_t, d_u, d_v, d_prim, d_inst, s);
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) return fail(ctx, HRT_ERR_HIP, "hrt_trace_rays: %s", hipGetErrorString(e));

@@ -85,6 +85,7 @@ struct Workspace {
     float4 *accum = nullptr;
     uint32_t *rows = nullptr;
     uint32_t *slice_cost = nullptr, *slice_order = nullptr; uint32_t slice_capacity = 0;   // fused mode: cost-ordered slices
+    PathSlot *slots = nullptr; uint32_t slots_capacity = 0;                                // k_paths: kMaxPipeSlots per workgroup
 };
 
 struct TimedSpan { int kind; hipEvent_t a, b; };
@@ -131,7 +132,12 @@ struct HrtContext {
     int postpone_pct = 25;
     int tail_split = 1;
     int node_stride = 80, prim_stride = 64;     // bytes between records in HBM (80/48 packed; 128/64 = one cache line each)
-    int fused = 1;                              // 1: fused persistent path mode (default), 0: wavefront kernels, -1: fused only for small tiles
+    int fused = 1;                              // 1: fused persistent path kernel (default), 3: slot-pipeline path kernel k_paths, 0: wavefront kernels, -1: fused only for small tiles
+    int paths_slots = 112;                      // k_paths: pixels in flight per wave (80 / 96 / 112 / 128): 64 in lanes, the rest queued in LDS
+    int paths_blocks_per_cu = 20;               // k_paths: one-wave workgroups per CU, at most what the LDS holds (20 / 18 / 16 / 15 for the slot counts above)
+    int paths_exchange_threshold = 8;           // k_paths: lanes that have finished before the wave stops to exchange rays with its queues
+    int paths_low_water = 8, paths_min_batch = 24;   // k_paths: shade ahead of starvation: ray queue down to this, at least that many hits waiting
+    int paths_shade_threshold = 8;              // k_paths: idle lanes the ray queue cannot serve before a (partial) shading batch starts
     int fused_max_pixels = 700000;
     int fused_lpt = 2;                          // samples of the probe launch that orders the slices by cost for the rest of the render (0: off)
     int fused_max_spp = 512;                    // samples per fused launch

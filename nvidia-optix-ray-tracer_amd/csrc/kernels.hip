@@ -21,67 +21,11 @@
 #include <stdint.h>
 #include "device_types.h"
 #include "srgb_pow.h"
+#include "trav_common.h"
 
 #pragma clang fp contract(off)
 
 namespace hrt {
-
-// ---------------------------------------------------------------------------------------
-// small helpers
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-__device__ __forceinline__ uint32_t wave_first_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-
-struct V3 { float x, y, z; };
-__device__ __forceinline__ V3 mk3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ V3 add3(V3 a, V3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ V3 sub3(V3 a, V3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ V3 muls3(V3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ V3 divs3(V3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
-__device__ __forceinline__ V3 neg3(V3 a) { return mk3(-a.x, -a.y, -a.z); }
-__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ float len2_3(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
-__device__ __forceinline__ V3 cross3(V3 a, V3 b) {
-    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
-}
-// normalize(), include/Global/DeviceFunctions.cuh:397-404; rsqrtf pinned as 1/sqrtf
-__device__ __forceinline__ V3 normalize3(V3 a) {
-    const float len2 = len2_3(a);
-    if (len2 <= kFloatZero * kFloatZero) return mk3(0.0f, 0.0f, 1.0f);
-    const float invLen = 1.0f / sqrtf(len2);
-    return muls3(a, invLen);
-}
-__device__ __forceinline__ bool finite3(V3 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
-
-// ---------------------------------------------------------------------------------------
-// XORWOW (cuRAND curandStateXORWOW_t)
-// ---------------------------------------------------------------------------------------
-struct Xorwow { uint32_t d, v0, v1, v2, v3, v4; };
-
-__device__ __forceinline__ uint32_t xorwow_next(Xorwow &s) {
-    const uint32_t t = s.v0 ^ (s.v0 >> 2);
-    s.v0 = s.v1; s.v1 = s.v2; s.v2 = s.v3; s.v3 = s.v4;
-    s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
-    s.d += 362437u;
-    return s.v4 + s.d;
-}
-// curand_uniform: (0, 1]
-__device__ __forceinline__ float xorwow_uniform(Xorwow &s) {
-    return (float)xorwow_next(s) * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
-}
-__device__ __forceinline__ Xorwow rng_load(const RngState *st) {
-    const uint2 *p = reinterpret_cast<const uint2 *>(st);
-    const uint2 a = p[0], b = p[1], c = p[2];
-    Xorwow s; s.d = a.x; s.v0 = a.y; s.v1 = b.x; s.v2 = b.y; s.v3 = c.x; s.v4 = c.y;
-    return s;
-}
-__device__ __forceinline__ void rng_store(RngState *st, const Xorwow &s) {
-    uint2 *p = reinterpret_cast<uint2 *>(st);
-    p[0] = make_uint2(s.d, s.v0); p[1] = make_uint2(s.v1, s.v2); p[2] = make_uint2(s.v3, s.v4);
-}
-
 // curand_init(seed = tid ^ salt, subsequence = tid, offset = 0): src/Global/HostFunctions.cu:122-127,
 // bounds-checked and indexed by the frame width (quirk Q9), clock64() pinned to salt (Q8).
 // jump[k] = T^(2^(67+k)) as 160 columns of 5 words.
@@ -119,87 +63,6 @@ __global__ __launch_bounds__(256) void k_rng_init(RngState *states, uint32_t n, 
 }
 
 // ---------------------------------------------------------------------------------------
-// shading arithmetic shared by the wavefront kernels (k_generate / k_shade / k_accumulate) and the
-// fused path mode of k_traverse: one definition, hence one rounding behaviour
-// ---------------------------------------------------------------------------------------
-// pinhole ray through the centre of pixel (ix, iy): shader/Shader.cu:249-261
-__device__ __forceinline__ V3 primary_direction(uint32_t ix, uint32_t iy, uint32_t width, uint32_t height,
-                                                const float *Uc, const float *Vc, const float *Wc) {
-    const float ndcx = (((float)ix + 0.5f) / (float)width) * 2.0f - 1.0f;          // :250
-    const float ndcy = (((float)iy + 0.5f) / (float)height) * 2.0f - 1.0f;         // :251
-    const V3 U = mk3(Uc[0], Uc[1], Uc[2]), V = mk3(Vc[0], Vc[1], Vc[2]), W = mk3(Wc[0], Wc[1], Wc[2]);
-    const float aspect = (float)width / (float)height;                            // :260
-    return normalize3(add3(add3(muls3(U, ndcx * aspect), muls3(V, ndcy)), W));    // :261
-}
-
-// randomSpaceVector, include/Global/DeviceFunctions.cuh:570-582 (length = 1)
-__device__ __forceinline__ V3 random_space_vector(Xorwow &rng) {
-    V3 ret; float lengthSquare;
-    do {
-        ret.x = -1.0f + 2.0f * xorwow_uniform(rng);      // randomDouble(state, -1, 1) :220-222
-        ret.y = -1.0f + 2.0f * xorwow_uniform(rng);
-        ret.z = -1.0f + 2.0f * xorwow_uniform(rng);
-        lengthSquare = len2_3(ret);
-    } while (lengthSquare < kFloatZero * kFloatZero);
-    ret = normalize3(ret);
-    return muls3(ret, 1.0f);
-}
-
-// closesthitImpl for one (geometry, material) program, shader/Shader.cu:111-213: hit point and the
-// direction of the next ray.  rng is touched only when the program draws (rough, or metal with fuzz > 0).
-template <bool kSphere, bool kRough>
-__device__ __forceinline__ void scatter(const HitGroup &hg, V3 rayOrigin, V3 rayDirection, float t, float u, float v,
-                                        uint32_t primitiveIndex, Xorwow &rng, V3 &hitPoint, V3 &reflectDirection) {
-    hitPoint = add3(rayOrigin, muls3(rayDirection, t));                   // :114
-    V3 normalVector;
-    if (kSphere) {                                                        // :122-136
-        const float *cp = reinterpret_cast<const float *>(hg.ptr0) + 3 * (size_t)primitiveIndex;
-        const V3 sphereCenter = mk3(cp[0], cp[1], cp[2]);
-        const float sphereRadius = reinterpret_cast<const float *>(hg.ptr1)[primitiveIndex];
-        const V3 outwardNormal = divs3(sub3(hitPoint, sphereCenter), sphereRadius);
-        const bool hitFrontFace = dot3(rayDirection, outwardNormal) < 0.0f;
-        normalVector = hitFrontFace ? outwardNormal : neg3(outwardNormal);
-    } else {                                                              // :137-155
-        const float *np = reinterpret_cast<const float *>(hg.ptr0) + 9 * (size_t)primitiveIndex;
-        const V3 n1 = mk3(np[0], np[1], np[2]), n2 = mk3(np[3], np[4], np[5]), n3 = mk3(np[6], np[7], np[8]);
-        const float w = 1.0f - u - v;
-        const V3 _normal = add3(add3(muls3(n1, w), muls3(n2, u)), muls3(n3, v));
-        const bool hitFrontFace = dot3(rayDirection, _normal) < 0.0f;
-        normalVector = hitFrontFace ? _normal : neg3(_normal);
-    }
-    if (kRough) {                                                         // :169-179
-        reflectDirection = add3(normalVector, random_space_vector(rng));
-        if (fabsf(len2_3(reflectDirection) - kFloatZero * kFloatZero) < kFloatZero) reflectDirection = normalVector;
-    } else {                                                              // :180-192
-        const V3 vv = rayDirection, nn = normalVector;
-        reflectDirection = normalize3(sub3(vv, muls3(nn, 2.0f * dot3(vv, nn))));
-        if (hg.fuzz > 0.0f) reflectDirection = add3(reflectDirection, muls3(random_space_vector(rng), hg.fuzz));
-    }
-    // :202-213
-    if (!finite3(reflectDirection) || len2_3(reflectDirection) <= kFloatZero * kFloatZero) {
-        reflectDirection = normalVector;
-        if (len2_3(reflectDirection) <= kFloatZero * kFloatZero || !finite3(reflectDirection))
-            reflectDirection = mk3(0.0f, 0.0f, 1.0f);
-    }
-    // the depth-1 AOV write (:216-227) is overwritten by the terminating program (quirk Q3): nothing to keep
-}
-__device__ __forceinline__ bool program_draws(int program, const HitGroup &hg) {
-    return program == kProgramSphereRough || program == kProgramTriangleRough || hg.fuzz > 0.0f;
-}
-
-// a path that ends at `depth`: miss colour (Shader.cu:276-287) or black at the depth limit (:102-107),
-// then the albedo products of the unwinding recursion (:236-238), innermost bounce first
-__device__ __forceinline__ V3 fold_chain(bool miss, const float *bg, const uint32_t *chain, uint32_t depth,
-                                         const HitGroup *__restrict__ hitgroups) {
-    V3 r = miss ? mk3(bg[0], bg[1], bg[2]) : mk3(0.0f, 0.0f, 0.0f);
-    for (int k = (int)depth - 2; k >= 0; --k) {
-        const HitGroup hg = hitgroups[chain[k]];
-        r.x *= hg.albedo[0]; r.y *= hg.albedo[1]; r.z *= hg.albedo[2];
-    }
-    return r;
-}
-
-// ---------------------------------------------------------------------------------------
 // generate: __raygen__raygenProgram up to the trace call, shader/Shader.cu:246-267
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_generate(GenerateArgs a) {
@@ -215,161 +78,6 @@ __global__ __launch_bounds__(256) void k_generate(GenerateArgs a) {
     r.d = make_float4(dir.x, dir.y, dir.z, __uint_as_float(iy * a.width + ix));
     a.rays[q] = r;
 }
-
-// ---------------------------------------------------------------------------------------
-// traverse: persistent waves over a ray queue, BVH8 with compressed child boxes
-// ---------------------------------------------------------------------------------------
-constexpr int kLdsStack = 8;          // entries per lane staged in LDS
-constexpr int kSpillStack = 56;       // overflow entries per lane in scratch
-constexpr int kTraverseBlock = 64;         // one wave per workgroup
-constexpr uint32_t kFetchShards = 8;         // slice counters (one per XCD-group of blocks)
-constexpr uint32_t kFetchShardStride = 32;   // u32s between counters: one 128-byte line each
-
-struct TravState {
-    float ox, oy, oz, dx, dy, dz;
-    float idx, idy, idz;
-    float bt, bu, bv;
-    uint32_t bprim, binst;
-    uint32_t oct_inv4;
-    uint2 cur;
-    uint2 ptri;                   // leaf group being consumed, one primitive per iteration
-    int sp, base;                 // stack = entries [base, sp): the bottom can be given away (tail splitting)
-    uint32_t slot;
-};
-
-// 1 / d for the slab test.  The counting build divides exactly, so that its node / primitive counts equal the CPU walk of
-// the same bytes (tests); the production build takes v_rcp_f32 (1 ULP, one instruction instead of the ~10 of the IEEE
-// sequence, three times per ray): the slab test only culls, and its boxes are padded by far more than an ULP.
-template <bool EXACT>
-__device__ __forceinline__ float safe_rcp_dir(float d) {
-    const float lim = 1e-20f;
-    const float dd = fabsf(d) < lim ? copysignf(lim, d) : d;
-    return EXACT ? 1.0f / dd : __builtin_amdgcn_rcpf(dd);
-}
-
-// canonical primitive test (DESIGN.md "canonical intersector"); updates the best hit.
-template <bool HAS_SPHERES>
-__device__ __forceinline__ bool test_prim(const float4 A, const float4 B, const float4 C, TravState &s,
-                                          float tmin, float tmax_ray,
-                                          const float *__restrict__ inst_inv, const uint32_t *__restrict__ inst_identity) {
-    float t, u = 0.0f, v = 0.0f;
-    uint32_t prim = __float_as_uint(A.w), inst;
-    const V3 o = mk3(s.ox, s.oy, s.oz), d = mk3(s.dx, s.dy, s.dz);
-    if (HAS_SPHERES && __float_as_uint(C.w) == 1u) {
-        inst = __float_as_uint(B.w);
-        V3 oo = o, dd = d;
-        if (!inst_identity[inst]) {
-            const float *m = inst_inv + 12 * (size_t)inst;
-            oo = mk3(((m[0] * o.x + m[1] * o.y) + m[2] * o.z) + m[3], ((m[4] * o.x + m[5] * o.y) + m[6] * o.z) + m[7],
-                     ((m[8] * o.x + m[9] * o.y) + m[10] * o.z) + m[11]);
-            dd = mk3((m[0] * d.x + m[1] * d.y) + m[2] * d.z, (m[4] * d.x + m[5] * d.y) + m[6] * d.z,
-                     (m[8] * d.x + m[9] * d.y) + m[10] * d.z);
-        }
-        const V3 oc = sub3(oo, mk3(A.x, A.y, A.z));
-        const float r = B.x;
-        const float a = dot3(dd, dd);
-        if (!(a != 0.0f)) return false;
-        const float b = dot3(oc, dd);
-        const float cc = dot3(oc, oc) - r * r;
-        const float disc = b * b - a * cc;
-        if (!(disc >= 0.0f)) return false;
-        const float sq = sqrtf(disc);
-        const float t0 = (-b - sq) / a;
-        if (t0 > tmin && t0 < tmax_ray) t = t0;
-        else {
-            const float t1 = (-b + sq) / a;
-            if (t1 > tmin && t1 < tmax_ray) t = t1; else return false;
-        }
-    } else {
-        inst = __float_as_uint(B.w);
-        const V3 e1 = mk3(B.x, B.y, B.z), e2 = mk3(C.x, C.y, C.z);
-        const V3 pvec = cross3(d, e2);
-        const float det = dot3(e1, pvec);
-        if (!(det != 0.0f)) return false;
-        const float inv = 1.0f / det;
-        const V3 tvec = sub3(o, mk3(A.x, A.y, A.z));
-        u = dot3(tvec, pvec) * inv;
-        if (!(u >= 0.0f && u <= 1.0f)) return false;
-        const V3 qvec = cross3(tvec, e1);
-        v = dot3(d, qvec) * inv;
-        if (!(v >= 0.0f && u + v <= 1.0f)) return false;
-        t = dot3(e2, qvec) * inv;
-        if (!(t > tmin && t < tmax_ray)) return false;
-    }
-    // closest hit: min t, ties -> lowest (instance, primitive)
-    bool better = t < s.bt;
-    if (!better && t == s.bt) {
-        const uint64_t id = ((uint64_t)inst << 32) | prim, bid = ((uint64_t)s.binst << 32) | s.bprim;
-        better = id < bid;
-    }
-    if (better) { s.bt = t; s.bu = u; s.bv = v; s.bprim = prim; s.binst = inst; }
-    return better;
-}
-
-#define HRT_BYTE_F(w, k) ((float)(((w) >> (8 * (k))) & 0xffu))
-
-// ---- cooperative gathers of the traversal pipeline ------------------------------------------------
-// One ray per lane means 64 unrelated 80-byte nodes (and 48-byte primitives) per wave and step.
-// Loaded lane by lane (5 + 3 dwordx4 per lane) that is 8 wave-instructions x 64 separate L1
-// look-ups; measured, this address divergence -- not HBM, not L2 -- bounded the kernel (83 G
-// steps/s on a 20 KB tree against 232 G with identical rays).  Instead the wave gathers the 64
-// nodes with 5 LDS-DMA instructions (global_load_lds_dwordx4): LDS byte x of the 5120-byte
-// staging image belongs to node slot x / 80, so lanes 5k..5k+4 of an instruction read the five
-// consecutive 16-byte pieces of ONE node -- coalesced into one or two line look-ups -- and the
-// data lands in LDS at wave base + 16 * lane, i.e. already as [slot][piece].  Each lane then
-// reads its own slot back with ds_read_b128 (stride 80 B / 48 B is bank-conflict-free).
-// The asm has no VGPR destination, so nothing can be read before it has landed except through
-// LDS, and the two waits below carry a "memory" clobber: register-safe.  vmcnt is counted by
-// hand: primitive pieces (3) are issued first, node pieces (5) second, so the primitive needs
-// vmcnt(5) and the node vmcnt(0); VMEM operations the compiler adds can only lengthen the waits.
-__device__ __forceinline__ void gather_node_pieces(uint32_t lds_base, const void *p0, const void *p1, const void *p2,
-                                                   const void *p3, const void *p4) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, off\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "s"(lds_base) : "memory", "scc");
-}
-__device__ __forceinline__ void gather_prim_pieces(uint32_t lds_base, const void *p0, const void *p1, const void *p2) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(p0), "v"(p1), "v"(p2), "s"(lds_base) : "memory", "scc");
-}
-// Per-lane variant (template parameter DMA = false): every lane loads its own node / primitive into
-// registers.  More L1 look-ups per step, but no staging image, so more waves fit per CU.  The
-// destinations are named "+v" in the wait statements so that no use is scheduled above the wait.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void issue_prim_loads(const void *p, f32x4 &a, f32x4 &b, f32x4 &c) {
-    asm volatile("global_load_dwordx4 %0, %3, off\n\t"
-                 "global_load_dwordx4 %1, %3, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %3, off offset:32"
-                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void issue_node_loads(const void *p, u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, u32x4 &e) {
-    asm volatile("global_load_dwordx4 %0, %5, off\n\t"
-                 "global_load_dwordx4 %1, %5, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %5, off offset:32\n\t"
-                 "global_load_dwordx4 %3, %5, off offset:48\n\t"
-                 "global_load_dwordx4 %4, %5, off offset:64"
-                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void wait_prim_loads(f32x4 &a, f32x4 &b, f32x4 &c) {
-    asm volatile("s_waitcnt vmcnt(5)" : "+v"(a), "+v"(b), "+v"(c) :: "memory");
-}
-__device__ __forceinline__ void wait_node_loads(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d, u32x4 &e) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) :: "memory");
-}
-__device__ __forceinline__ void wait_prim_gather() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
-__device__ __forceinline__ void wait_node_gather() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <bool COUNT, bool HAS_SPHERES, bool DMA, bool FUSED>
 // 5 waves per SIMD: the register allocator is held to 96 VGPRs (the fused instantiations spill 27 / 71 dwords to scratch,
@@ -494,7 +202,11 @@ __global__ __launch_bounds__(kTraverseBlock, 5) void k_traverse(TraverseArgs a) 
                 if (!alive && waiting) {
                     waiting = false;
                     const bool miss = s.bprim == kMissPrim;
-                    if (miss || px_depth >= kRayTraceDepth) {
+                    if (a.path.trace_rays) {           // hrt_trace_rays on this kernel: the "pixel" is a caller's ray, its hit record the result
+                        a.path.trace_tuvp[px_local] = make_float4(s.bt, s.bu, s.bv, __uint_as_float(s.bprim));
+                        a.path.trace_inst[px_local] = s.binst;
+                        have_pixel = false;
+                    } else if (miss || px_depth >= kRayTraceDepth) {
                         const V3 r = fold_chain(miss, a.path.bg, px_chain, px_depth, a.path.hitgroups);
                         if (px_first) { px_ax = r.x; px_ay = r.y; px_az = r.z; px_first = false; }
                         else { px_ax += r.x; px_ay += r.y; px_az += r.z; }
@@ -549,21 +261,28 @@ __global__ __launch_bounds__(kTraverseBlock, 5) void k_traverse(TraverseArgs a) 
                         wbeg += take;
                         if (!alive && !have_pixel && !want_primary && rank < take) {
                             const uint32_t j = a.path.first_pixel + mine;
-                            const uint32_t row = j / a.path.width;
-                            const uint32_t ix = j - row * a.path.width;
-                            const uint32_t iy = a.path.rows[row];
-                            px_local = j; px_tid = iy * a.path.width + ix;
-                            px_sample = 0u; px_rng = rng_load(a.path.states + px_tid);
-                            px_first = a.path.continue_sum == 0u;         // later launches of a long render continue the pixel's sum
-                            if (!px_first) { const float4 acc = a.path.accum[px_local]; px_ax = acc.x; px_ay = acc.y; px_az = acc.z; }
+                            px_local = j;
                             have_pixel = true; want_primary = true;
-                            if (a.path.slice_cost) px_t0 = (uint32_t)__builtin_amdgcn_s_memtime();
-                            const V3 pd = primary_direction(ix, iy, a.path.width, a.path.height, a.path.U, a.path.V, a.path.W);
-                            px_pdx = pd.x; px_pdy = pd.y; px_pdz = pd.z;
+                            if (!a.path.trace_rays) {
+                                const uint32_t row = j / a.path.width;
+                                const uint32_t ix = j - row * a.path.width;
+                                const uint32_t iy = a.path.rows[row];
+                                px_tid = iy * a.path.width + ix;
+                                px_sample = 0u; px_rng = rng_load(a.path.states + px_tid);
+                                px_first = a.path.continue_sum == 0u;         // later launches of a long render continue the pixel's sum
+                                if (!px_first) { const float4 acc = a.path.accum[px_local]; px_ax = acc.x; px_ay = acc.y; px_az = acc.z; }
+                                if (a.path.slice_cost) px_t0 = (uint32_t)__builtin_amdgcn_s_memtime();
+                                const V3 pd = primary_direction(ix, iy, a.path.width, a.path.height, a.path.U, a.path.V, a.path.W);
+                                px_pdx = pd.x; px_pdy = pd.y; px_pdz = pd.z;
+                            }
                         }
                     }
                 }
-                if (!alive && want_primary) {
+                if (!alive && want_primary && a.path.trace_rays) {
+                    const RayRec r = a.path.trace_rays[px_local];
+                    px_depth = a.path.trace_any ? kRayTraceDepth : 1u;      // any-hit queries take the depth-limit ray's early exit
+                    start_ray(mk3(r.o.x, r.o.y, r.o.z), mk3(r.d.x, r.d.y, r.d.z));
+                } else if (!alive && want_primary) {
                     px_depth = 1u;
                     V3 pd = mk3(px_pdx, px_pdy, px_pdz);
                     if (HAS_SPHERES) {      // the sphere build is at its register limit (4 waves per SIMD): recompute instead of keeping
@@ -1111,7 +830,7 @@ void launch_traverse(const TraverseArgs &a, bool count, bool has_spheres, bool d
     }
 }
 // fused path mode: one launch renders every sample of every pixel of the tile
-void launch_paths(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s) {
+void launch_paths_v1(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s) {
     const dim3 g(grid_blocks), b(kTraverseBlock);
     if (has_spheres) hipLaunchKernelGGL((k_traverse<false, true, false, true>), g, b, 0, s, a);
     else hipLaunchKernelGGL((k_traverse<false, false, false, true>), g, b, 0, s, a);

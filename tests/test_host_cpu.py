@@ -143,3 +143,17 @@ def test_tiles_partition_the_frame(hrt):
         t = hrt.tile_for_rank(1080, rank, 8)
         sizes.append(sum(1 for y in range(1080) if (y // t.stripe_rows) % t.stripe_period == t.stripe_phase))
     assert max(sizes) - min(sizes) <= 8
+
+
+def test_hand_issued_loads_are_not_touched_before_their_wait():
+    """The traversal kernels issue their node / primitive loads from inline asm and retire them with hand-counted
+    s_waitcnt: between the two the compiler must not read, copy or spill the destination registers (it does not know they
+    are in flight).  tools/audit_asm_loads.py compiles kernels.hip and paths.hip to assembly with the Makefile's own flags
+    and checks every instantiation; any compiler or flag change that breaks the invariant fails here."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "audit_asm_loads.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 hazardous instructions" in r.stdout and "hazardous instructions" in r.stdout
