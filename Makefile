@@ -25,6 +25,10 @@ $(LIBDIR)/paths.o: $(CSRC)/paths.hip $(CSRC)/device_types.h $(CSRC)/trav_common.
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+$(LIBDIR)/build.o: $(CSRC)/build.hip $(CSRC)/build.h $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 $(LIBDIR)/refit.o: $(CSRC)/refit.hip $(CSRC)/device_types.h $(CSRC)/bvh8_geom.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -33,7 +37,7 @@ $(LIBDIR)/pose.o: $(CSRC)/pose.hip $(CSRC)/device_types.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-API_DEPS := $(CSRC)/hrt_internal.hpp $(CSRC)/device_types.h $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.h include/hrt.h include/hrt_params.h
+API_DEPS := $(CSRC)/build.h $(CSRC)/hrt_internal.hpp $(CSRC)/device_types.h $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.h include/hrt.h include/hrt_params.h
 
 $(LIBDIR)/hrt_accel.o: $(CSRC)/hrt_accel.cpp $(API_DEPS)
 	@mkdir -p $(LIBDIR)
@@ -47,7 +51,7 @@ $(LIBDIR)/bvh8_build.o: $(CSRC)/bvh8_build.cpp $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
-$(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/paths.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o
+$(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/paths.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -pthread
 
 # host-side readers of the reference's input formats (include/hrt_io.h): plain C++, no GPU
@@ -77,13 +81,13 @@ stats: $(LIBDIR)/libhrt_stats.so
 $(LIBDIR)/libhrt_stats.so: $(CSRC)/kernels.hip $(CSRC)/paths.hip $(CSRC)/trav_common.h $(LIBDIR)/libhrt.so
 	$(HIPCC) $(HIPFLAGS) -DHRT_LANE_STATS -c $(CSRC)/kernels.hip -o $(LIBDIR)/kernels_stats.o
 	$(HIPCC) $(HIPFLAGS) -DHRT_LANE_STATS -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_stats.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LIBDIR)/kernels_stats.o $(LIBDIR)/paths_stats.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LIBDIR)/kernels_stats.o $(LIBDIR)/paths_stats.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
 
 # bound-finding experiments on k_paths (tools only, never shipped): twice the slab arithmetic / twice the node loads
 exp: $(LIBDIR)/libhrt.so
 	$(HIPCC) $(HIPFLAGS) -DHRT_EXP_VALU2 -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_valu2.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_valu2.so $(LIBDIR)/kernels.o $(LIBDIR)/paths_valu2.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_valu2.so $(LIBDIR)/kernels.o $(LIBDIR)/paths_valu2.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
 	$(HIPCC) $(HIPFLAGS) -DHRT_EXP_LOAD2 -DHRT_EXP_LOAD2_SAME -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_load2s.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_load2s.so $(LIBDIR)/kernels.o $(LIBDIR)/paths_load2s.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_load2s.so $(LIBDIR)/kernels.o $(LIBDIR)/paths_load2s.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
 	$(HIPCC) $(HIPFLAGS) -DHRT_EXP_LOAD2 -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_load2.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_load2.so $(LIBDIR)/kernels.o $(LIBDIR)/paths_load2.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_load2.so $(LIBDIR)/kernels.o $(LIBDIR)/paths_load2.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread

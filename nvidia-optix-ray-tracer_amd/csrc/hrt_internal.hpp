@@ -27,10 +27,13 @@ namespace hrt {
 struct Blas {
     uint32_t kind = kPrimKindTriangle;
     uint32_t n_prims = 0;
+    // host copies of the geometry: only filled when the HOST builder is asked for (HRT_BUILD=host), from d_verts
     std::vector<float> verts;        // triangles: 9 floats each (object space)
     std::vector<float> centers;      // spheres: 3 floats each
     std::vector<float> radii;
-    float *d_verts = nullptr;        // device copy of verts: the refit re-derives the world-space records from it
+    bool host_geometry = false;
+    float *d_verts = nullptr;        // device copy of the geometry (triangles: 9 floats each; spheres: {cx, cy, cz, r}): the device
+                                     // build and every refit derive the world-space records from it
                                      // (the caller may free its vertex buffer after the build, RendererMesh.cu:116)
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};   // object-space bounds
     // object-space BVH8 of this geometry alone: the per-instance subtree of the trees over instances (built on first use)
@@ -42,7 +45,9 @@ struct Tlas {
     uint32_t n_instances = 0;
     std::vector<uint32_t> sbt_offset;      // per instance
     std::vector<uint32_t> kind;            // per instance: triangle / sphere BLAS
-    Bvh8 bvh;                               // host copy (download / stats)
+    Bvh8 bvh;                               // host copy of a HOST-built tree (empty for device builds)
+    uint32_t n_nodes = 0, n_prims = 0, n_triangles = 0, n_spheres = 0, max_depth = 0;
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     void *d_nodes = nullptr, *d_prims = nullptr;
     float *d_inst_inv = nullptr;
     uint32_t *d_inst_identity = nullptr;
@@ -55,6 +60,7 @@ struct Tlas {
     std::vector<float> h_xf, h_inv; std::vector<uint32_t> h_ident;   // staging of the per-instance uploads
     float *d_node_box = nullptr, *d_node_ref = nullptr, *d_inst_xf = nullptr, *d_area = nullptr;
     uint32_t *d_order = nullptr;                         // trees over instances: refit order (NULL: breadth-first index ranges)
+    uint32_t *d_inst_first = nullptr, *d_inst_kind = nullptr;   // device build: global number of each instance's first primitive; geometry kind
     std::vector<std::pair<uint32_t, uint32_t>> phases;   // (first, count) in processing order, children before parents
     bool instanced = false;
     const void **d_inst_src = nullptr;
@@ -145,6 +151,10 @@ struct HrtContext {
     int fetch_chunk = 64;
     int substream_min_pixels = 32768;
     int tlas_instanced = 0;                     // 1: hrt_tlas_build makes trees over instances too, 0: only rebuilds during updates do, -1: never
+    int build_on_device = 1;                    // 1: PLOC build on the GPU (build.hip), 0: binned-SAH build on the host (HRT_BUILD=host; needs a host copy of the geometry)
+    int ploc_radius = 2;                        // device build: nearest-neighbour search radius of the PLOC rounds (positions in Morton order); 2 traces fastest
+                                                // on the soup scenes (C4: 24.1 node visits per ray, 16: 28.3, 64: 36.6 -- profiles/r02_build_bench.txt)
+    float build_c_node = 1.0f, build_c_prim = 0.45f;   // collapse costs (bvh8_build.cpp has the same defaults)
     int refit = 1;                              // hrt_tlas_update: 1 = device refit when only transforms changed, 0 = always rebuild
     float refit_rebuild_ratio = 1.5f;           // rebuild when the refitted tree's weighted mean node area has grown by this factor
     uint64_t tlas_refits = 0, tlas_rebuilds = 0; double tlas_refit_ratio = 1.0;
