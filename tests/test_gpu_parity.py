@@ -954,3 +954,22 @@ def test_fused_mode_tiles(hrt, oracle, gpu_available, monkeypatch):
         assert np.array_equal(acc.view(np.uint32), ref["color"].view(np.uint32))
     finally:
         r.close()
+
+
+def test_cpp_multi_gpu_host_with_rccl(gpu_available):
+    """csrc/host/multi_gpu.hpp through the hrt_render driver: one process, N devices (here N = 1, the box has one GPU),
+    ncclCommInitAll, per-device context + stream, stripes through HrtTile, one ncclReduce(sum) of the float4 frame into
+    device 0 -- and --check renders the frame again on one context, untiled, and compares the bits."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    import subprocess
+    import tempfile
+    from pathlib import Path
+    exe = Path(__file__).resolve().parent.parent / "nvidia-optix-ray-tracer_amd" / "lib" / "hrt_render"
+    assert exe.exists(), "run `make tools`"
+    with tempfile.TemporaryDirectory() as tmp:
+        r = subprocess.run([str(exe), "20000", "320", "200", "3", str(Path(tmp) / "f.ppm"), "--gpus", "1", "--check"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "IS BIT-IDENTICAL TO" in r.stdout and "1 GPU(s)" in r.stdout
+        assert (Path(tmp) / "f.ppm").stat().st_size == 320 * 200 * 3 + len("P6\n320 200\n255\n")
