@@ -123,9 +123,11 @@ def main():
         scene["spp"] = args.spp
     W, H, spp = scene["width"], scene["height"], scene["spp"]
 
-    # the tree is built on the device (PLOC, build.hip: no host copy of the geometry, ~13 ms for the million triangles including the
-    # upload); HRT_BENCH_HOST_BUILD=1 times the frame on the host's binned-SAH tree instead (HRT_CTX_FAST_TRACE: 2 % fewer node visits)
-    device_build = os.environ.get("HRT_BENCH_HOST_BUILD") != "1"
+    # The scene is static, so trace speed is preferred to build speed, as the reference does for its geometry
+    # (OPTIX_BUILD_FLAG_PREFER_FAST_TRACE, RendererImpl.cu:94): HRT_CTX_FAST_TRACE = the host's binned-SAH tree (0.65 s, outside the timed
+    # region).  HRT_BENCH_DEVICE_BUILD=1 times the frame on the device-built PLOC tree instead (13 ms with the upload, 2.5 % more node
+    # visits per ray, ~3.5 % fewer Mrays/s: profiles/r02_build_bench.txt).
+    device_build = os.environ.get("HRT_BENCH_DEVICE_BUILD") == "1"
     r = hrt.Renderer(local_rank, hrt.CTX_TIMING | (0 if device_build else hrt.CTX_FAST_TRACE))
     t0 = time.perf_counter()
     r.load_scene(scene)
@@ -201,13 +203,28 @@ def main():
         rays_per_launch = st.rays / trav_launches
         bytes_per_launch = (b_closest * st.rays_closest + b_any * st.rays_any) / trav_launches
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        traffic = None
-        tf = ROOT / "profiles" / "traverse_traffic.json"
-        if tf.exists() and args.config == "C4" and world == 1:      # the PMC passes were taken on this workload
-            try:
-                traffic = json.loads(tf.read_text()).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # memory-side traffic and the VALU view come from the PMC passes committed for THIS workload (tools/profile_final.sh: separate
+        # --pmc runs, which cannot share a process with the timed region); the line names the files and the build they were taken on
+        traffic = traffic_source = valu = None
+        if args.config == "C4" and world == 1 and fused and args.spp == 0:
+            for tf in sorted((ROOT / "profiles").glob("r*_traverse_traffic.json"), reverse=True)[:1]:
+                try:
+                    d = json.loads(tf.read_text())
+                    traffic = d.get("fabric_bytes_per_launch")
+                    traffic_source = {"file": f"profiles/{tf.name}", "build": d.get("provenance", {}).get("build"),
+                                      "what": "bytes the L2s requested from the fabric per launch (read + write); Infinity-Cache hits included: an upper bound on HBM bytes"}
+                except Exception:
+                    traffic = None
+            for pf in sorted((ROOT / "profiles").glob("r*_pmc_fused_kernel.json"), reverse=True)[:1]:
+                try:
+                    d = json.loads(pf.read_text())
+                    if "valu" in d:
+                        valu = {"issue_slot_frac": round(d["valu"]["issue_slot_frac"], 4), "lanes_active_frac": round(d["valu"]["lanes_active_frac"], 4),
+                                "wave_time_split": {k: round(v, 4) for k, v in (d["valu"].get("wave_time_split") or {}).items()},
+                                "file": f"profiles/{pf.name}", "build": d.get("provenance", {}).get("build"),
+                                "what": "SQ_INSTS_VALU x 4 cycles / (kernel cycles x 1024 SIMDs); SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)"}
+                except Exception:
+                    valu = None
         out = {
             "metric": "Mrays/s at 1920x1080, 1M-tri scene",
             "value": round(total_rays / elapsed / 1e6, 3),
@@ -224,8 +241,14 @@ def main():
                        "rays_per_step": int(total_rays / max(args.steps, 1)), "rays_per_path": round(st.rays / max(st.paths, 1), 4),
                        "bvh_nodes": int(st.bvh_nodes), "bvh_bytes": int(st.bvh_bytes), "bvh_build_s": round(build_s, 3),
                        "bvh_builder": "device PLOC (build.hip)" if device_build else "host binned SAH (HRT_CTX_FAST_TRACE)"},
+            # `achieved` / `frac` are the ALGORITHMIC bytes (80 B per node visit + 48 B per primitive test) over the launch
+            # time: the contract's figure.  They are NOT what limits the kernel: the bytes are served by L1 / L2 / Infinity Cache
+            # (`traffic` = what reached the fabric, `measured_frac` = that over launch time over the HBM peak), and the kernel is
+            # bound by VALU issue at ~half the lanes active (`limited_by`, `valu`; DESIGN.md section 4 has the experiments).
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "measured_frac": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_ms > 0 else None,
+                         "limited_by": "valu-issue", "valu": valu, "algorithmic_gbps": round(achieved, 2),
                          "bytes_per_ray": round(b_closest, 1), "nodes_per_ray": round(nodes_per_ray, 3),
                          "prims_per_ray": round(prims_per_ray, 3), "bytes_per_any_hit_ray": round(b_any, 1),
                          "bytes_per_launch": round(bytes_per_launch, 0), "avg_launch_ms": round(avg_launch_ms, 4),
