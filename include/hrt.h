@@ -45,6 +45,12 @@ typedef struct HrtContext HrtContext;
 /* context flags */
 #define HRT_CTX_TIMING   0x1u    /* bracket every kernel with HIP events (hrt_get_stats) */
 #define HRT_CTX_COUNT    0x2u    /* traverse kernel counts node visits / primitive tests */
+#define HRT_CTX_ASYNC_UPDATE 0x8u /* hrt_tlas_update never reads the instance array back: the per-instance tables (object->world, its inverse, the
+                                    scene scale) are derived on the device and the refit is only enqueued -- the whole Time-mode frame (pose kernel,
+                                    update, launch) then runs without a host synchronisation.  The caller promises what updateIAS requires anyway
+                                    (OPTIX_BUILD_OPERATION_UPDATE, RendererImpl.cu:210-242): same BLAS handles, visibility bits and sbtOffsets as
+                                    at the build.  A broken promise and a tree that has degraded past the rebuild ratio are both detected on the
+                                    device and acted on at the NEXT update (one frame late), which then takes the synchronous path and rebuilds. */
 #define HRT_CTX_FAST_TRACE 0x4u  /* hrt_tlas_build prefers trace speed to build speed: the reference's OPTIX_BUILD_FLAG_PREFER_FAST_TRACE
                                     (its GAS builds, RendererImpl.cu:94,118,144).  The tree is then built by the host's binned-SAH builder
                                     from a host copy of the geometry (1 M triangles: ~0.65 s, ~17 % fewer node visits per ray) instead of by

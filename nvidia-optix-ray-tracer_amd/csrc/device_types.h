@@ -155,6 +155,8 @@ struct RefitArgs {
     const uint32_t *inst_identity;
     const void *const *inst_src;   // per instance: object-space triangle vertices (9 floats per triangle) of its BLAS
     float pad;
+    const uint32_t *scale_bits;    // when set: pad = 4e-6 * max(1, scene scale) with the scale read from here (float bits; written by
+                                   // k_instance_tables on the same stream), instead of the host's `pad`
     float *node_ref;               // 2 floats per node: {weight, 1 / half area as built}
     uint32_t write_reference;      // 1: this refit completes a build -- record the areas instead of comparing with them
     float *area_sum;               // weighted mean of area now / area as built (quality after the refit), may be NULL
@@ -162,6 +164,16 @@ struct RefitArgs {
 constexpr uint32_t kRefitTopLevels = 16, kRefitTopLevelNodes = 1024;
 struct RefitLevels { uint32_t n_levels; uint32_t first[kRefitTopLevels], count[kRefitTopLevels]; };   // phases in processing order, each at most kRefitTopLevelNodes wide
 void launch_refit_level(const RefitArgs &a, hipStream_t s);
+// per-instance tables of an update derived on the device from the caller's instance array (asynchronous updates)
+struct InstanceTableArgs {
+    const void *instances;         // HrtInstance[] (80 B each): transform[12], instanceId, sbtOffset, visibilityMask, flags, handle (u64), pad
+    uint32_t n;
+    const unsigned long long *sig_handle; const uint32_t *sig_visibility;   // what the tree was built with
+    const float *blas_box;         // 6 floats per instance: object-space bounds of its BLAS (lo > hi: empty)
+    float *inst_xf, *inst_inv; uint32_t *inst_identity;
+    uint32_t *flags;               // [0]: scene scale (float bits, starts at 1.0f); [1]: set when a handle or visibility bit differs
+};
+void launch_instance_tables(const InstanceTableArgs &a, hipStream_t s);
 void launch_refit_top(const RefitArgs &a, const RefitLevels &lv, hipStream_t s);
 
 // particle pose update (pose.hip)

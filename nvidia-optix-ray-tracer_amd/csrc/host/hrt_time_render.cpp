@@ -41,7 +41,10 @@ int main(int argc, char **argv) {
     const uint32_t H = argc > 6 ? (uint32_t)std::atoi(argv[6]) : (uint32_t)cfg.window_height;
 
     HrtContext *ctx = createContext(0, false);
-    if (std::getenv("HRT_TIME_RENDER_KERNEL_TIMES")) hrtCheckError(ctx, hrt_ctx_set_flags(ctx, HRT_CTX_TIMING));   // per-kernel HIP events
+    // the frame loop below only moves instances (same shapes, same records): updates may be asynchronous -- pose kernel, updateIAS and
+    // the launch are then enqueued back to back with no read-back in between (HRT_TIME_RENDER_SYNC_UPDATE=1: the synchronous update)
+    const uint32_t flags = (std::getenv("HRT_TIME_RENDER_KERNEL_TIMES") ? HRT_CTX_TIMING : 0u) | (std::getenv("HRT_TIME_RENDER_SYNC_UPDATE") ? 0u : HRT_CTX_ASYNC_UPDATE);
+    hrtCheckError(ctx, hrt_ctx_set_flags(ctx, flags));
 
     // extra geometry first (buildAddDataGAS, RendererTime.cu:73-84), then one GAS per STL shape in name order (:183-190)
     std::vector<GAS> gasAll;

@@ -39,12 +39,19 @@ void free_tlas_device(Tlas &t) {
     if (t.d_inst_first) (void)hipFree(t.d_inst_first);
     if (t.d_inst_kind) (void)hipFree(t.d_inst_kind);
     t.d_inst_first = t.d_inst_kind = nullptr;
+    if (t.d_sig_handle) (void)hipFree(t.d_sig_handle);
+    if (t.d_sig_visibility) (void)hipFree(t.d_sig_visibility);
+    if (t.d_blas_box) (void)hipFree(t.d_blas_box);
+    if (t.d_update_flags) (void)hipFree(t.d_update_flags);
+    t.d_sig_handle = nullptr; t.d_sig_visibility = nullptr; t.d_blas_box = nullptr; t.d_update_flags = nullptr;
     t.d_nodes = t.d_prims = nullptr; t.d_inst_inv = nullptr; t.d_inst_identity = nullptr;
     t.d_node_box = t.d_node_ref = t.d_inst_xf = t.d_area = nullptr; t.d_inst_src = nullptr; t.d_order = nullptr;
     t.area_pending = false;
 }
 void free_tlas_host(Tlas &t) {
     if (t.h_area) (void)hipHostFree(t.h_area);
+    if (t.h_update_flags) (void)hipHostFree(t.h_update_flags);
+    t.h_update_flags = nullptr;
     if (t.area_ready) (void)hipEventDestroy(t.area_ready);
     t.h_area = nullptr; t.area_ready = nullptr;
 }
@@ -294,6 +301,22 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
     HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_xf, t.h_xf.data(), sizeof(float) * t.h_xf.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_identity, t.h_ident.data(), sizeof(uint32_t) * t.h_ident.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync((void *)t.d_inst_src, src.data(), sizeof(void *) * src.size(), hipMemcpyHostToDevice, s));
+    {   // what asynchronous updates compare against and transform on the device
+        std::vector<float> bbox(6 * (size_t)std::max(n, 1u), 0.0f);
+        for (uint32_t i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) { bbox[6 * (size_t)i + a] = t.blas_refs[i]->lo[a]; bbox[6 * (size_t)i + 3 + a] = t.blas_refs[i]->hi[a]; }
+        std::vector<unsigned long long> sigh(std::max(n, 1u), 0ull);
+        for (uint32_t i = 0; i < n; ++i) sigh[i] = t.sig_handle[i];
+        HIP_TRY(ctx, hipMalloc((void **)&t.d_sig_handle, sizeof(unsigned long long) * sigh.size()));
+        HIP_TRY(ctx, hipMalloc((void **)&t.d_sig_visibility, sizeof(uint32_t) * std::max(n, 1u)));
+        HIP_TRY(ctx, hipMalloc((void **)&t.d_blas_box, sizeof(float) * bbox.size()));
+        HIP_TRY(ctx, hipMalloc((void **)&t.d_update_flags, sizeof(uint32_t) * 2));
+        if (!t.h_update_flags) HIP_TRY(ctx, hipHostMalloc((void **)&t.h_update_flags, sizeof(uint32_t) * 4, hipHostMallocDefault));
+        t.h_update_flags[0] = t.h_update_flags[2] = 0x3f800000u; t.h_update_flags[1] = t.h_update_flags[3] = 0u;
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_sig_handle, sigh.data(), sizeof(unsigned long long) * sigh.size(), hipMemcpyHostToDevice, s));
+        if (n) HIP_TRY(ctx, hipMemcpyAsync(t.d_sig_visibility, t.sig_visibility.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_blas_box, bbox.data(), sizeof(float) * bbox.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));            // (the staging vectors go out of scope)
+    }
     RefitArgs ra{};
     ra.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); ra.node_stride = t.node_stride;
     ra.prims = reinterpret_cast<unsigned char *>(t.d_prims); ra.prim_stride = t.prim_stride;
@@ -504,10 +527,41 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
     { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->tlas.find(tlas); if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle"); t = it->second.get(); }
     if (n != t->n_instances) return fail(ctx, HRT_ERR_INVALID, "update must keep the instance count (%u != %u)", n, t->n_instances);
     if (n && !d_instances) return fail(ctx, HRT_ERR_INVALID, "d_instances is NULL");
+    bool force_rebuild = false;
+    if ((ctx->flags & HRT_CTX_ASYNC_UPDATE) != 0 && ctx->refit != 0 && t->n_prims != 0u && n != 0u) {
+        // ---- asynchronous update: nothing is read back now.  First the verdict of the previous one (long complete). ----
+        if (t->area_pending) {
+            HIP_TRY(ctx, hipEventSynchronize(t->area_ready));
+            t->area_pending = false;
+            ctx->tlas_refit_ratio = (double)*t->h_area;
+            if (!(ctx->tlas_refit_ratio <= (double)ctx->refit_rebuild_ratio) || t->h_update_flags[1] != 0u) force_rebuild = true;
+        }
+        if (!force_rebuild) {
+            HIP_TRY(ctx, hipMemcpyAsync(t->d_update_flags, t->h_update_flags + 2, sizeof(uint32_t) * 2, hipMemcpyHostToDevice, s));
+            InstanceTableArgs ia{};
+            ia.instances = d_instances; ia.n = n; ia.sig_handle = t->d_sig_handle; ia.sig_visibility = t->d_sig_visibility; ia.blas_box = t->d_blas_box;
+            ia.inst_xf = t->d_inst_xf; ia.inst_inv = t->d_inst_inv; ia.inst_identity = t->d_inst_identity; ia.flags = t->d_update_flags;
+            launch_instance_tables(ia, s);
+            HIP_TRY(ctx, hipMemsetAsync(t->d_area, 0, sizeof(float), s));
+            RefitArgs ra{};
+            ra.nodes = reinterpret_cast<unsigned char *>(t->d_nodes); ra.node_stride = t->node_stride;
+            ra.prims = reinterpret_cast<unsigned char *>(t->d_prims); ra.prim_stride = t->prim_stride;
+            ra.node_box = t->d_node_box; ra.node_ref = t->d_node_ref; ra.inst_xf = t->d_inst_xf; ra.inst_identity = t->d_inst_identity; ra.inst_src = t->d_inst_src;
+            ra.scale_bits = t->d_update_flags; ra.area_sum = t->d_area; ra.order = t->d_order;
+            { Timer tm(ctx, s, HRT_K_REFIT); launch_refit_phases(ra, t->phases, s); }
+            HIP_TRY(ctx, hipGetLastError());
+            HIP_TRY(ctx, hipMemcpyAsync(t->h_area, t->d_area, sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipMemcpyAsync(t->h_update_flags, t->d_update_flags, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipEventRecord(t->area_ready, s));
+            t->area_pending = true;
+            t->refits++; t->refits_since_build++; ctx->tlas_refits++;
+            return HRT_OK;
+        }
+    }
     std::vector<HrtInstance> inst;
     const int rc = download_instances(ctx, d_instances, n, s, inst);
     if (rc != HRT_OK) return rc;
-    bool same = ctx->refit != 0 && t->n_prims != 0u;
+    bool same = ctx->refit != 0 && t->n_prims != 0u && !force_rebuild;
     for (uint32_t i = 0; i < n && same; ++i)
         same = inst[i].traversableHandle == t->sig_handle[i] && (inst[i].visibilityMask & 1u) == t->sig_visibility[i];
     if (same && t->area_pending) {

@@ -61,6 +61,10 @@ struct Tlas {
     float *d_node_box = nullptr, *d_node_ref = nullptr, *d_inst_xf = nullptr, *d_area = nullptr;
     uint32_t *d_order = nullptr;                         // trees over instances: refit order (NULL: breadth-first index ranges)
     uint32_t *d_inst_first = nullptr, *d_inst_kind = nullptr;   // device build: global number of each instance's first primitive; geometry kind
+    // asynchronous updates (HRT_CTX_ASYNC_UPDATE): what the tree was built with, for the device-side tables kernel, and its verdict
+    unsigned long long *d_sig_handle = nullptr; uint32_t *d_sig_visibility = nullptr; float *d_blas_box = nullptr;
+    uint32_t *d_update_flags = nullptr;                  // [0] scene scale (float bits), [1] handle / visibility changed
+    uint32_t *h_update_flags = nullptr;                  // pinned: [0..1] copy of the above after the last update, [2..3] their initial values
     std::vector<std::pair<uint32_t, uint32_t>> phases;   // (first, count) in processing order, children before parents
     bool instanced = false;
     const void **d_inst_src = nullptr;

@@ -28,6 +28,7 @@ __device__ __forceinline__ void refit_slot(const RefitArgs &a, uint32_t node, ui
 
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     uint32_t meta = 0;
+    const float pad = a.scale_bits ? 4e-6f * fmaxf(1.0f, __uint_as_float(a.scale_bits[0])) : a.pad;
     if (live) {
         const uint32_t imask = ndw[3] >> 24, child_base = ndw[4], prim_base = ndw[5];
         meta = nd[24 + slot];
@@ -61,7 +62,7 @@ __device__ __forceinline__ void refit_slot(const RefitArgs &a, uint32_t node, ui
                         sphere_world_bounds(c3, rf[4], m, ident, plo, phi);
                     }
                     if (finite_box(plo, phi))
-                        for (int q = 0; q < 3; ++q) { lo[q] = fminf(lo[q], plo[q] - a.pad); hi[q] = fmaxf(hi[q], phi[q] + a.pad); }
+                        for (int q = 0; q < 3; ++q) { lo[q] = fminf(lo[q], plo[q] - pad); hi[q] = fmaxf(hi[q], phi[q] + pad); }
                 }
             }
         }
@@ -136,6 +137,54 @@ __global__ __launch_bounds__(1024) void k_refit_top(RefitArgs a, RefitLevels lv)
         __threadfence_block();
         __syncthreads();                                       // the next level reads this level's node boxes
     }
+}
+
+// ---- instance tables on the device (asynchronous hrt_tlas_update): what hrt_accel.cpp's instance_tables / invert_affine
+// compute on the host, from the instance array where it lies.  One thread per instance. ----
+__global__ __launch_bounds__(256) void k_instance_tables(InstanceTableArgs a) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.n) return;
+    const float *m = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(a.instances) + 80 * (size_t)i);
+    const uint32_t *u = reinterpret_cast<const uint32_t *>(m);
+    const uint32_t visibility = u[14] & 1u;
+    const unsigned long long handle = *reinterpret_cast<const unsigned long long *>(u + 16);
+    if (handle != a.sig_handle[i] || visibility != a.sig_visibility[i]) atomicOr(&a.flags[1], 1u);
+    float t[12];
+    for (int k = 0; k < 12; ++k) { t[k] = m[k]; a.inst_xf[12 * (size_t)i + k] = t[k]; }
+    const bool id = t[0] == 1.0f && t[1] == 0.0f && t[2] == 0.0f && t[3] == 0.0f && t[4] == 0.0f && t[5] == 1.0f && t[6] == 0.0f && t[7] == 0.0f &&
+                    t[8] == 0.0f && t[9] == 0.0f && t[10] == 1.0f && t[11] == 0.0f &&
+                    !(__float_as_uint(t[1]) | __float_as_uint(t[2]) | __float_as_uint(t[3]) | __float_as_uint(t[4]) | __float_as_uint(t[6]) | __float_as_uint(t[7]) |
+                      __float_as_uint(t[8]) | __float_as_uint(t[9]) | __float_as_uint(t[11]));      // bitwise, as the host's memcmp (-0 is not identity)
+    a.inst_identity[i] = id ? 1u : 0u;
+    {   // world -> object: cofactors in double, rounded once (invert_affine of hrt_accel.cpp)
+        const double aa = t[0], b = t[1], c = t[2], d = t[4], e = t[5], f = t[6], g = t[8], h = t[9], ii = t[10];
+        const double A = e * ii - f * h, B = -(d * ii - f * g), C = d * h - e * g;
+        const double det = aa * A + b * B + c * C;
+        const double r = 1.0 / det;
+        const double n00 = A * r, n01 = -(b * ii - c * h) * r, n02 = (b * f - c * e) * r;
+        const double n10 = B * r, n11 = (aa * ii - c * g) * r, n12 = -(aa * f - c * d) * r;
+        const double n20 = C * r, n21 = -(aa * h - b * g) * r, n22 = (aa * e - b * d) * r;
+        const double tx = t[3], ty = t[7], tz = t[11];
+        float *o = a.inst_inv + 12 * (size_t)i;
+        o[0] = (float)n00; o[1] = (float)n01; o[2] = (float)n02; o[3] = (float)(-(n00 * tx + n01 * ty + n02 * tz));
+        o[4] = (float)n10; o[5] = (float)n11; o[6] = (float)n12; o[7] = (float)(-(n10 * tx + n11 * ty + n12 * tz));
+        o[8] = (float)n20; o[9] = (float)n21; o[10] = (float)n22; o[11] = (float)(-(n20 * tx + n21 * ty + n22 * tz));
+    }
+    // largest |coordinate| of the transformed BLAS box: the scene scale the padding is derived from
+    const float *bb = a.blas_box + 6 * (size_t)i;
+    if (visibility && bb[0] <= bb[3]) {
+        float smax = 1.0f;
+        for (int cidx = 0; cidx < 8; ++cidx) {
+            const float q[3] = {(cidx & 1) ? bb[3] : bb[0], (cidx & 2) ? bb[4] : bb[1], (cidx & 4) ? bb[5] : bb[2]};
+            float w[3];
+            if (id) { w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; } else xf_point(t, q, w);
+            for (int k = 0; k < 3; ++k) if (fabsf(w[k]) <= 3.0e38f) smax = fmaxf(smax, fabsf(w[k]));
+        }
+        atomicMax(&a.flags[0], __float_as_uint(smax));         // positive floats order like their bits
+    }
+}
+void launch_instance_tables(const InstanceTableArgs &a, hipStream_t s) {
+    if (a.n) hipLaunchKernelGGL(k_instance_tables, dim3((a.n + 255u) / 256u), dim3(256), 0, s, a);
 }
 
 void launch_refit_level(const RefitArgs &a, hipStream_t s) {

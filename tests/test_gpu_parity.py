@@ -384,6 +384,72 @@ def test_particle_animation_refit_every_frame(hrt, oracle, renderer):
     assert s.tlas_refits >= 4
 
 
+def test_asynchronous_update_frames(hrt, oracle, gpu_available, monkeypatch):
+    """HRT_CTX_ASYNC_UPDATE: hrt_tlas_update derives the instance tables on the device (k_instance_tables: object->world,
+    inverse in double, identity flags, scene scale) and only enqueues the refit -- no read-back of the instance array.  The
+    frames of a particle animation (shared shapes, the huge ground sphere, spheres under rotation in the mixed scene) are
+    the oracle's bit for bit, i.e. the device tables equal the host's; a changed BLAS handle (a broken promise) is detected
+    on the device and rebuilt at the next update."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    import torch
+    monkeypatch.setenv("HRT_REFIT_REBUILD_RATIO", "1e30")      # the quality guard is not what is tested here
+    r = hrt.Renderer(0, hrt.CTX_ASYNC_UPDATE)
+    try:
+        w, h, salt, n_p = 72, 48, 99, 27
+        scene = hrt.scenes.particle_scene(n_p, w, h, 1, frame=0)
+        r.load_scene(scene)
+        r.set_frame(w, h, salt, linear=True)
+        states = oracle.rng_init(w, h, salt)
+        ground = scene["instances"][0]["transform"]
+        for frame in range(1, 5):
+            poses = hrt.scenes.particle_poses(n_p, frame)
+            r.update_instances([ground] + poses)
+            for it, m in zip(scene["instances"][1:], poses):
+                it["transform"] = m
+            r.render(1)
+            ref = oracle.OracleScene(scene).render(w, h, states, 1)
+            assert np.array_equal(r.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32)), frame
+        s = r.stats()
+        assert s.tlas_refits == 4 and s.tlas_rebuilds == 1
+        # spheres under a rotation + scale (the inverse matters), triangles under a shear-free affine map
+        scene = hrt.scenes.mixed_test_scene(900, 20, 5, 64, 48, 1)
+        r.load_scene(scene)
+        moved = [it["transform"].copy() for it in scene["instances"]]
+        moved[0][3] += 0.25
+        moved[1] = hrt.scenes.rigid_transform((0.1, -0.2, 0.05), (0.3, 1.0, 0.2), 0.7, 1.1)
+        moved[3] = hrt.scenes.rigid_transform((0.05, 0.02, -0.1), (1.0, 0.2, 0.1), 1.3, 0.8)
+        moved[4] = hrt.scenes.rigid_transform((-0.1, 0.1, 0.0), (0.0, 0.0, 1.0), 0.4)
+        before = r.stats()
+        r.update_instances(moved)
+        for it, m in zip(scene["instances"], moved):
+            it["transform"] = m
+        _moved_scene_matches_oracle(hrt, oracle, r, scene, 64, 48, 7)
+        assert r.stats().tlas_refits == before.tlas_refits + 1
+        # a broken promise: another BLAS handle in the array.  This update still refits (nothing is read back) ...
+        tri = [i for i, it in enumerate(scene["instances"]) if it["geometry"] == "triangles"]
+        r._h_inst[tri[0]].traversableHandle, r._h_inst[tri[1]].traversableHandle = r._h_inst[tri[1]].traversableHandle, r._h_inst[tri[0]].traversableHandle
+        r._d_inst.copy_(torch.from_numpy(np.frombuffer(bytes(r._h_inst), dtype=np.uint8).copy()))
+        mid = r.stats()
+        r._check(r.lib.hrt_tlas_update(r.ctx, r.tlas, r._d_inst.data_ptr(), len(moved), r._stream()), "update")
+        assert r.stats().tlas_rebuilds == mid.tlas_rebuilds
+        # ... and the next one has the device's verdict and rebuilds with the handles as they are now
+        r._check(r.lib.hrt_tlas_update(r.ctx, r.tlas, r._d_inst.data_ptr(), len(moved), r._stream()), "update")
+        assert r.stats().tlas_rebuilds == mid.tlas_rebuilds + 1
+        a, b = scene["instances"][tri[0]], scene["instances"][tri[1]]
+        for key in ("vertices", "normals"):
+            a[key], b[key] = b[key], a[key]
+        # (the SBT records still point at the normals of the instances' old geometry: swap them back into place for the oracle)
+        for key in ("normals",):
+            a[key], b[key] = b[key], a[key]
+        o, d = oracle.random_rays(20000, 31)
+        t, u, v, prim, inst = r.trace_rays(o, d)
+        rt, ru, rv, rprim, rinst = oracle.OracleScene(scene, force_brute=True).trace(o, d)
+        assert np.array_equal(prim, rprim) and np.array_equal(inst, rinst) and np.array_equal(t.view(np.uint32), rt.view(np.uint32))
+    finally:
+        r.close()
+
+
 def test_pose_instances_matches_oracle(hrt, oracle, renderer):
     """hrt_pose_instances (slerp -> quatToEuler -> constructTransformMatrix on the device, RendererTime.cu:436-472)
     against the oracle, which calls float libm like the reference.  Bars: the translation column has no

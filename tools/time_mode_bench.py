@@ -14,7 +14,7 @@ hrt = importlib.import_module("nvidia-optix-ray-tracer_amd")
 def run(n_particles, subdiv, frames, w=1200, h=800):
     import torch
     scene = hrt.scenes.particle_scene(n_particles, w, h, 1, subdiv=subdiv)
-    r = hrt.Renderer(0, 0)
+    r = hrt.Renderer(0, 0 if os.environ.get("HRT_SYNC_UPDATE") else hrt.CTX_ASYNC_UPDATE)
     r.load_scene(scene)
     r.set_frame(w, h, hrt.scenes.SEED_SALT, aov=False)
     cur = r._dev(hrt.scenes.particle_states(n_particles, 0))
