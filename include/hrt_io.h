@@ -8,6 +8,8 @@
  *   hrt_io_construct_transform MathHelper::constructTransformMatrix, include/Global/DeviceFunctions.cuh:133-148 (host, float libm)
  *   hrt_io_load_config         ProgramArgumentParser::parseProgramArguments, src/Util/ProgramArgumentParser.cu:4-165
  *   hrt_io_read_mesh_cache / hrt_io_write_mesh_cache   Mesh-mode particleN.cache, src/Util/VTKMeshReader.cu:54-72,217-257
+ *   hrt_io_read_metadata_cache / hrt_io_write_metadata_cache   metadata.cache, src/Util/VTKMeshReader.cu:196-205,273-282
+ *   hrt_io_read_vtk_mesh_file   Mesh-mode VTK files (triangle strips + cell data), src/Util/VTKReaderImpl.cpp:24-137
  * Every function returns 0 on success; hrt_io_last_error() describes the last failure of the calling thread
  * (the reference logs and exit()s instead: src/Util/VTKReaderImpl.cpp, VTK_READER_ERROR_EXIT_CODE).
  */
@@ -95,6 +97,21 @@ typedef struct HrtIoMeshCache {
 int  hrt_io_read_mesh_cache(const char *path, HrtIoMeshCache *out);
 int  hrt_io_write_mesh_cache(const char *path, const HrtIoMeshCache *in);
 void hrt_io_free_mesh_cache(HrtIoMeshCache *c);
+
+/* metadata.cache of a cache directory (VTKMeshReader.cuh:23; written at VTKMeshReader.cu:196-205, read at :273-282): the
+ * largest cell count of any VTK file of the series, as decimal text -- it sizes the material array of Mesh mode.
+ * `directory` ends with a separator, as the reference's cache path does. */
+int  hrt_io_read_metadata_cache(const char *directory, uint64_t *out_max_cell_count);
+int  hrt_io_write_metadata_cache(const char *directory, uint64_t max_cell_count);
+
+/* Mesh-mode VTK file with embedded geometry (vtk_reader::readVTKMeshFile, src/Util/VTKReaderImpl.cpp:24-137): legacy ASCII
+ * POLYDATA whose cells are TRIANGLE_STRIPS, one strip per particle, with CELL_DATA `id` and `vel`.  Strip k yields
+ * (points - 2) triangles, odd ones with their last two vertices swapped (:96-104); every triangle vertex carries its POINT's
+ * normal = the normalised sum of the unit normals of the triangles that use the point (vtkPolyDataNormals with point normals,
+ * no splitting; its consistency / auto-orientation passes are not applied: consistently wound input is assumed).  The result
+ * has the layout of a cache file, so hrt_io_write_mesh_cache(out) writes what the reference's cache run writes.
+ * *out_cell_count (may be NULL) receives the file's cell count (the reference's maxCellCountSingleFile candidate). */
+int  hrt_io_read_vtk_mesh_file(const char *path, HrtIoMeshCache *out, uint64_t *out_cell_count);
 
 #ifdef __cplusplus
 }

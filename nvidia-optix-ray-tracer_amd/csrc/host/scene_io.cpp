@@ -413,6 +413,134 @@ int hrt_io_write_mesh_cache(const char *path, const HrtIoMeshCache *c) {
     return o ? 0 : fail(std::string("write failed: ") + path);
 }
 
+// ---- metadata.cache -----------------------------------------------------------------------------------
+int hrt_io_read_metadata_cache(const char *directory, uint64_t *out_max_cell_count) {
+    if (!directory || !out_max_cell_count) return fail("hrt_io_read_metadata_cache: NULL argument");
+    const std::string path = std::string(directory) + "metadata.cache";
+    std::ifstream in(path, std::ios::in);
+    if (!in) return fail("cannot open " + path);
+    uint64_t v = 0;
+    in >> v;                                             // `metaData >> maxCount`, VTKMeshReader.cu:277
+    if (in.fail()) return fail(path + ": no cell count");
+    *out_max_cell_count = v;
+    return 0;
+}
+
+int hrt_io_write_metadata_cache(const char *directory, uint64_t max_cell_count) {
+    if (!directory) return fail("hrt_io_write_metadata_cache: NULL argument");
+    const std::string path = std::string(directory) + "metadata.cache";
+    std::ofstream o(path, std::ios::out);
+    if (!o) return fail("cannot create " + path);
+    o << max_cell_count;                                 // `metaData << maxCellCount`, VTKMeshReader.cu:203: decimal text, no newline
+    o.close();
+    return o ? 0 : fail("write failed: " + path);
+}
+
+// ---- Mesh-mode VTK file: triangle strips + cell data ---------------------------------------------------
+int hrt_io_read_vtk_mesh_file(const char *path, HrtIoMeshCache *out, uint64_t *out_cell_count) {
+    if (!path || !out) return fail("hrt_io_read_vtk_mesh_file: NULL argument");
+    std::memset(out, 0, sizeof *out);
+    std::string text;
+    if (!read_text(path, text)) return fail(std::string("cannot open VTK file ") + path);
+    if (text.compare(0, 14, "# vtk DataFile") != 0) return fail(std::string(path) + ": not a legacy VTK file");
+    Tokens tk(text);
+    tk.skip_line(); ++tk.p;                             // version line
+    tk.skip_line(); ++tk.p;                             // title line
+    std::string t;
+    if (!tk.next(t) || t != "ASCII") return fail(std::string(path) + ": only ASCII legacy VTK is supported");
+    std::vector<double> points, id, vel;
+    std::vector<std::vector<uint64_t>> strips;
+    uint64_t n_points = 0, n_cells = 0; bool in_cell_data = false;
+    auto read_values = [&](size_t count, std::vector<double> *dst) -> bool {
+        for (size_t i = 0; i < count; ++i) { double d; if (!tk.number(d)) return false; if (dst) dst->push_back(d); }
+        return true;
+    };
+    while (tk.next(t)) {
+        if (t == "DATASET") { if (!tk.next(t) || t != "POLYDATA") return fail(std::string(path) + ": DATASET POLYDATA expected"); }
+        else if (t == "POINTS") {
+            double cnt; std::string type;
+            if (!tk.number(cnt) || !tk.next(type)) return fail(std::string(path) + ": bad POINTS header");
+            n_points = (uint64_t)cnt;
+            if (!read_values(3 * n_points, &points)) return fail(std::string(path) + ": short POINTS block");
+        } else if (t == "TRIANGLE_STRIPS") {
+            double cells, size;
+            if (!tk.number(cells) || !tk.number(size)) return fail(std::string(path) + ": bad TRIANGLE_STRIPS header");
+            for (uint64_t c = 0; c < (uint64_t)cells; ++c) {
+                double k;
+                if (!tk.number(k) || k < 3) return fail(std::string(path) + ": a triangle strip needs at least 3 points");
+                std::vector<double> idx;
+                if (!read_values((size_t)k, &idx)) return fail(std::string(path) + ": short TRIANGLE_STRIPS block");
+                std::vector<uint64_t> s;
+                for (double d : idx) { if (d < 0 || (uint64_t)d >= n_points) return fail(std::string(path) + ": strip point index out of range"); s.push_back((uint64_t)d); }
+                strips.push_back(std::move(s));
+            }
+        } else if (t == "VERTICES" || t == "LINES" || t == "POLYGONS") {
+            // the reference rejects any cell that is not a vtkTriangleStrip (VTKReaderImpl.cpp:73-77)
+            double cells, size;
+            if (!tk.number(cells) || !tk.number(size)) return fail(std::string(path) + ": bad " + t + " block");
+            if (cells > 0) return fail(std::string(path) + ": found illegal cell type (" + t + "): Mesh mode takes triangle strips only");
+        } else if (t == "CELL_DATA") {
+            double cnt; if (!tk.number(cnt)) return fail(std::string(path) + ": bad CELL_DATA");
+            n_cells = (uint64_t)cnt; in_cell_data = true;
+        } else if (t == "POINT_DATA") {
+            double cnt; if (!tk.number(cnt)) return fail(std::string(path) + ": bad POINT_DATA"); in_cell_data = false; n_cells = (uint64_t)cnt;
+        } else if (t == "SCALARS") {
+            std::string name, type, maybe;
+            if (!tk.next(name) || !tk.next(type)) return fail(std::string(path) + ": bad SCALARS header");
+            size_t comps = 1;
+            const size_t save = tk.p;
+            if (!tk.next(maybe)) return fail(std::string(path) + ": truncated SCALARS");
+            if (maybe != "LOOKUP_TABLE") { comps = (size_t)std::strtoul(maybe.c_str(), nullptr, 10); if (comps == 0) { tk.p = save; comps = 1; } else if (!tk.next(maybe)) return fail(std::string(path) + ": truncated SCALARS"); }
+            if (maybe != "LOOKUP_TABLE" || !tk.next(maybe)) return fail(std::string(path) + ": LOOKUP_TABLE expected after SCALARS " + name);
+            if (!read_values(comps * n_cells, (in_cell_data && name == "id" && comps == 1) ? &id : nullptr)) return fail(std::string(path) + ": short SCALARS " + name);
+        } else if (t == "VECTORS" || t == "NORMALS") {
+            std::string name, type;
+            if (!tk.next(name) || !tk.next(type)) return fail(std::string(path) + ": bad " + t + " header");
+            if (!read_values(3 * n_cells, (in_cell_data && t == "VECTORS" && name == "vel") ? &vel : nullptr)) return fail(std::string(path) + ": short " + t + " " + name);
+        } else {
+            return fail(std::string(path) + ": unsupported keyword '" + t + "'");
+        }
+    }
+    if (n_points == 0) return fail(std::string(path) + ": failed to get poly data or there is no points in file");     // VTKReaderImpl.cpp:38-41
+    if (id.size() != strips.size() || vel.size() != 3 * strips.size()) return fail(std::string(path) + ": failed to read cell data (id and vel per cell)");   // :49-52
+    // triangles of the strips (:92-104) and the unit normal of each; point normals = normalised sum over the triangles using the point
+    std::vector<uint64_t> ids, first{0};
+    std::vector<float> velocities, verts, normals;
+    std::vector<double> pn(3 * n_points, 0.0);
+    struct Tri { uint64_t a, b, c; };
+    std::vector<std::vector<Tri>> tris(strips.size());
+    for (size_t s2 = 0; s2 < strips.size(); ++s2) {
+        const auto &st = strips[s2];
+        for (size_t k = 0; k + 2 < st.size(); ++k) {
+            Tri tr{st[k], st[k + 1], st[k + 2]};
+            if (k & 1) std::swap(tr.b, tr.c);
+            tris[s2].push_back(tr);
+            const double *A = &points[3 * tr.a], *B = &points[3 * tr.b], *C = &points[3 * tr.c];
+            const double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+            double nrm[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            const double len = std::sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+            if (len > 0.0) for (uint64_t v : {tr.a, tr.b, tr.c}) for (int d = 0; d < 3; ++d) pn[3 * v + d] += nrm[d] / len;
+        }
+    }
+    for (uint64_t v = 0; v < n_points; ++v) {
+        const double len = std::sqrt(pn[3 * v] * pn[3 * v] + pn[3 * v + 1] * pn[3 * v + 1] + pn[3 * v + 2] * pn[3 * v + 2]);
+        if (len > 0.0) for (int d = 0; d < 3; ++d) pn[3 * v + d] /= len;
+    }
+    for (size_t s2 = 0; s2 < strips.size(); ++s2) {
+        ids.push_back((uint64_t)id[s2]);
+        for (int d = 0; d < 3; ++d) velocities.push_back((float)vel[3 * s2 + d]);
+        for (const Tri &tr : tris[s2])
+            for (uint64_t v : {tr.a, tr.b, tr.c})
+                for (int d = 0; d < 3; ++d) { verts.push_back((float)points[3 * v + d]); normals.push_back((float)pn[3 * v + d]); }
+        first.push_back(first.back() + tris[s2].size());
+    }
+    out->n_particles = strips.size(); out->ids = dup_array(ids); out->velocities = dup_array(velocities); out->first_triangle = dup_array(first);
+    out->vertices = dup_array(verts); out->normals = dup_array(normals);
+    if (!out->ids || !out->velocities || !out->first_triangle || !out->vertices || !out->normals) { hrt_io_free_mesh_cache(out); return fail("out of memory"); }
+    if (out_cell_count) *out_cell_count = strips.size();
+    return 0;
+}
+
 void hrt_io_free_mesh_cache(HrtIoMeshCache *c) {
     if (!c) return;
     std::free(c->ids); std::free(c->velocities); std::free(c->first_triangle); std::free(c->vertices); std::free(c->normals);

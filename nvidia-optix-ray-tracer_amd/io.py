@@ -12,7 +12,8 @@ import numpy as np
 _LIB = None
 IO_EXPORTS = ["hrt_io_last_error", "hrt_io_read_stl", "hrt_io_free_mesh", "hrt_io_read_particle_vtk", "hrt_io_free_particles",
               "hrt_io_read_series", "hrt_io_free_series", "hrt_io_bake_color_ramp", "hrt_io_construct_transform",
-              "hrt_io_load_config", "hrt_io_free_config", "hrt_io_read_mesh_cache", "hrt_io_write_mesh_cache", "hrt_io_free_mesh_cache"]
+              "hrt_io_load_config", "hrt_io_free_config", "hrt_io_read_mesh_cache", "hrt_io_write_mesh_cache", "hrt_io_free_mesh_cache",
+              "hrt_io_read_metadata_cache", "hrt_io_write_metadata_cache", "hrt_io_read_vtk_mesh_file"]
 
 
 class IoMesh(C.Structure):
@@ -69,6 +70,9 @@ def lib():
         L.hrt_io_read_series.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p]
         for name in ("hrt_io_read_stl", "hrt_io_read_particle_vtk", "hrt_io_load_config", "hrt_io_read_mesh_cache", "hrt_io_write_mesh_cache"):
             getattr(L, name).argtypes = [C.c_char_p, C.c_void_p]
+        L.hrt_io_read_metadata_cache.argtypes = [C.c_char_p, C.POINTER(C.c_uint64)]
+        L.hrt_io_write_metadata_cache.argtypes = [C.c_char_p, C.c_uint64]
+        L.hrt_io_read_vtk_mesh_file.argtypes = [C.c_char_p, C.c_void_p, C.POINTER(C.c_uint64)]
         _LIB = L
     return _LIB
 
@@ -162,6 +166,38 @@ def read_mesh_cache(path):
     lib().hrt_io_free_mesh_cache(C.byref(m))
     return [{"id": int(ids[i]), "velocity": vel[i], "vertices": v[int(first[i]):int(first[i + 1])], "normals": nm[int(first[i]):int(first[i + 1])]}
             for i in range(n)]
+
+
+def _mesh_cache_to_list(m):
+    n = m.n_particles
+    first = _arr(m.first_triangle, n + 1, np.uint64)
+    total = int(first[-1]) if n else 0
+    ids, vel = _arr(m.ids, n, np.uint64), _arr(m.velocities, 3 * n, np.float32).reshape(n, 3)
+    v, nm = _arr(m.vertices, 9 * total, np.float32).reshape(total, 3, 3), _arr(m.normals, 9 * total, np.float32).reshape(total, 3, 3)
+    return [{"id": int(ids[i]), "velocity": vel[i], "vertices": v[int(first[i]):int(first[i + 1])], "normals": nm[int(first[i]):int(first[i + 1])]}
+            for i in range(n)]
+
+
+def read_vtk_mesh_file(path):
+    """Mesh-mode VTK file (triangle strips + CELL_DATA id / vel; VTKReaderImpl.cpp:24-137) -> (particles as read_mesh_cache
+    returns them, cell count)."""
+    m = IoMeshCache()
+    cells = C.c_uint64(0)
+    _check(lib().hrt_io_read_vtk_mesh_file(os.fsencode(path), C.byref(m), C.byref(cells)))
+    out = _mesh_cache_to_list(m)
+    lib().hrt_io_free_mesh_cache(C.byref(m))
+    return out, int(cells.value)
+
+
+def read_metadata_cache(directory):
+    """metadata.cache of a cache directory (path with trailing separator, as in config.json's cache-path) -> max cell count."""
+    v = C.c_uint64(0)
+    _check(lib().hrt_io_read_metadata_cache(os.fsencode(str(directory)), C.byref(v)))
+    return int(v.value)
+
+
+def write_metadata_cache(directory, max_cell_count):
+    _check(lib().hrt_io_write_metadata_cache(os.fsencode(str(directory)), int(max_cell_count)))
 
 
 def write_mesh_cache(path, particles):

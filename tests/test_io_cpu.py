@@ -200,6 +200,111 @@ def test_mesh_cache_round_trip_and_layout(io, tmp_path):
         io.read_mesh_cache(tmp_path / "short.cache")
 
 
+def test_mesh_cache_reader_against_hand_assembled_bytes(io, tmp_path):
+    """A pin for the cache reader that is not its own writer: the bytes of a two-particle cache file put together field by
+    field from the layout the reference documents (include/Util/VTKMeshReader.cuh:15-23) and writes (VTKMeshReader.cu:54-72:
+    every size a fixed-width little-endian uint64, float3 = 12 bytes, vertices then normals)."""
+    import struct
+    v0 = [(0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0), (1.0, 0.0, 1.0), (0.0, 1.0, 1.0)]
+    n0 = [(0.0, 0.0, 1.0)] * 6
+    v1 = [(2.0, 2.0, 2.0), (3.0, 2.0, 2.0), (2.0, 3.0, 2.5)]
+    n1 = [(0.0, -0.4472136, 0.8944272)] * 3
+    blob = struct.pack("<Q", 2)
+    blob += struct.pack("<Q", 41) + struct.pack("<3f", 0.5, -1.5, 2.0) + struct.pack("<Q", 6)
+    blob += b"".join(struct.pack("<3f", *p) for p in v0) + b"".join(struct.pack("<3f", *p) for p in n0)
+    blob += struct.pack("<Q", 7) + struct.pack("<3f", 0.0, 0.0, -9.81) + struct.pack("<Q", 3)
+    blob += b"".join(struct.pack("<3f", *p) for p in v1) + b"".join(struct.pack("<3f", *p) for p in n1)
+    assert len(blob) == 8 + (8 + 12 + 8 + 2 * 72) + (8 + 12 + 8 + 2 * 36)
+    path = tmp_path / "particle17.cache"
+    path.write_bytes(blob)
+    parts = io.read_mesh_cache(path)
+    assert [p["id"] for p in parts] == [41, 7]
+    assert np.array_equal(parts[0]["velocity"], np.float32([0.5, -1.5, 2.0])) and np.array_equal(parts[1]["velocity"], np.float32([0.0, 0.0, -9.81]))
+    assert parts[0]["vertices"].shape == (2, 3, 3) and parts[1]["vertices"].shape == (1, 3, 3)      # triangleCount = vertexCount / 3, VTKMeshReader.cu:254
+    assert np.array_equal(parts[0]["vertices"].reshape(-1, 3), np.float32(v0)) and np.array_equal(parts[0]["normals"].reshape(-1, 3), np.float32(n0))
+    assert np.array_equal(parts[1]["vertices"].reshape(-1, 3), np.float32(v1)) and np.array_equal(parts[1]["normals"].reshape(-1, 3), np.float32(n1))
+    # and the writer reproduces these very bytes
+    io.write_mesh_cache(tmp_path / "again.cache", parts)
+    assert (tmp_path / "again.cache").read_bytes() == blob
+    # a vertex count that is not a multiple of 3 cannot be a triangle list
+    bad = bytearray(blob); bad[28:36] = struct.pack("<Q", 5)
+    (tmp_path / "bad.cache").write_bytes(bytes(bad))
+    with pytest.raises(io.IoError):
+        io.read_mesh_cache(tmp_path / "bad.cache")
+
+
+def test_metadata_cache(io, tmp_path):
+    """metadata.cache (VTKMeshReader.cuh:23): the largest cell count of the series as decimal text, `metaData << maxCellCount` /
+    `metaData >> maxCount` (VTKMeshReader.cu:203, :277); the directory argument ends with a separator like cache-path does."""
+    d = str(tmp_path) + "/"
+    (tmp_path / "metadata.cache").write_text("12345")                # what the reference's cache run leaves behind
+    assert io.read_metadata_cache(d) == 12345
+    (tmp_path / "metadata.cache").write_text("  77\n")                # operator>> skips white space
+    assert io.read_metadata_cache(d) == 77
+    io.write_metadata_cache(d, 2 ** 40 + 5)
+    assert (tmp_path / "metadata.cache").read_bytes() == str(2 ** 40 + 5).encode()       # no newline, no padding
+    assert io.read_metadata_cache(d) == 2 ** 40 + 5
+    (tmp_path / "metadata.cache").write_text("cells")
+    with pytest.raises(io.IoError, match="no cell count"):
+        io.read_metadata_cache(d)
+    with pytest.raises(io.IoError, match="cannot open"):
+        io.read_metadata_cache(str(tmp_path / "nowhere") + "/")
+
+
+MESH_VTK = """# vtk DataFile Version 2.0
+two particles as triangle strips
+ASCII
+DATASET POLYDATA
+POINTS 9 double
+0 0 0  1 0 0  0 1 0  1 1 0  0 2 0
+5 5 5  6 5 5  5 6 5  5 5 6
+TRIANGLE_STRIPS 2 11
+5 0 1 2 3 4
+4 5 6 7 8
+CELL_DATA 2
+SCALARS id int 1
+LOOKUP_TABLE default
+12 3
+VECTORS vel double
+0 0 -1  0.5 0.25 0
+"""
+
+
+def test_vtk_mesh_file_strips_to_triangles(io, tmp_path):
+    """readVTKMeshFile (VTKReaderImpl.cpp:24-137): a strip of k points gives k - 2 triangles, the odd ones with their last two
+    vertices swapped (:96-104) so that the winding stays the same; ids / velocities from CELL_DATA; every vertex carries its
+    point's normal (normalised sum of the unit normals of the triangles around the point).  The result written as a cache
+    file is what the reference's cache run would write, and reads back the same."""
+    p = tmp_path / "mesh_000.vtk"
+    p.write_text(MESH_VTK)
+    parts, cells = io.read_vtk_mesh_file(p)
+    assert cells == 2 and [q["id"] for q in parts] == [12, 3]
+    assert np.array_equal(parts[0]["velocity"], np.float32([0, 0, -1])) and np.array_equal(parts[1]["velocity"], np.float32([0.5, 0.25, 0]))
+    a = parts[0]["vertices"]
+    assert a.shape == (3, 3, 3)
+    assert np.array_equal(a[0], np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0]]))
+    assert np.array_equal(a[1], np.float32([[1, 0, 0], [1, 1, 0], [0, 1, 0]]))          # odd triangle: (v1, v3, v2)
+    assert np.array_equal(a[2], np.float32([[0, 1, 0], [1, 1, 0], [0, 2, 0]]))
+    for t in a:                                                                          # one winding throughout: all face +z
+        assert np.cross(t[1] - t[0], t[2] - t[0])[2] > 0
+    assert np.array_equal(parts[0]["normals"], np.broadcast_to(np.float32([0, 0, 1]), (3, 3, 3)))   # a flat strip
+    b, bn = parts[1]["vertices"], parts[1]["normals"]
+    assert b.shape == (2, 3, 3) and np.array_equal(b[1], np.float32([[6, 5, 5], [5, 5, 6], [5, 6, 5]]))
+    n_face0 = np.float64([0, 0, 1]); n_face1 = np.cross([-1, 0, 1], [-1, 1, 0]); n_face1 = n_face1 / np.linalg.norm(n_face1)
+    shared = (n_face0 + n_face1) / np.linalg.norm(n_face0 + n_face1)
+    assert np.allclose(bn[0][0], n_face0) and np.allclose(bn[0][1], shared, atol=1e-7) and np.allclose(bn[1][1], n_face1, atol=1e-7)
+    io.write_mesh_cache(tmp_path / "particle0.cache", parts)
+    back = io.read_mesh_cache(tmp_path / "particle0.cache")
+    assert all(np.array_equal(x["vertices"], y["vertices"]) and np.array_equal(x["normals"], y["normals"]) for x, y in zip(parts, back))
+    # the reference refuses any other cell type (:73-77) and files without the cell data (:49-52)
+    (tmp_path / "poly.vtk").write_text(MESH_VTK.replace("TRIANGLE_STRIPS 2 11", "POLYGONS 2 11"))
+    with pytest.raises(io.IoError, match="illegal cell type"):
+        io.read_vtk_mesh_file(tmp_path / "poly.vtk")
+    (tmp_path / "nodata.vtk").write_text(MESH_VTK.split("CELL_DATA")[0])
+    with pytest.raises(io.IoError, match="cell data"):
+        io.read_vtk_mesh_file(tmp_path / "nodata.vtk")
+
+
 def test_time_mode_scene_assembly(io):
     """RendererTime::commitRendererData in small: extra sphere first, then the particles of file 0 sharing shapes."""
     tm = io.time_mode_scene(FILES / "config.json")
