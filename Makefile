@@ -21,6 +21,10 @@ $(LIBDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/device_types.h $(CSRC)/srgb_pow
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+$(LIBDIR)/fused.o: $(CSRC)/fused.hip $(CSRC)/device_types.h $(CSRC)/trav_common.h $(CSRC)/trav_lean.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 $(LIBDIR)/paths.o: $(CSRC)/paths.hip $(CSRC)/device_types.h $(CSRC)/trav_common.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -51,7 +55,7 @@ $(LIBDIR)/bvh8_build.o: $(CSRC)/bvh8_build.cpp $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
-$(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/paths.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o
+$(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/paths.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -pthread
 
 # host-side readers of the reference's input formats (include/hrt_io.h): plain C++, no GPU
@@ -78,16 +82,17 @@ clean:
 
 # instrumented build for tools/lane_stats.py: lane-utilisation counters compiled into the path kernels
 stats: $(LIBDIR)/libhrt_stats.so
-$(LIBDIR)/libhrt_stats.so: $(CSRC)/kernels.hip $(CSRC)/paths.hip $(CSRC)/trav_common.h $(LIBDIR)/libhrt.so
+$(LIBDIR)/libhrt_stats.so: $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/paths.hip $(CSRC)/trav_common.h $(CSRC)/trav_lean.h $(LIBDIR)/libhrt.so
 	$(HIPCC) $(HIPFLAGS) -DHRT_LANE_STATS -c $(CSRC)/kernels.hip -o $(LIBDIR)/kernels_stats.o
+	$(HIPCC) $(HIPFLAGS) -DHRT_LANE_STATS -c $(CSRC)/fused.hip -o $(LIBDIR)/fused_stats.o
 	$(HIPCC) $(HIPFLAGS) -DHRT_LANE_STATS -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_stats.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LIBDIR)/kernels_stats.o $(LIBDIR)/paths_stats.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LIBDIR)/kernels_stats.o $(LIBDIR)/fused_stats.o $(LIBDIR)/paths_stats.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
 
 # bound-finding experiments on k_paths (tools only, never shipped): twice the slab arithmetic / twice the node loads
 exp: $(LIBDIR)/libhrt.so
 	$(HIPCC) $(HIPFLAGS) -DHRT_EXP_VALU2 -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_valu2.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_valu2.so $(LIBDIR)/kernels.o $(LIBDIR)/paths_valu2.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_valu2.so $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/paths_valu2.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
 	$(HIPCC) $(HIPFLAGS) -DHRT_EXP_LOAD2 -DHRT_EXP_LOAD2_SAME -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_load2s.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_load2s.so $(LIBDIR)/kernels.o $(LIBDIR)/paths_load2s.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_load2s.so $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/paths_load2s.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
 	$(HIPCC) $(HIPFLAGS) -DHRT_EXP_LOAD2 -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_load2.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_load2.so $(LIBDIR)/kernels.o $(LIBDIR)/paths_load2.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_load2.so $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/paths_load2.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread

@@ -104,6 +104,7 @@ struct TraverseArgs {
     uint32_t fetch_chunk;          // rays per slice a wave takes from the queue
     int tail_split;                // split long rays across idle lanes once the queue is drained
     int postpone_pct;              // the leaf pass is skipped while fewer than this % of the alive lanes have leaf work and none needs it
+    int leaf_quorum;               // k_fused: ... and fewer than this many lanes have nothing but leaf work (they wait; >= 1)
     PathArgs path;                 // FUSED only
 };
 
@@ -193,7 +194,10 @@ void launch_generate(const GenerateArgs &a, hipStream_t s);
 void launch_traverse(const TraverseArgs &a, bool count, bool has_spheres, bool dma, uint32_t grid_blocks, hipStream_t s);
 void launch_paths(const TraverseArgs &a, bool has_spheres, int slots, uint32_t grid_blocks, hipStream_t s);
 uint32_t paths_blocks_that_fit(int slots);
-void launch_paths_v1(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s);   // the fused kernel k_traverse<.., FUSED> (default)
+void launch_paths_v1(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s);   // round 1's fused kernel k_traverse<.., FUSED> (HRT_FUSED=2)
+constexpr int kFusedBlocksPerCu = 16;  // k_fused is compiled for 4 waves per SIMD (125 VGPRs, nothing spilled): more workgroups per CU would only queue
+constexpr int kFusedMaxDepth = 12;     // deepest tree (levels below the root) k_fused takes: its per-lane node stack in LDS (trav_lean.h: kNodeStackLds)
+void launch_fused(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s);      // k_fused (fused.hip): the default
 void launch_sum(float4 *accum, const float4 *result, uint32_t n, uint32_t first_sample, hipStream_t s);
 void launch_bin(const BinArgs &a, uint32_t grid_blocks, hipStream_t s);
 void launch_shade(const ShadeArgs &a, int program, uint32_t grid_blocks, hipStream_t s);

@@ -146,6 +146,8 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_TAIL_SPLIT")) ctx->tail_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_SUBSTREAM_MIN_PIXELS")) { const int v = std::atoi(e); if (v >= 1024) ctx->substream_min_pixels = v; }
     if (const char *e = std::getenv("HRT_SUBSTREAMS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) ctx->substreams = v; }
+    if (const char *e = std::getenv("HRT_FUSED_MAX_DEPTH")) { const int v = std::atoi(e); if (v >= 0 && v <= kFusedMaxDepth) ctx->fused_max_depth = v; }
+    if (const char *e = std::getenv("HRT_LEAF_QUORUM")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->leaf_quorum = v; }
     if (const char *e = std::getenv("HRT_POSTPONE_PCT")) { const int v = std::atoi(e); if (v >= 0 && v <= 100) ctx->postpone_pct = v; }
     if (const char *e = std::getenv("HRT_REFILL_THRESHOLD")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) { ctx->refill_threshold = v; ctx->fused_refill_threshold = v; } }
     *out_ctx = ctx.release();
@@ -235,6 +237,12 @@ int hrt_rng_free(HrtContext *ctx, HrtRngState *d_states, void *stream) {
 }
 
 // ---- the launch -----------------------------------------------------------------------
+// k_fused (fused.hip) keeps one sibling group per tree level in LDS without an overflow path and addresses the records with
+// 32-bit byte offsets; a tree outside either limit takes round 1's fused kernel (kernels.hip), which has neither.
+static bool fits_fused_kernel(const HrtContext *ctx, const Tlas &t) {
+    return t.max_depth <= (uint32_t)ctx->fused_max_depth && (uint64_t)t.n_nodes * t.node_stride < (1ull << 32) &&
+           (uint64_t)std::max(t.n_prims, 1u) * t.prim_stride < (1ull << 32);
+}
 static int refresh_tables(HrtContext *ctx, uint64_t handle, Tlas *t, hipStream_t s) {
     if (ctx->table_tlas == handle && ctx->table_tlas_gen == t->generation && ctx->table_mat_gen == ctx->materials_generation) return HRT_OK;
     const uint32_t n = std::max(t->n_instances, 1u);
@@ -319,7 +327,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         ta.fetch_counter = stg[0].fetch;
         ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
         ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;
-        ta.refill_threshold = ctx->fused_refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.tail_split = 0; ta.fetch_chunk = (uint32_t)ctx->fused_fetch_chunk;
+        ta.refill_threshold = ctx->fused_refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.leaf_quorum = ctx->leaf_quorum; ta.tail_split = 0; ta.fetch_chunk = (uint32_t)ctx->fused_fetch_chunk;
         PathArgs &pa = ta.path;
         pa.rows = w.rows; pa.first_pixel = 0; pa.n_tile_pixels = n; pa.width = rg->width; pa.height = rg->height; pa.spp = spp;
         std::memcpy(pa.center, &rg->cameraCenter, 12); std::memcpy(pa.U, &rg->cameraU, 12);
@@ -331,11 +339,14 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         // Waves per CU: a lane runs its pixel's samples one after the other, so a small tile (the multi-GPU split) ends
         // with its slowest pixels; about 1.4 pixels per lane lets the lanes that drew cheap pixels take a second one
         // while fewer waves share each SIMD (measured, profiles/r01_sweep_tile_waves.txt: 1/8 of the C4 frame takes
-        // 172 ms on 12 waves per CU, 210 ms on 16).  A full frame has many pixels per lane and keeps the maximum:
-        // 20 waves per CU = 5 per SIMD, for which k_traverse is compiled (__launch_bounds__(64, 5): 96 VGPRs, a few
-        // spills; 2905 Mrays/s on C4 against 2835 with 4 waves of 101 VGPRs, 6 waves of 80 VGPRs spill too much: 2801).
-        const bool v1 = ctx->fused != 3;            // 3: the slot pipeline k_paths (paths.hip); otherwise the fused kernel of kernels.hip
-        uint32_t blocks_per_cu = v1 ? (uint32_t)ctx->fused_blocks_per_cu : std::min<uint32_t>((uint32_t)ctx->paths_blocks_per_cu, paths_blocks_that_fit(ctx->paths_slots));
+        // 172 ms on 12 waves per CU, 210 ms on 16).  A full frame has many pixels per lane and keeps the maximum: 16 waves
+        // per CU = 4 per SIMD for k_fused (122 VGPRs, nothing spilled: 3120 Mrays/s on C4; compiled for 5 waves it spills 95
+        // registers around the shading: 2560), 20 = 5 per SIMD for round 1's kernel (96 VGPRs, a few spills: 2905).
+        const bool v1 = ctx->fused != 3;            // 3: the slot pipeline k_paths (paths.hip); otherwise a fused kernel: k_fused (fused.hip), 2: round 1's (kernels.hip)
+        // k_fused keeps one sibling group per tree level in LDS and has no overflow path: deeper trees take round 1's kernel
+        const bool lean = v1 && ctx->fused != 2 && fits_fused_kernel(ctx, *t);
+        uint32_t blocks_per_cu = lean ? std::min<uint32_t>((uint32_t)ctx->fused_blocks_per_cu, (uint32_t)kFusedBlocksPerCu)
+                               : v1 ? (uint32_t)ctx->fused_blocks_per_cu : std::min<uint32_t>((uint32_t)ctx->paths_blocks_per_cu, paths_blocks_that_fit(ctx->paths_slots));
         if (!v1) { ta.refill_threshold = ctx->paths_exchange_threshold; pa.shade_threshold = ctx->paths_shade_threshold; pa.low_water = ctx->paths_low_water; pa.min_batch = ctx->paths_min_batch; }
         if (ctx->traverse_blocks_auto && v1) {
             const uint32_t fit = (uint32_t)((10ull * n + 14ull * 64ull * (uint64_t)ctx->n_cu - 1ull) / (14ull * 64ull * (uint64_t)ctx->n_cu));
@@ -352,7 +363,11 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
             }
             pa.slots = w.slots;
         }
-        auto launch = [&]() { if (v1) launch_paths_v1(ta, t->has_spheres, grid, s); else launch_paths(ta, t->has_spheres, ctx->paths_slots, grid, s); };
+        auto launch = [&]() {
+            if (lean) launch_fused(ta, t->has_spheres, grid, s);
+            else if (v1) launch_paths_v1(ta, t->has_spheres, grid, s);
+            else launch_paths(ta, t->has_spheres, ctx->paths_slots, grid, s);
+        };
         // Longest-processing-time-first: a pixel's samples run one after the other in one lane, so a render ends with
         // whatever pixels were started last.  For renders of many samples the first sample is a probe launch of its own
         // that records how long each slice's pixels took over their sample; the slices are then handed out slowest first,
@@ -470,7 +485,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         ta.fetch_counter = stages_of(sa, sb)[da].fetch;
         ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
         ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;      // Shader.cu:232, :266
-        ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fetch_chunk;
+        ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.leaf_quorum = ctx->leaf_quorum; ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fetch_chunk;
         Timer tm(ctx, sb.st, (da >= kRayTraceDepth && !second) ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
         launch_traverse(ta, count, t->has_spheres, ctx->lds_gather != 0, sb.grid_trav, sb.st);
     };
@@ -624,7 +639,7 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
     TraverseArgs ta{};
     ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.node_stride = t->node_stride; ta.prim_stride = t->prim_stride;
     ta.fetch_counter = fetch; ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
-    ta.tmin = tmin; ta.tmax = tmax; ta.postpone_pct = ctx->postpone_pct;
+    ta.tmin = tmin; ta.tmax = tmax; ta.postpone_pct = ctx->postpone_pct; ta.leaf_quorum = ctx->leaf_quorum;
     const bool count = (ctx->flags & HRT_CTX_COUNT) != 0;
     if (!count && ctx->fused > 0) {
         // the production configuration: the rays go through the very kernel hrt_render_launch runs (fused path kernel, v_rcp_f32
@@ -634,9 +649,11 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
         pa.n_tile_pixels = n_rays; pa.first_pixel = 0; pa.width = n_rays; pa.height = 1; pa.spp = 1;
         pa.trace_rays = rays; pa.trace_tuvp = tuvp; pa.trace_inst = inst; pa.trace_any = any_hit ? 1u : 0u;
         pa.rays_closest = &ctx->d_stats->rays_closest; pa.rays_any = &ctx->d_stats->rays_any;
-        const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->fused_blocks_per_cu, (n_rays + 63u) / 64u);
+        const bool lean = ctx->fused != 2 && fits_fused_kernel(ctx, *t);
+        const uint32_t blocks_per_cu = lean ? std::min<uint32_t>((uint32_t)ctx->fused_blocks_per_cu, (uint32_t)kFusedBlocksPerCu) : (uint32_t)ctx->fused_blocks_per_cu;
+        const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * blocks_per_cu, (n_rays + 63u) / 64u);
         Timer tm(ctx, s, HRT_K_PATHS);
-        launch_paths_v1(ta, t->has_spheres, grid, s);
+        if (lean) launch_fused(ta, t->has_spheres, grid, s); else launch_paths_v1(ta, t->has_spheres, grid, s);
     } else {
         ta.seg[0].rays = rays; ta.seg[0].n_ptr = nullptr; ta.seg[0].n = n_rays; ta.seg[0].any_hit = any_hit ? 1u : 0u;
         ta.seg[0].hit_tuvp = tuvp; ta.seg[0].hit_inst = inst;

@@ -137,12 +137,14 @@ struct HrtContext {
     int refill_threshold = 16;                  // wavefront mode; fused mode: fused_refill_threshold
     int fused_refill_threshold = 24, fused_fetch_chunk = 16;   // measured optimum of the fused path mode (profiles/r01_sweep_fused_*.txt)
     int traverse_blocks_per_cu = 16;            // one-wave workgroups of the wavefront traverse kernel per CU
-    int fused_blocks_per_cu = 20;               // ... of the fused path kernel: 5 waves per SIMD (the kernel is compiled for 96 VGPRs)
+    int fused_blocks_per_cu = 20;               // ... of the fused path kernels: round 1's takes 5 waves per SIMD (96 VGPRs), k_fused is capped at kFusedBlocksPerCu
     bool traverse_blocks_auto = true;           // fused mode: fewer of them for small tiles (not when the env knob is set)
     int postpone_pct = 25;
+    int fused_max_depth = kFusedMaxDepth;       // deeper trees take round 1's fused kernel (HRT_FUSED_MAX_DEPTH lowers it: tests)
+    int leaf_quorum = 1;                        // k_fused: lanes with nothing but leaf work wait until this many of them have gathered (HRT_LEAF_QUORUM)
     int tail_split = 1;
     int node_stride = 80, prim_stride = 64;     // bytes between records in HBM (80/48 packed; 128/64 = one cache line each)
-    int fused = 1;                              // 1: fused persistent path kernel (default), 3: slot-pipeline path kernel k_paths, 0: wavefront kernels, -1: fused only for small tiles
+    int fused = 1;                              // 1: fused persistent path kernel k_fused (default), 2: round 1's fused kernel, 3: slot-pipeline path kernel k_paths, 0: wavefront kernels, -1: fused only for small tiles
     int paths_slots = 112;                      // k_paths: pixels in flight per wave (80 / 96 / 112 / 128): 64 in lanes, the rest queued in LDS
     int paths_blocks_per_cu = 20;               // k_paths: one-wave workgroups per CU, at most what the LDS holds (20 / 18 / 16 / 15 for the slot counts above)
     int paths_exchange_threshold = 8;           // k_paths: lanes that have finished before the wave stops to exchange rays with its queues

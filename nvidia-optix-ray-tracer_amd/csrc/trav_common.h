@@ -141,6 +141,45 @@ __device__ __forceinline__ void scatter(const HitGroup &hg, V3 rayOrigin, V3 ray
     hitPoint = hit_point(rayOrigin, rayDirection, t);                     // :114
     scatter_at<kSphere, kRough>(hg, hitPoint, rayDirection, u, v, primitiveIndex, rng, reflectDirection);
 }
+// All four programs in ONE body, for kernels whose lanes run different programs side by side (fused.hip): the programs differ
+// in where the normal comes from (sphere / triangle) and in what becomes of it (rough / metal); the random vector, its
+// normalisation, the checks of the result and the hit point are the same instructions for every lane, executed once instead of
+// once per program present in the wave.  Operation for operation what scatter<kSphere, kRough> computes.
+template <bool HAS_SPHERES>
+__device__ __forceinline__ void scatter_programs(uint32_t program, const HitGroup &hg, V3 rayOrigin, V3 rayDirection, float t, float u, float v,
+                                                 uint32_t primitiveIndex, Xorwow &rng, V3 &hitPoint, V3 &reflectDirection) {
+    hitPoint = hit_point(rayOrigin, rayDirection, t);                     // :114
+    const bool rough = (program & 1u) == 0u;                              // kProgramSphereRough = 0, kProgramTriangleRough = 2
+    V3 _normal;
+    if (HAS_SPHERES && program < (uint32_t)kProgramTriangleRough) {       // :122-136
+        const float *cp = reinterpret_cast<const float *>(hg.ptr0) + 3 * (size_t)primitiveIndex;
+        const V3 sphereCenter = mk3(cp[0], cp[1], cp[2]);
+        const float sphereRadius = reinterpret_cast<const float *>(hg.ptr1)[primitiveIndex];
+        _normal = divs3(sub3(hitPoint, sphereCenter), sphereRadius);
+    } else {                                                              // :137-155
+        const float *np = reinterpret_cast<const float *>(hg.ptr0) + 9 * (size_t)primitiveIndex;
+        const V3 n1 = mk3(np[0], np[1], np[2]), n2 = mk3(np[3], np[4], np[5]), n3 = mk3(np[6], np[7], np[8]);
+        const float w = 1.0f - u - v;
+        _normal = add3(add3(muls3(n1, w), muls3(n2, u)), muls3(n3, v));
+    }
+    const bool hitFrontFace = dot3(rayDirection, _normal) < 0.0f;
+    const V3 normalVector = hitFrontFace ? _normal : neg3(_normal);
+    V3 rsv = mk3(0.0f, 0.0f, 0.0f);
+    if (rough || hg.fuzz > 0.0f) rsv = random_space_vector(rng);
+    if (rough) {                                                          // :169-179
+        reflectDirection = add3(normalVector, rsv);
+        if (fabsf(len2_3(reflectDirection) - kFloatZero * kFloatZero) < kFloatZero) reflectDirection = normalVector;
+    } else {                                                              // :180-192
+        const V3 vv = rayDirection, nn = normalVector;
+        reflectDirection = normalize3(sub3(vv, muls3(nn, 2.0f * dot3(vv, nn))));
+        if (hg.fuzz > 0.0f) reflectDirection = add3(reflectDirection, muls3(rsv, hg.fuzz));
+    }
+    if (!finite3(reflectDirection) || len2_3(reflectDirection) <= kFloatZero * kFloatZero) {     // :202-213
+        reflectDirection = normalVector;
+        if (len2_3(reflectDirection) <= kFloatZero * kFloatZero || !finite3(reflectDirection))
+            reflectDirection = mk3(0.0f, 0.0f, 1.0f);
+    }
+}
 __device__ __forceinline__ bool program_draws(int program, const HitGroup &hg) {
     return program == kProgramSphereRough || program == kProgramTriangleRough || hg.fuzz > 0.0f;
 }
@@ -222,20 +261,31 @@ __device__ __forceinline__ bool test_prim(const float4 A, const float4 B, const 
             if (t1 > tmin && t1 < tmax_ray) t = t1; else return false;
         }
     } else {
+        // Straight-line: every quantity is computed for every lane and ONE condition decides.  The early returns of the
+        // textbook form save nothing on a wave (the instructions run as long as one lane is still in) and cost a mask save /
+        // branch / restore each; the SIMD issues ~1 instruction of ANY kind per 2.4 cycles, scalar ones included
+        // (profiles/r02_valu_issue_patterns_microbench.txt).  Same decisions, same values: a rejected lane's later
+        // quantities are never used, det == 0 gives inv = inf and u = NaN or +-inf, which fails the u test like the
+        // explicit one does.
         inst = __float_as_uint(B.w);
         const V3 e1 = mk3(B.x, B.y, B.z), e2 = mk3(C.x, C.y, C.z);
         const V3 pvec = cross3(d, e2);
         const float det = dot3(e1, pvec);
-        if (!(det != 0.0f)) return false;
         const float inv = 1.0f / det;
         const V3 tvec = sub3(o, mk3(A.x, A.y, A.z));
         u = dot3(tvec, pvec) * inv;
-        if (!(u >= 0.0f && u <= 1.0f)) return false;
         const V3 qvec = cross3(tvec, e1);
         v = dot3(d, qvec) * inv;
-        if (!(v >= 0.0f && u + v <= 1.0f)) return false;
         t = dot3(e2, qvec) * inv;
-        if (!(t > tmin && t < tmax_ray)) return false;
+        const bool ok = (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tmin) & (t < tmax_ray);
+        if (!HAS_SPHERES) {
+            // closest hit: min t, ties -> lowest (instance, primitive); predicated update
+            const bool better = ok & ((t < s.bt) | ((t == s.bt) & ((inst < s.binst) | ((inst == s.binst) & (prim < s.bprim)))));
+            s.bt = better ? t : s.bt; s.bu = better ? u : s.bu; s.bv = better ? v : s.bv;
+            s.bprim = better ? prim : s.bprim; s.binst = better ? inst : s.binst;
+            return better;
+        }
+        if (!ok) return false;
     }
     // closest hit: min t, ties -> lowest (instance, primitive)
     bool better = t < s.bt;

@@ -931,6 +931,10 @@ MODES = {
     "slot-pipeline-128-slots-lazy-exchange-few-waves": {"HRT_FUSED": "3", "HRT_PATHS_SLOTS": "128", "HRT_PATHS_EXCHANGE": "32", "HRT_PATHS_SHADE": "48", "HRT_PATHS_BLOCKS_PER_CU": "2", "HRT_PATHS_MIN_BATCH": "64"},
     "slot-pipeline-two-samples-per-launch": {"HRT_FUSED": "3", "HRT_FUSED_MAX_SPP": "2", "HRT_PATHS_SLOTS": "96"},
     "fused-two-samples-per-launch": {"HRT_FUSED_MAX_SPP": "2"},
+    "fused-round-1-kernel": {"HRT_FUSED": "2"},
+    "fused-deep-trees-take-round-1-kernel": {"HRT_FUSED_MAX_DEPTH": "1"},
+    "fused-leaf-quorum-lazy-leaf-passes": {"HRT_LEAF_QUORUM": "12", "HRT_POSTPONE_PCT": "70"},
+    "fused-eager-leaf-passes-one-wave-per-simd": {"HRT_POSTPONE_PCT": "0", "HRT_TRAVERSE_BLOCKS_PER_CU": "4", "HRT_REFILL_THRESHOLD": "48"},
     "fused-cost-ordered-slices-off": {"HRT_FUSED_LPT": "0"},
     "fused-small-slices": {"HRT_FETCH_CHUNK": "16", "HRT_REFILL_THRESHOLD": "4", "HRT_TRAVERSE_BLOCKS_PER_CU": "3"},
     "aligned-records": {"HRT_NODE_STRIDE": "128", "HRT_PRIM_STRIDE": "64"},
