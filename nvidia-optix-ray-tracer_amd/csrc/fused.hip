@@ -11,6 +11,7 @@
 // instruction of any kind per ~2.4 cycles and this kernel is bound by that: DESIGN.md section 4).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "device_types.h"
 #include "trav_common.h"
 #include "trav_lean.h"
@@ -27,6 +28,10 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
     static_assert(kTraverseBlock == 64, "one wave per workgroup: the stacks are per wave");
     __shared__ uint2 s_nodes[kNodeStackLds][kTraverseBlock];     // sibling groups: one per tree level (hrt_api.cpp sends deeper trees to k_traverse)
     __shared__ uint2 s_leaves[kLeafStackLds][kTraverseBlock];    // leaf groups
+    // tail splitting: one mailbox per lane that owns a split ray (indexed by its home lane) collects the pieces' hits
+    __shared__ float s_mb_t[kTraverseBlock], s_mb_u[kTraverseBlock], s_mb_v[kTraverseBlock];
+    __shared__ uint32_t s_mb_prim[kTraverseBlock], s_mb_inst[kTraverseBlock], s_mb_pending[kTraverseBlock];
+    __shared__ uint32_t s_pair[kTraverseBlock];
 
     const uint32_t n_pixels = a.path.n_tile_pixels;
     const char *__restrict__ node_bytes = reinterpret_cast<const char *>(a.nodes);
@@ -43,6 +48,8 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
     bool waiting = false;                   // ... has finished and waits for the next regeneration
     bool any = false;                       // this lane's ray only needs to know whether anything is hit
     bool exhausted = false;                 // wave-uniform: no pixels left to start
+    bool shared = false;                    // this lane works on a piece of a ray that has been split across lanes (tail splitting)
+    uint32_t home = tx;                     // ... whose owner is this lane
 
     // the lane's pixel
     bool have_pixel = false, px_first = true;
@@ -65,7 +72,11 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
         const uint64_t idle = __ballot(!alive);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         // ---- regenerate: shade finished rays in place, start the next sample / pixel ----
-        if (n_idle >= (uint32_t)a.refill_threshold || idle == ~0ull) {
+        // (once the tile is used up the lanes without a pixel stay idle and the render ends with the slowest pixels' sample chains:
+        // what counts then is how soon a finished ray's successor starts, against what a regeneration costs the rays still under
+        // way -- a dozen waiting rays, or nothing else left to do: 1/8 of the C4 frame 142 ms with 1, 129 ms with 8 to 16)
+        const bool tail_mode = exhausted && a.tail_split;      // wave-uniform: lanes without a pixel help the others
+        if (idle == ~0ull || (exhausted ? (uint32_t)__popcll(__ballot(waiting)) >= (uint32_t)a.tail_regen : n_idle >= (uint32_t)a.refill_threshold)) {
 #ifdef HRT_LANE_STATS
             ++ls_regen;
 #endif
@@ -170,52 +181,143 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
         if (__ballot(alive) == 0ull) break;     // the tile is used up and every lane has finished (nothing waits after a full regeneration)
 
         // ---- traverse until enough lanes have finished to make a regeneration worthwhile ----
-        // the registers the loads land in: "defined" without an instruction (lanes that load nothing never look at theirs)
-        f32x4 rpa, rpb, rpc;
-        u32x4 rn0, rn1, rn2, rn3, rn4;
-        asm volatile("" : "=v"(rpa), "=v"(rpb), "=v"(rpc), "=v"(rn0), "=v"(rn1), "=v"(rn2), "=v"(rn3), "=v"(rn4));
-        for (;;) {
-            // ---- G. fetch what the lanes need next: primitives first, nodes second -- for the lanes that need one only (the
-            //      instruction slots of the loads are not saved, but their L1 / TA cycles are).  The node loads are issued even when
-            //      no lane wants one: they are then ALWAYS the five youngest vector-memory operations at the primitives' wait,
-            //      whose vmcnt(5) is counted by hand. ----
-            const uint64_t mask_p = __ballot(L.pidx != kNoWork), mask_n0 = __ballot(L.nidx != kNoWork);
-            {
-                uint32_t po = L.pidx * a.prim_stride, no = L.nidx * a.node_stride;      // (garbage for kNoWork: masked out)
-                asm volatile("" : "+v"(po), "+v"(no));          // both offsets before the first load
-                if (mask_p != 0ull) issue_prim_loads_off(mask_p, prim_bytes, po, rpa, rpb, rpc);
-                issue_node_loads_off(mask_n0, node_bytes, no, rn0, rn1, rn2, rn3, rn4);
-            }
-#ifdef HRT_LANE_STATS
-            { ++ls_iter; ls_alive += __popcll(__ballot(alive)); ls_node += __popcll(mask_n0); ls_prim += __popcll(mask_p); ls_ppass += mask_p != 0ull; }
-#endif
-            // ---- C. leaf test: waits for the primitive pieces only (the node loads issued behind them stay in flight) ----
-            bool hit_any = false;
-            if (mask_p != 0ull) {
-                wait_prim_loads(rpa, rpb, rpc);
-                if (L.pidx != kNoWork) {
-                    const float4 pa = make_float4(rpa.x, rpa.y, rpa.z, rpa.w), pb = make_float4(rpb.x, rpb.y, rpb.z, rpb.w),
-                                 pc = make_float4(rpc.x, rpc.y, rpc.z, rpc.w);
-                    const bool better = test_prim<HAS_SPHERES>(pa, pb, pc, L.s, tmin, tmax_ray, a.inst_inv, a.inst_identity);
-                    hit_any = any && better;
+        // Two copies of the loop: the second one, with tail splitting, runs once the tile is used up -- the first pays nothing for it.
+        auto traverse = [&](auto tail_tag) {
+            constexpr bool kTail = decltype(tail_tag)::value;
+            // the registers the loads land in: "defined" without an instruction (lanes that load nothing never look at theirs)
+            f32x4 rpa, rpb, rpc;
+            u32x4 rn0, rn1, rn2, rn3, rn4;
+            asm volatile("" : "=v"(rpa), "=v"(rpb), "=v"(rpc), "=v"(rn0), "=v"(rn1), "=v"(rn2), "=v"(rn3), "=v"(rn4));
+            for (;;) {
+                // ---- tail: the tile is used up, lanes have no pixel any more and a few pixels' sample chains remain, one ray after
+                //      the other.  A busy lane gives the BOTTOM entry of its node stack (the largest pending subtree) to a free lane of
+                //      the wave, which continues with a copy of the ray.  The pieces of a split ray share ONE best hit, the mailbox of
+                //      the lane that owns the ray: a piece publishes every improvement there (canonical order: the result does not
+                //      depend on who found what, or when) and adopts what the others found closer, so every piece culls with the
+                //      ray's best hit so far. ----
+                if (kTail) {
+                    const bool is_free = !alive && !waiting && !have_pixel && !shared;
+                    const uint64_t free_m = __ballot(is_free);
+                    const uint64_t donors = __ballot(alive && L.nsp > L.base);
+                    const uint32_t n_free = (uint32_t)__popcll(free_m), n_don = (uint32_t)__popcll(donors);
+                    const uint32_t n_pairs = n_free < n_don ? n_free : n_don;
+                    if (n_pairs) {
+                        const uint32_t drank = lane_prefix(donors), irank = lane_prefix(free_m);
+                        const bool is_donor = alive && L.nsp > L.base && drank < n_pairs;
+                        const bool is_recv = is_free && irank < n_pairs;
+                        uint2 give = make_uint2(0u, 0u);
+                        if (is_donor) {
+                            give = s_nodes[L.base][tx];
+                            ++L.base;
+                            if (!shared) {
+                                shared = true; home = tx;
+                                s_mb_t[tx] = L.s.bt; s_mb_u[tx] = L.s.bu; s_mb_v[tx] = L.s.bv; s_mb_prim[tx] = L.s.bprim; s_mb_inst[tx] = L.s.binst;
+                                s_mb_pending[tx] = 2u;
+                            } else atomicAdd(&s_mb_pending[home], 1u);
+                            s_pair[drank] = tx;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const int src = is_recv ? (int)s_pair[irank] : (int)tx;
+                        // every lane shuffles; only receivers keep what they read
+                        TravState &s = L.s;
+                        const float r_ox = __shfl(s.ox, src), r_oy = __shfl(s.oy, src), r_oz = __shfl(s.oz, src);
+                        const float r_dx = __shfl(s.dx, src), r_dy = __shfl(s.dy, src), r_dz = __shfl(s.dz, src);
+                        const uint32_t r_home = (uint32_t)__shfl((int)(home | (any ? 0x100u : 0u)), src);
+                        const uint32_t r_gx = (uint32_t)__shfl((int)give.x, src), r_gy = (uint32_t)__shfl((int)give.y, src);
+                        if (is_recv) {
+                            lean_start(L, mk3(r_ox, r_oy, r_oz), mk3(r_dx, r_dy, r_dz), tmax_ray);     // the same reciprocals and octant as the owner's
+                            home = r_home & 0xffu; any = (r_home & 0x100u) != 0u; shared = true; alive = true;
+                            s.bt = s_mb_t[home]; s.bu = s_mb_u[home]; s.bv = s_mb_v[home]; s.bprim = s_mb_prim[home]; s.binst = s_mb_inst[home];
+                            s.cur = make_uint2(r_gx, r_gy);           // a sibling group with hits: only those are pushed
+                            lean_pick_node(L);                        // (replaces the root lean_start chose)
+                        }
+                    }
                 }
+
+                // ---- G. fetch what the lanes need next: primitives first, nodes second -- for the lanes that need one only (the
+                //      instruction slots of the loads are not saved, but their L1 / TA cycles are).  The node loads are issued even when
+                //      no lane wants one: they are then ALWAYS the five youngest vector-memory operations at the primitives' wait,
+                //      whose vmcnt(5) is counted by hand. ----
+                const uint64_t mask_p = __ballot(L.pidx != kNoWork), mask_n0 = __ballot(L.nidx != kNoWork);
+                {
+                    uint32_t po = L.pidx * a.prim_stride, no = L.nidx * a.node_stride;      // (garbage for kNoWork: masked out)
+                    asm volatile("" : "+v"(po), "+v"(no));          // both offsets before the first load
+                    if (mask_p != 0ull) issue_prim_loads_off(mask_p, prim_bytes, po, rpa, rpb, rpc);
+                    issue_node_loads_off(mask_n0, node_bytes, no, rn0, rn1, rn2, rn3, rn4);
+                }
+    #ifdef HRT_LANE_STATS
+                { ++ls_iter; ls_alive += __popcll(__ballot(alive)); ls_node += __popcll(mask_n0); ls_prim += __popcll(mask_p); ls_ppass += mask_p != 0ull; }
+    #endif
+                // ---- C. leaf test: waits for the primitive pieces only (the node loads issued behind them stay in flight) ----
+                bool hit_any = false, improved = false;
+                if (mask_p != 0ull) {
+                    wait_prim_loads(rpa, rpb, rpc);
+                    if (L.pidx != kNoWork) {
+                        const float4 pa = make_float4(rpa.x, rpa.y, rpa.z, rpa.w), pb = make_float4(rpb.x, rpb.y, rpb.z, rpb.w),
+                                     pc = make_float4(rpc.x, rpc.y, rpc.z, rpc.w);
+                        improved = test_prim<HAS_SPHERES>(pa, pb, pc, L.s, tmin, tmax_ray, a.inst_inv, a.inst_identity);
+                        hit_any = any && improved;
+                    }
+                }
+                if (kTail) {
+                    // pieces of split rays publish their improvements one lane at a time (rare: a few per ray) ...
+                    uint64_t pub = __ballot(improved && shared);
+                    while (pub) {
+                        const uint32_t l = (uint32_t)__ffsll((long long)pub) - 1u;
+                        pub &= pub - 1ull;
+                        if (tx == l) {
+                            const TravState &s = L.s;
+                            const float mt = s_mb_t[home];
+                            const uint64_t mid = ((uint64_t)s_mb_inst[home] << 32) | s_mb_prim[home];
+                            const uint64_t id = ((uint64_t)s.binst << 32) | s.bprim;
+                            if (any ? s_mb_prim[home] == kMissPrim : (s.bt < mt || (s.bt == mt && id < mid))) {
+                                s_mb_t[home] = s.bt; s_mb_u[home] = s.bu; s_mb_v[home] = s.bv; s_mb_prim[home] = s.bprim; s_mb_inst[home] = s.binst;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    // ... and take over what another piece has found closer; an any-hit ray is done once any piece has hit
+                    if (alive && shared) {
+                        if (any) hit_any = hit_any || s_mb_prim[home] != kMissPrim;
+                        else if (s_mb_t[home] < L.s.bt) {
+                            L.s.bt = s_mb_t[home]; L.s.bu = s_mb_u[home]; L.s.bv = s_mb_v[home]; L.s.bprim = s_mb_prim[home]; L.s.binst = s_mb_inst[home];
+                        }
+                    }
+                }
+                // ---- A. node step ----
+                uint2 child = make_uint2(0u, 0u), tri = make_uint2(0u, 0u);
+                wait_node_loads(rn0, rn1, rn2, rn3, rn4);
+                if (L.nidx != kNoWork && !hit_any) lean_node(L.s, tmin, rn0, rn1, rn2, rn3, rn4, child, tri);
+                // ---- B. bookkeeping (trav_lean.h: one hand-written sequence): file the new groups; the leaf pass (ONE per iteration, one
+                //      primitive per lane, skipped while few lanes have leaf work and none depends on it); the primitive and the node of
+                //      the next iteration; finished? ----
+                bool done = false;
+                if (hit_any) { lean_reset(L); done = true; }           // an any-hit ray is done with its first accepted intersection
+                if (alive && !done) done = lean_bookkeeping_asm(L, child, tri, ldsn, ldsl, (uint32_t)a.postpone_pct, (uint32_t)a.leaf_quorum) != 0u;
+                if (done && (!kTail || !shared)) { alive = false; waiting = true; }
+                if (kTail) {
+                    // a piece that has finished has nothing left to merge: the mailbox holds the ray's best hit
+                    if (alive && done && shared) {
+                        atomicSub(&s_mb_pending[home], 1u);
+                        alive = false;
+                        if (home != tx) { shared = false; home = tx; }        // a helper is free again; the owner waits for the last piece
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    // the owner of a split ray picks the merged hit up once its last piece has finished
+                    if (shared && !alive && home == tx && s_mb_pending[tx] == 0u) {
+                        L.s.bt = s_mb_t[tx]; L.s.bu = s_mb_u[tx]; L.s.bv = s_mb_v[tx]; L.s.bprim = s_mb_prim[tx]; L.s.binst = s_mb_inst[tx];
+                        shared = false; waiting = true;
+                    }
+                }
+                const uint64_t act = __ballot(alive);
+                if (act == 0ull) break;
+                if (exhausted ? (uint32_t)__popcll(__ballot(waiting)) >= (uint32_t)a.tail_regen : (64u - (uint32_t)__popcll(act)) >= (uint32_t)a.refill_threshold) break;
             }
-            // ---- A. node step ----
-            uint2 child = make_uint2(0u, 0u), tri = make_uint2(0u, 0u);
-            wait_node_loads(rn0, rn1, rn2, rn3, rn4);
-            if (L.nidx != kNoWork && !hit_any) lean_node(L.s, tmin, rn0, rn1, rn2, rn3, rn4, child, tri);
-            // ---- B. bookkeeping (trav_lean.h: one hand-written sequence): file the new groups; the leaf pass (ONE per iteration, one
-            //      primitive per lane, skipped while few lanes have leaf work and none depends on it); the primitive and the node of
-            //      the next iteration; finished? ----
-            if (hit_any) { lean_reset(L); alive = false; waiting = true; }     // an any-hit ray is done with its first accepted intersection
-            if (alive) {
-                const uint32_t fin = lean_bookkeeping_asm(L, child, tri, ldsn, ldsl, (uint32_t)a.postpone_pct, (uint32_t)a.leaf_quorum);
-                if (fin != 0u) { alive = false; waiting = true; }
-            }
-            const uint64_t act = __ballot(alive);
-            if (act == 0ull) break;
-            if ((64u - (uint32_t)__popcll(act)) >= (uint32_t)a.refill_threshold) break;
-        }
+        };
+        if (tail_mode) traverse(std::true_type{}); else traverse(std::false_type{});
     }
 #ifdef HRT_LANE_STATS
     if (tx == 0u) {

@@ -147,6 +147,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_SUBSTREAM_MIN_PIXELS")) { const int v = std::atoi(e); if (v >= 1024) ctx->substream_min_pixels = v; }
     if (const char *e = std::getenv("HRT_SUBSTREAMS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) ctx->substreams = v; }
     if (const char *e = std::getenv("HRT_FUSED_MAX_DEPTH")) { const int v = std::atoi(e); if (v >= 0 && v <= kFusedMaxDepth) ctx->fused_max_depth = v; }
+    if (const char *e = std::getenv("HRT_TAIL_REGEN")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->fused_tail_regen = v; }
     if (const char *e = std::getenv("HRT_LEAF_QUORUM")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->leaf_quorum = v; }
     if (const char *e = std::getenv("HRT_POSTPONE_PCT")) { const int v = std::atoi(e); if (v >= 0 && v <= 100) ctx->postpone_pct = v; }
     if (const char *e = std::getenv("HRT_REFILL_THRESHOLD")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) { ctx->refill_threshold = v; ctx->fused_refill_threshold = v; } }
@@ -327,7 +328,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         ta.fetch_counter = stg[0].fetch;
         ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
         ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;
-        ta.refill_threshold = ctx->fused_refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.leaf_quorum = ctx->leaf_quorum; ta.tail_split = 0; ta.fetch_chunk = (uint32_t)ctx->fused_fetch_chunk;
+        ta.refill_threshold = ctx->fused_refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.leaf_quorum = ctx->leaf_quorum; ta.tail_regen = ctx->fused_tail_regen; ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fused_fetch_chunk;
         PathArgs &pa = ta.path;
         pa.rows = w.rows; pa.first_pixel = 0; pa.n_tile_pixels = n; pa.width = rg->width; pa.height = rg->height; pa.spp = spp;
         std::memcpy(pa.center, &rg->cameraCenter, 12); std::memcpy(pa.U, &rg->cameraU, 12);
@@ -485,7 +486,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         ta.fetch_counter = stages_of(sa, sb)[da].fetch;
         ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
         ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;      // Shader.cu:232, :266
-        ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.leaf_quorum = ctx->leaf_quorum; ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fetch_chunk;
+        ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.leaf_quorum = ctx->leaf_quorum; ta.tail_regen = ctx->fused_tail_regen; ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fetch_chunk;
         Timer tm(ctx, sb.st, (da >= kRayTraceDepth && !second) ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
         launch_traverse(ta, count, t->has_spheres, ctx->lds_gather != 0, sb.grid_trav, sb.st);
     };
@@ -639,12 +640,12 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
     TraverseArgs ta{};
     ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.node_stride = t->node_stride; ta.prim_stride = t->prim_stride;
     ta.fetch_counter = fetch; ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
-    ta.tmin = tmin; ta.tmax = tmax; ta.postpone_pct = ctx->postpone_pct; ta.leaf_quorum = ctx->leaf_quorum;
+    ta.tmin = tmin; ta.tmax = tmax; ta.postpone_pct = ctx->postpone_pct; ta.leaf_quorum = ctx->leaf_quorum; ta.tail_regen = ctx->fused_tail_regen;
     const bool count = (ctx->flags & HRT_CTX_COUNT) != 0;
     if (!count && ctx->fused > 0) {
         // the production configuration: the rays go through the very kernel hrt_render_launch runs (fused path kernel, v_rcp_f32
         // slab test, regeneration thresholds), each ray standing in for a pixel that is traced once and not shaded
-        ta.refill_threshold = ctx->fused_refill_threshold; ta.tail_split = 0; ta.fetch_chunk = (uint32_t)ctx->fused_fetch_chunk;
+        ta.refill_threshold = ctx->fused_refill_threshold; ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fused_fetch_chunk;
         PathArgs &pa = ta.path;
         pa.n_tile_pixels = n_rays; pa.first_pixel = 0; pa.width = n_rays; pa.height = 1; pa.spp = 1;
         pa.trace_rays = rays; pa.trace_tuvp = tuvp; pa.trace_inst = inst; pa.trace_any = any_hit ? 1u : 0u;

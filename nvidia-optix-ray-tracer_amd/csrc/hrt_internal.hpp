@@ -141,6 +141,7 @@ struct HrtContext {
     bool traverse_blocks_auto = true;           // fused mode: fewer of them for small tiles (not when the env knob is set)
     int postpone_pct = 25;
     int fused_max_depth = kFusedMaxDepth;       // deeper trees take round 1's fused kernel (HRT_FUSED_MAX_DEPTH lowers it: tests)
+    int fused_tail_regen = 12;                  // k_fused, tile used up: finished rays that wait before a regeneration (HRT_TAIL_REGEN; 1/8 of C4: 142 ms with 1, 129 with 8..16)
     int leaf_quorum = 1;                        // k_fused: lanes with nothing but leaf work wait until this many of them have gathered (HRT_LEAF_QUORUM)
     int tail_split = 1;
     int node_stride = 80, prim_stride = 64;     // bytes between records in HBM (80/48 packed; 128/64 = one cache line each)

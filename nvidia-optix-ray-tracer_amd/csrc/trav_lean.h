@@ -9,7 +9,8 @@
 //   * two small LDS stacks instead of one mixed LDS + scratch stack: sibling groups (node work) and leaf groups (primitive
 //     work) are popped independently, one pop each per iteration, no "what kind is the top entry" loop; the leaf stack needs no
 //     overflow path at all (a lane whose leaf stack is full does not take a new node until a group has been consumed), the
-//     node stack overflows into scratch behind ONE rarely taken branch;
+//     node stack holds one group per tree level and trees deeper than that take round 1's kernel (hrt_api.cpp);
+//   * the bookkeeping after the node step as one hand-written instruction sequence;
 //   * "no work" encoded in the work index itself (nidx / pidx = kNoWork) instead of separate bools;
 //   * the straight-line primitive test of trav_common.h;
 //   * lazy pushes: the sibling group in hand goes to the stack only when a child group arrives while siblings remain.
@@ -22,17 +23,17 @@ constexpr uint32_t kNoWork = 0xffffffffu;
 static_assert(kFusedMaxDepth == 12, "the node stack below is sized for it");
 constexpr int kNodeStackLds = kFusedMaxDepth;      // sibling groups per lane in LDS: one per tree level above the current node (deeper trees: another kernel)
 constexpr int kLeafStackLds = 4;       // leaf groups per lane in LDS (never more: see lean_select)
-constexpr int kNodeStackSpill = 56;
 
 struct LeanLane {
     TravState s;                 // ray, reciprocal direction, octant, best hit; s.cur = sibling group in hand, s.ptri = leaf group in hand
-    int nsp, lsp;                // entries on the node / leaf stack
+    int nsp, lsp;                // top of the node stack / entries on the leaf stack
+    int base;                    // bottom of the node stack: entries below have been given away (tail splitting, fused.hip)
     uint32_t nidx, pidx;         // node / primitive to fetch next (kNoWork: none)
 };
 
 __device__ __forceinline__ void lean_reset(LeanLane &L) {
     L.s.cur = make_uint2(0u, 0u); L.s.ptri = make_uint2(0u, 0u);
-    L.nsp = 0; L.lsp = 0; L.nidx = kNoWork; L.pidx = kNoWork;
+    L.nsp = 0; L.base = 0; L.lsp = 0; L.nidx = kNoWork; L.pidx = kNoWork;
 }
 
 // a new ray: the root is its first node
@@ -88,53 +89,15 @@ __device__ __forceinline__ void lean_node(const TravState &s, float tmin, const 
     tri = make_uint2(rn1.y, hitmask & 0x00ffffffu);
 }
 
-// Everything after the node step: file the new groups, choose the primitive and the node of the next iteration.
-//   child / tri: what lean_node returned (zeros when the lane had no node this iteration)
-//   leaf_pass:   wave-uniform: lanes with a leaf group in hand take one primitive of it
-// ns / ls: the wave's LDS stacks [entry][lane]; spill: the lane's scratch overflow of the node stack.
-__device__ __forceinline__ void lean_file_groups(LeanLane &L, uint2 child, uint2 tri, uint2 (*ns)[kTraverseBlock], uint2 (*ls)[kTraverseBlock],
-                                                 uint2 *spill, uint32_t tx) {
+// the next node of a lane that has just been handed a sibling group (tail splitting): its nearest child -- step (7) of
+// lean_bookkeeping_asm in C++
+__device__ __forceinline__ void lean_pick_node(LeanLane &L) {
     TravState &s = L.s;
-    // the leaf group of this node: into the hand if it is free, else onto the leaf stack (room is guaranteed: lean_select)
-    if (tri.y != 0u) {
-        if (s.ptri.y == 0u) s.ptri = tri;
-        else { ls[L.lsp][tx] = tri; ++L.lsp; }
-    }
-    // the sibling group of this node's children: it becomes the group in hand; siblings still in hand go to the stack first
-    if (child.y > 0x00ffffffu) {
-        if (s.cur.y > 0x00ffffffu) {
-            if (L.nsp < kNodeStackLds) ns[L.nsp][tx] = s.cur; else spill[L.nsp - kNodeStackLds] = s.cur;
-            ++L.nsp;
-        }
-        s.cur = child;
-    }
-}
-
-__device__ __forceinline__ void lean_select(LeanLane &L, bool leaf_pass, uint2 (*ns)[kTraverseBlock], uint2 (*ls)[kTraverseBlock], uint2 *spill, uint32_t tx) {
-    TravState &s = L.s;
-    // one primitive of the leaf group in hand
-    L.pidx = kNoWork;
-    if (leaf_pass && s.ptri.y != 0u) {
-        const uint32_t k = (uint32_t)__ffs((int)s.ptri.y) - 1u;
-        s.ptri.y &= s.ptri.y - 1u;
-        L.pidx = s.ptri.x + k;
-    }
-    if (s.ptri.y == 0u && L.lsp > 0) { --L.lsp; s.ptri = ls[L.lsp][tx]; }
-    // the next node: the nearest child of the group in hand; an empty hand takes the top of the node stack.  A lane whose
-    // leaf stack could not take another group waits with its node work until primitives have been consumed.
-    if (s.cur.y <= 0x00ffffffu && L.nsp > 0) {
-        --L.nsp;
-        s.cur = L.nsp < kNodeStackLds ? ns[L.nsp][tx] : spill[L.nsp - kNodeStackLds];
-    }
-    L.nidx = kNoWork;
-    if (s.cur.y > 0x00ffffffu && L.lsp < kLeafStackLds) {
-        const uint32_t hits_imask = s.cur.y;
-        const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
-        s.cur.y &= ~(1u << bit);
-        const uint32_t slot_index = (bit - 24u) ^ (s.oct_inv4 & 0xffu);
-        const uint32_t rel = (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot_index));
-        L.nidx = s.cur.x + rel;
-    }
+    const uint32_t hits_imask = s.cur.y;
+    const uint32_t bit = 31u - (uint32_t)__clz((int)hits_imask);
+    s.cur.y &= ~(1u << bit);
+    const uint32_t slot_index = (bit - 24u) ^ (s.oct_inv4 & 0xffu);
+    L.nidx = s.cur.x + (uint32_t)__popc(hits_imask & ~(0xffffffffu << slot_index));
 }
 
 // Hand-issued loads like issue_*_loads_masked (trav_common.h), addressed as uniform base + 32-bit byte offset per lane (one
@@ -163,10 +126,21 @@ __device__ __forceinline__ void issue_node_loads_off(uint64_t mask, const void *
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "=&s"(save) : "v"(off), "s"(base), "s"(mask) : "memory");
 }
 
-// lean_file_groups + the leaf-pass decision + lean_select + lean_finished as ONE hand-written instruction sequence (the C++ above
-// is its specification; hipcc turns it into ~250 instructions, two thirds of them mask bookkeeping; this is 88).  Runs for the
-// lanes that are active at the call (alive, not finished by an any-hit); inactive lanes keep their registers.  The node stack
-// has NO overflow path here: the caller guarantees a tree of at most kNodeStackLds levels below the root.
+// Everything after the node step as ONE hand-written instruction sequence: file the node's two groups, decide on the leaf pass,
+// choose the primitive and the node of the next iteration, report finished rays.  (Written in C++ this is ~250 instructions,
+// two thirds of them mask bookkeeping: every `if` on per-lane data a mask save, a branch and a restore; here it is 97.)
+//   (1) the node's leaf group (tri: first primitive, bit per primitive that may be hit) goes into the hand (s.ptri) if that is
+//       empty, else onto the leaf stack -- room is guaranteed by (7)
+//   (2) the node's sibling group (child: first child, hit bits 31..24 | inner mask) becomes the group in hand (s.cur); siblings
+//       still in hand go to the node stack first (lazy push)
+//   (3) leaf pass?  (4) lanes with a leaf group in hand take one primitive of it  (5) an empty hand takes the top of the leaf stack
+//   (6) a group in hand without hits left is replaced by the top of the node stack (entries [base, nsp) are the lane's own:
+//       the bottom may have been given away, tail splitting)
+//   (7) the next node: the nearest child of the group in hand -- unless the leaf stack could not take another group: such a
+//       lane waits with its node work until primitives have been consumed, which is why the leaf stack needs no overflow path
+//   (8) nothing left to do?
+// Runs for the lanes that are active at the call (alive, not finished by an any-hit); inactive lanes keep their registers.  The
+// node stack has NO overflow path either: the caller guarantees a tree of at most kNodeStackLds levels below the root.
 //   ldsn / ldsl: byte address in LDS of this lane's column of the node / leaf stack (entries are 512 bytes apart)
 //   pct, quorum: leaf passes are skipped while fewer than pct % of the active lanes have leaf work and fewer than `quorum`
 //   lanes have nothing else to do (those wait)
@@ -206,7 +180,7 @@ __device__ __forceinline__ uint32_t lean_bookkeeping_asm(LeanLane &L, uint2 chil
         "v_cmp_ne_u32_e32 vcc, 0, %[py]\n\t"
         "s_mov_b64 %[sv1], vcc\n\t"
         "v_cmp_ge_u32_e32 vcc, %[k24], %[cy]\n\t"
-        "v_cmp_eq_u32_e64 %[sv2], 0, %[nsp]\n\t"
+        "v_cmp_eq_u32_e64 %[sv2], %[base], %[nsp]\n\t"
         "s_and_b64 %[sv2], %[sv2], vcc\n\t"
         "s_bcnt1_i32_b64 %[c0], %[sv1]\n\t"
         "s_bcnt1_i32_b64 %[c1], exec\n\t"
@@ -248,7 +222,7 @@ __device__ __forceinline__ uint32_t lean_bookkeeping_asm(LeanLane &L, uint2 chil
         "s_mov_b64 exec, %[sv0]\n\t"
         // (6) a group in hand without hits left is replaced by the top of the node stack
         "v_cmp_ge_u32_e32 vcc, %[k24], %[cy]\n\t"
-        "v_cmp_ne_u32_e64 %[sv1], 0, %[nsp]\n\t"
+        "v_cmp_ne_u32_e64 %[sv1], %[base], %[nsp]\n\t"
         "s_and_b64 exec, vcc, %[sv1]\n\t"
         "v_add_u32_e32 %[nsp], -1, %[nsp]\n\t"
         "v_lshl_add_u32 %[t0], %[nsp], 9, %[ldsn]\n\t"
@@ -274,7 +248,8 @@ __device__ __forceinline__ uint32_t lean_bookkeeping_asm(LeanLane &L, uint2 chil
         "s_mov_b64 exec, %[sv0]\n\t"
         // (8) nothing left?
         "v_and_b32_e32 %[t0], %[nidx], %[pidx]\n\t"
-        "v_or3_b32 %[t1], %[py], %[nsp], %[lsp]\n\t"
+        "v_sub_u32_e32 %[t2], %[nsp], %[base]\n\t"
+        "v_or3_b32 %[t1], %[py], %[t2], %[lsp]\n\t"
         "v_cmp_eq_u32_e32 vcc, -1, %[t0]\n\t"
         "v_cmp_eq_u32_e64 %[sv1], 0, %[t1]\n\t"
         "s_and_b64 %[sv1], %[sv1], vcc\n\t"
@@ -284,15 +259,10 @@ __device__ __forceinline__ uint32_t lean_bookkeeping_asm(LeanLane &L, uint2 chil
         : [cx] "+v"(L.s.cur.x), [cy] "+v"(L.s.cur.y), [px] "+v"(L.s.ptri.x), [py] "+v"(L.s.ptri.y), [nsp] "+v"(L.nsp), [lsp] "+v"(L.lsp),
           [nidx] "+v"(L.nidx), [pidx] "+v"(L.pidx), [fin] "=&v"(fin), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
           [sv0] "=&s"(sv0), [sv1] "=&s"(sv1), [sv2] "=&s"(sv2), [c2] "=&s"(c2), [c0] "=&s"(c0), [c1] "=&s"(c1)
-        : [chx] "v"(child.x), [chy] "v"(child.y), [tx] "v"(tri.x), [ty] "v"(tri.y), [oct] "v"(L.s.oct_inv4), [ldsn] "v"(ldsn), [ldsl] "v"(ldsl),
+        : [chx] "v"(child.x), [chy] "v"(child.y), [tx] "v"(tri.x), [ty] "v"(tri.y), [oct] "v"(L.s.oct_inv4), [base] "v"(L.base), [ldsn] "v"(ldsn), [ldsl] "v"(ldsl),
           [k24] "s"(k24), [pct] "s"(pct), [quorum] "s"(quorum)
         : "vcc", "scc", "memory");
     return fin;
-}
-
-// nothing left to do for this lane's ray?
-__device__ __forceinline__ bool lean_finished(const LeanLane &L) {
-    return L.nidx == kNoWork && L.pidx == kNoWork && L.s.ptri.y == 0u && L.s.cur.y <= 0x00ffffffu && L.nsp == 0 && L.lsp == 0;
 }
 
 }  // namespace hrt

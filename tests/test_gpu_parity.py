@@ -932,6 +932,9 @@ MODES = {
     "slot-pipeline-two-samples-per-launch": {"HRT_FUSED": "3", "HRT_FUSED_MAX_SPP": "2", "HRT_PATHS_SLOTS": "96"},
     "fused-two-samples-per-launch": {"HRT_FUSED_MAX_SPP": "2"},
     "fused-round-1-kernel": {"HRT_FUSED": "2"},
+    "fused-no-tail-splitting": {"HRT_TAIL_SPLIT": "0"},
+    "fused-tail-splitting-eager-regeneration-few-waves": {"HRT_TAIL_REGEN": "1", "HRT_TRAVERSE_BLOCKS_PER_CU": "2", "HRT_FETCH_CHUNK": "16"},
+    "fused-tail-splitting-lazy-regeneration": {"HRT_TAIL_REGEN": "40", "HRT_TRAVERSE_BLOCKS_PER_CU": "1"},
     "fused-deep-trees-take-round-1-kernel": {"HRT_FUSED_MAX_DEPTH": "1"},
     "fused-leaf-quorum-lazy-leaf-passes": {"HRT_LEAF_QUORUM": "12", "HRT_POSTPONE_PCT": "70"},
     "fused-eager-leaf-passes-one-wave-per-simd": {"HRT_POSTPONE_PCT": "0", "HRT_TRAVERSE_BLOCKS_PER_CU": "4", "HRT_REFILL_THRESHOLD": "48"},

@@ -30,7 +30,7 @@ def loops(source, prefix):
         if not hdrs:
             continue
         hdr = max(hdrs)
-        nxt = [i for i, l in enumerate(body) if "Loop Header: Depth=" in l and i > idx]
+        nxt = [i for i, l in enumerate(body) if ("Loop Header: Depth=1" in l or "Loop Header: Depth=2" in l) and i > idx]
         limit = min(nxt) if nxt else len(body)
         back = [(i, labels[l.strip().split()[-1]]) for i, l in enumerate(body)
                 if idx < i < limit and "branch" in l and l.strip().split()[-1] in labels and hdr - 60 <= labels[l.strip().split()[-1]] <= hdr]

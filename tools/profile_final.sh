@@ -24,14 +24,15 @@ pmc fs FETCH_SIZE
 python3 - "$TAG" "$BUILD_ID" <<'PY'
 import csv, glob, json, collections, sys, time
 tag, build = sys.argv[1], sys.argv[2]
-acc = collections.defaultdict(list)
+acc = collections.defaultdict(list); kernel_names = set()
 for path in glob.glob("gpurun_out/final/*/*/*counter_collection.csv"):
     for row in csv.DictReader(open(path)):
-        if "k_traverse<false, false, false, true>" in row["Kernel_Name"] or "k_paths<" in row["Kernel_Name"]:
+        if "k_fused<" in row["Kernel_Name"] or "k_traverse<false, false, false, true>" in row["Kernel_Name"] or "k_paths<" in row["Kernel_Name"]:
+            kernel_names.add(row["Kernel_Name"])
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in acc.items()}
 prov = {"build": build, "taken": time.strftime("%Y-%m-%d %H:%M:%S"), "command": "rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline  (tools/profile_final.sh)",
-        "workload": "C4, 1920x1080, 256 spp: one launch of the fused path kernel = one bench step", "kernel": "hrt::k_traverse<false, false, false, true> (COUNT off, SPHERES off, DMA off, FUSED on)"}
+        "workload": "C4, 1920x1080, 256 spp: one launch of the fused path kernel = one bench step", "kernel": " / ".join(sorted(kernel_names))}
 cycles = m.get("GRBM_GUI_ACTIVE", 0) / 8.0                        # the counter is the sum over the 8 XCDs
 simds = 256 * 4
 valu = {"kernel_cycles": cycles,
