@@ -20,6 +20,18 @@
 
 namespace hrt {
 
+// Issue priority of a wave per phase of its loop (s_setprio: among the waves of a SIMD that are ready, the highest goes first).
+// A wave that is about to fetch -- the bookkeeping that chooses its next node and primitive, the loads themselves -- and a wave
+// in a regeneration go before a wave in its node step, and that before a wave in its primitive test: the fetches go out as
+// early as possible and the waves drift apart instead of queueing for memory together.  C4: 3180 -> 3390 Mrays/s
+// (profiles/r02_sweep_wave_priority.txt; every other assignment of the levels tried is within 3 % of this one, none at all -6 %).
+#ifndef HRT_PRIO_BOOK
+#define HRT_PRIO_BOOK 2      // bookkeeping + address arithmetic + load issue
+#define HRT_PRIO_PRIM 0      // primitive wait + test
+#define HRT_PRIO_NODE 1      // node wait + slab tests
+#define HRT_PRIO_REGEN 2     // shading, next pixel, new ray
+#endif
+
 template <bool HAS_SPHERES>
 #ifndef HRT_FUSED_WAVES_PER_SIMD
 #define HRT_FUSED_WAVES_PER_SIMD 4      // 125 VGPRs and no spills: 3122 Mrays/s on C4; 5 waves (96 VGPRs, 95 spilled around the shading) 2560
@@ -75,11 +87,11 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
         // (once the tile is used up the lanes without a pixel stay idle and the render ends with the slowest pixels' sample chains:
         // what counts then is how soon a finished ray's successor starts, against what a regeneration costs the rays still under
         // way -- a dozen waiting rays, or nothing else left to do: 1/8 of the C4 frame 142 ms with 1, 129 ms with 8 to 16)
-        const bool tail_mode = exhausted && a.tail_split;      // wave-uniform: lanes without a pixel help the others
         if (idle == ~0ull || (exhausted ? (uint32_t)__popcll(__ballot(waiting)) >= (uint32_t)a.tail_regen : n_idle >= (uint32_t)a.refill_threshold)) {
 #ifdef HRT_LANE_STATS
             ++ls_regen;
 #endif
+            __builtin_amdgcn_s_setprio(HRT_PRIO_REGEN);
             bool launch = false, want_primary = false;      // launch: this lane starts the ray (ro, rd) below
             V3 ro = mk3(0.0f, 0.0f, 0.0f), rd = mk3(0.0f, 0.0f, 1.0f);
             if (!alive && waiting) {
@@ -181,7 +193,8 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
         if (__ballot(alive) == 0ull) break;     // the tile is used up and every lane has finished (nothing waits after a full regeneration)
 
         // ---- traverse until enough lanes have finished to make a regeneration worthwhile ----
-        // Two copies of the loop: the second one, with tail splitting, runs once the tile is used up -- the first pays nothing for it.
+        // Two copies of the loop: the second one, with tail splitting and the drained phase's exit rule, runs once the tile is used
+        // up -- the first pays nothing for either.
         auto traverse = [&](auto tail_tag) {
             constexpr bool kTail = decltype(tail_tag)::value;
             // the registers the loads land in: "defined" without an instruction (lanes that load nothing never look at theirs)
@@ -195,7 +208,7 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
                 //      the lane that owns the ray: a piece publishes every improvement there (canonical order: the result does not
                 //      depend on who found what, or when) and adopts what the others found closer, so every piece culls with the
                 //      ray's best hit so far. ----
-                if (kTail) {
+                if (kTail && a.tail_split) {
                     const bool is_free = !alive && !waiting && !have_pixel && !shared;
                     const uint64_t free_m = __ballot(is_free);
                     const uint64_t donors = __ballot(alive && L.nsp > L.base);
@@ -245,6 +258,7 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
                     asm volatile("" : "+v"(po), "+v"(no));          // both offsets before the first load
                     if (mask_p != 0ull) issue_prim_loads_off(mask_p, prim_bytes, po, rpa, rpb, rpc);
                     issue_node_loads_off(mask_n0, node_bytes, no, rn0, rn1, rn2, rn3, rn4);
+                    __builtin_amdgcn_s_setprio(HRT_PRIO_PRIM);
                 }
     #ifdef HRT_LANE_STATS
                 { ++ls_iter; ls_alive += __popcll(__ballot(alive)); ls_node += __popcll(mask_n0); ls_prim += __popcll(mask_p); ls_ppass += mask_p != 0ull; }
@@ -260,7 +274,7 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
                         hit_any = any && improved;
                     }
                 }
-                if (kTail) {
+                if (kTail && a.tail_split) {
                     // pieces of split rays publish their improvements one lane at a time (rare: a few per ray) ...
                     uint64_t pub = __ballot(improved && shared);
                     while (pub) {
@@ -288,16 +302,20 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
                 }
                 // ---- A. node step ----
                 uint2 child = make_uint2(0u, 0u), tri = make_uint2(0u, 0u);
+                __builtin_amdgcn_s_setprio(HRT_PRIO_NODE);
                 wait_node_loads(rn0, rn1, rn2, rn3, rn4);
                 if (L.nidx != kNoWork && !hit_any) lean_node(L.s, tmin, rn0, rn1, rn2, rn3, rn4, child, tri);
                 // ---- B. bookkeeping (trav_lean.h: one hand-written sequence): file the new groups; the leaf pass (ONE per iteration, one
                 //      primitive per lane, skipped while few lanes have leaf work and none depends on it); the primitive and the node of
                 //      the next iteration; finished? ----
+                __builtin_amdgcn_s_setprio(HRT_PRIO_BOOK);
                 bool done = false;
-                if (hit_any) { lean_reset(L); done = true; }           // an any-hit ray is done with its first accepted intersection
+                if (__ballot(hit_any) != 0ull) {                       // (rare: behind a branch, not nine masked moves per iteration)
+                    if (hit_any) { lean_reset(L); done = true; }       // an any-hit ray is done with its first accepted intersection
+                }
                 if (alive && !done) done = lean_bookkeeping_asm(L, child, tri, ldsn, ldsl, (uint32_t)a.postpone_pct, (uint32_t)a.leaf_quorum) != 0u;
                 if (done && (!kTail || !shared)) { alive = false; waiting = true; }
-                if (kTail) {
+                if (kTail && a.tail_split) {
                     // a piece that has finished has nothing left to merge: the mailbox holds the ray's best hit
                     if (alive && done && shared) {
                         atomicSub(&s_mb_pending[home], 1u);
@@ -314,10 +332,10 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
                 }
                 const uint64_t act = __ballot(alive);
                 if (act == 0ull) break;
-                if (exhausted ? (uint32_t)__popcll(__ballot(waiting)) >= (uint32_t)a.tail_regen : (64u - (uint32_t)__popcll(act)) >= (uint32_t)a.refill_threshold) break;
+                if (kTail ? (uint32_t)__popcll(__ballot(waiting)) >= (uint32_t)a.tail_regen : (64u - (uint32_t)__popcll(act)) >= (uint32_t)a.refill_threshold) break;
             }
         };
-        if (tail_mode) traverse(std::true_type{}); else traverse(std::false_type{});
+        if (exhausted) traverse(std::true_type{}); else traverse(std::false_type{});
     }
 #ifdef HRT_LANE_STATS
     if (tx == 0u) {
