@@ -225,6 +225,11 @@ def main():
                                 "wave_time_split": {k: round(v, 4) for k, v in (d["valu"].get("wave_time_split") or {}).items()},
                                 "file": f"profiles/{pf.name}", "build": d.get("provenance", {}).get("build"),
                                 "what": "SQ_INSTS_VALU x 4 cycles / (kernel cycles x 1024 SIMDs); SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)"}
+                        c = d.get("counters_mean_per_launch", {})
+                        if c.get("SQ_INSTS_VALU") and d["valu"].get("kernel_cycles"):
+                            n_inst = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"))
+                            valu["instructions_per_launch"] = n_inst
+                            valu["simd_cycles_per_instruction"] = round(d["valu"]["kernel_cycles"] * 1024.0 / n_inst, 3)
                 except Exception:
                     valu = None
         out = {
@@ -246,11 +251,12 @@ def main():
             # `achieved` / `frac` are the ALGORITHMIC bytes (80 B per node visit + 48 B per primitive test) over the launch
             # time: the contract's figure.  They are NOT what limits the kernel: the bytes are served by L1 / L2 / Infinity Cache
             # (`traffic` = what reached the fabric, `measured_frac` = that over launch time over the HBM peak), and the kernel is
-            # bound by VALU issue at ~half the lanes active (`limited_by`, `valu`; DESIGN.md section 4 has the experiments).
+            # bound by instruction issue -- one instruction of any kind per ~2.7 SIMD cycles -- at ~60 % of the lanes active (`limited_by`,
+            # `valu`; DESIGN.md section 4.1 has the model and the experiments).
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "measured_frac": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_ms > 0 else None,
-                         "limited_by": "valu-issue", "valu": valu, "algorithmic_gbps": round(achieved, 2),
+                         "limited_by": "instruction-issue", "valu": valu, "algorithmic_gbps": round(achieved, 2),
                          "bytes_per_ray": round(b_closest, 1), "nodes_per_ray": round(nodes_per_ray, 3),
                          "prims_per_ray": round(prims_per_ray, 3), "bytes_per_any_hit_ray": round(b_any, 1),
                          "bytes_per_launch": round(bytes_per_launch, 0), "avg_launch_ms": round(avg_launch_ms, 4),
