@@ -156,6 +156,7 @@ typedef struct HrtStats {
                                               sum of alive lanes over iterations, reserved                     */
     uint64_t tlas_refits, tlas_rebuilds;   /* hrt_tlas_update calls served by the device refit / builds + rebuilds    */
     double   tlas_refit_ratio;             /* quality sum of the last refitted tree checked / that of the built tree  */
+    uint64_t bvh_depth;                    /* levels below the root of the TLAS last launched (trees deeper than 12 take round 1's path kernel) */
 } HrtStats;
 
 int  hrt_stats_reset(HrtContext *ctx);

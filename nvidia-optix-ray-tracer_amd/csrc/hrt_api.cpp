@@ -613,7 +613,7 @@ int hrt_stats_get(HrtContext *ctx, HrtStats *out) {
     auto it = ctx->tlas.find(ctx->last_tlas);
     if (it != ctx->tlas.end()) {
         const Tlas &tl = *it->second;
-        out->bvh_nodes = tl.n_nodes; out->bvh_triangles = tl.n_triangles; out->bvh_spheres = tl.n_spheres;
+        out->bvh_nodes = tl.n_nodes; out->bvh_triangles = tl.n_triangles; out->bvh_spheres = tl.n_spheres; out->bvh_depth = tl.max_depth;
         out->bvh_bytes = (uint64_t)tl.n_nodes * sizeof(Bvh8Node) + (uint64_t)tl.n_prims * sizeof(PrimRecord);
     }
     return HRT_OK;

@@ -50,7 +50,8 @@ def face_normals(vertices: np.ndarray) -> np.ndarray:
     e1 = v[:, 1] - v[:, 0]
     e2 = v[:, 2] - v[:, 0]
     n = np.cross(e1, e2).astype(np.float32)
-    ln = np.sqrt((n * n).sum(axis=1, dtype=np.float32)).astype(np.float32)
+    with np.errstate(over="ignore"):          # huge triangles (growing_chain): the squares overflow, the normal becomes 0 -- for everyone alike
+        ln = np.sqrt((n * n).sum(axis=1, dtype=np.float32)).astype(np.float32)
     ok = ln > 0
     n[ok] = (n[ok] / ln[ok, None]).astype(np.float32)
     n[~ok] = np.array([0, 0, 1], dtype=np.float32)
@@ -142,6 +143,20 @@ def _random_triangles(n, edge, seed):
     third = np.float32(1.0 / 3.0)
     v0 = (c - (e1 + e2) * third).astype(np.float32)          # centroid stays at c
     return np.stack([v0, (v0 + e1).astype(np.float32), (v0 + e2).astype(np.float32)], axis=1).astype(np.float32)
+
+
+def growing_chain(n_triangles=210, growth=1.1, width=96, height=64, spp=2):
+    """A deep tree on purpose: triangles whose size and distance from the origin grow geometrically, so that every SAH split takes
+    one triangle off the rest.  210 triangles at 1.1 give a BVH8 of 12 levels below the root with the host builder (the most
+    the path kernel's LDS node stack holds), 300 give 13 (round 1's kernel takes over).  One metal material with fuzz."""
+    k = np.arange(n_triangles, dtype=np.float64)
+    s = 0.004 * growth ** k
+    c = np.stack([3.0 * s, 0.3 * s, 0.0 * s], axis=1)
+    v = np.stack([c + np.stack([-s, -s, 0.0 * s], 1), c + np.stack([s, -s, 0.0 * s], 1), c + np.stack([0.0 * s, s, 0.2 * s], 1)], axis=1)
+    cam = {"center": np.array([-20, 5, 40], dtype=np.float32), "target": np.array([60, 6, 0], dtype=np.float32),
+           "up": np.array([0, 1, 0], dtype=np.float32), "opengl": True}
+    return {"name": f"chain-{n_triangles}", "instances": [_tri_instance(v, WHITE, material="metal", fuzz=0.3)], "camera": cam,
+            "background": BACKGROUND.copy(), "width": width, "height": height, "spp": spp}
 
 
 def _soup_camera():

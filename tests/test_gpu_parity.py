@@ -981,6 +981,40 @@ def test_every_execution_mode_is_bit_exact(hrt, oracle, gpu_available, monkeypat
         r.close()
 
 
+@pytest.mark.parametrize("builder", ["host", "device"])
+def test_deep_trees_at_and_beyond_the_path_kernels_node_stack(hrt, oracle, gpu_available, monkeypatch, builder):
+    """k_fused keeps one sibling group per tree level in LDS, 12 at most, and has no overflow path; deeper trees take round 1's
+    path kernel by themselves.  Two scenes built to be deep (scenes.growing_chain): with the host builder 12 levels below the
+    root -- the stack used to its last entry -- and 13; with the device builder whatever PLOC makes of them.  Image, RNG states and
+    ray counts are the oracle's in every case."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    if builder == "host":
+        monkeypatch.setenv("HRT_BUILD", "host")
+    depths = []
+    r = hrt.Renderer(0, 0)
+    try:
+        for n in (210, 300):
+            scene = hrt.scenes.growing_chain(n)
+            w, h, spp = scene["width"], scene["height"], scene["spp"]
+            r.load_scene(scene)
+            r.set_frame(w, h, hrt.scenes.SEED_SALT, aov=False, linear=True)
+            r.reset_stats()
+            r.render(spp)
+            states = oracle.rng_init(w, h, hrt.scenes.SEED_SALT)
+            ref = oracle.OracleScene(scene).render(w, h, states, spp)
+            assert ref["rays"] > 3 * w * h * spp                       # the paths do bounce around in there
+            assert np.array_equal(r.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32)), n
+            assert np.array_equal(r.rng_states_numpy(), states), n
+            st = r.stats()
+            assert st.rays == ref["rays"], n
+            depths.append(int(st.bvh_depth))
+    finally:
+        r.close()
+    if builder == "host":
+        assert depths == [12, 13], depths          # = kFusedMaxDepth and one more: both kernels ran
+
+
 def test_cost_ordered_slices_bit_exact(hrt, oracle, gpu_available):
     """Few pixels per lane and many samples: the first samples run as a probe launch that measures the slices, the rest
     of the render hands the slices out slowest first.  The order is free -- image, RNG states and ray count are those of
