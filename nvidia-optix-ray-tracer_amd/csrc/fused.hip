@@ -310,9 +310,9 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
                 //      the next iteration; finished? ----
                 __builtin_amdgcn_s_setprio(HRT_PRIO_BOOK);
                 bool done = false;
-                if (__ballot(hit_any) != 0ull) {                       // (rare: behind a branch, not nine masked moves per iteration)
-                    if (hit_any) { lean_reset(L); done = true; }       // an any-hit ray is done with its first accepted intersection
-                }
+                // an any-hit ray is done with its first accepted intersection: nothing more to fetch (what is left on its stacks is
+                // dropped when the lane's next ray starts, lean_start)
+                if (hit_any) { L.nidx = kNoWork; L.pidx = kNoWork; done = true; }
                 if (alive && !done) done = lean_bookkeeping_asm(L, child, tri, ldsn, ldsl, (uint32_t)a.postpone_pct, (uint32_t)a.leaf_quorum) != 0u;
                 if (done && (!kTail || !shared)) { alive = false; waiting = true; }
                 if (kTail && a.tail_split) {
