@@ -66,13 +66,16 @@ $(LIBDIR)/libhrt_io.so: $(CSRC)/host/scene_io.cpp $(CSRC)/host/json_min.hpp incl
 oracle:
 	$(MAKE) -C oracle
 
-tools: $(LIBDIR)/hrt_render $(LIBDIR)/hrt_time_render
+tools: $(LIBDIR)/hrt_render $(LIBDIR)/hrt_time_render $(LIBDIR)/hrt_mesh_render
 
 $(LIBDIR)/hrt_render: $(CSRC)/host/hrt_render.cpp $(CSRC)/host/renderer_host.hpp $(CSRC)/host/multi_gpu.hpp $(LIBDIR)/libhrt.so
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Iinclude -I$(CSRC) -I/opt/rocm/include -o $@ $< -L$(LIBDIR) -lhrt -L/opt/rocm/lib -lrccl -pthread -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 $(LIBDIR)/hrt_time_render: $(CSRC)/host/hrt_time_render.cpp $(CSRC)/host/renderer_host.hpp $(LIBDIR)/libhrt.so $(LIBDIR)/libhrt_io.so
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Iinclude -I$(CSRC) -o $@ $< -L$(LIBDIR) -lhrt -lhrt_io -Wl,-rpath,'$$ORIGIN'
+
+$(LIBDIR)/hrt_mesh_render: $(CSRC)/host/hrt_mesh_render.cpp $(CSRC)/host/renderer_host.hpp $(LIBDIR)/libhrt.so $(LIBDIR)/libhrt_io.so
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Iinclude -I$(CSRC) -o $@ $< -L$(LIBDIR) -lhrt -lhrt_io -pthread -Wl,-rpath,'$$ORIGIN'
 
 clean:
 	rm -rf $(LIBDIR)

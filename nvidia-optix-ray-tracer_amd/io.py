@@ -252,3 +252,117 @@ def time_mode_scene(config_path, base_dir=None, width=None, height=None):
     frames = [int(np.float32(d) * np.float32(cfg["fps"] * cfg["render-speed-ratio"])) for d in durations]   # RendererTime.cu:427-428
     return {"scene": scene, "config": cfg, "states": [s["states"] for s in steps], "durations": durations, "frame_counts": frames,
             "n_extra": len(cfg["spheres"]), "shapes": shapes, "ramp": ramp}
+
+
+def mesh_mode_scene(config_path, base_dir=None, width=None, height=None):
+    """What RendererMesh::commitRendererData assembles (src/Global/RendererMesh.cu:160-310), one scene dict per VTK file for
+    Renderer.load_scene plus the drift velocities for Renderer.pose_instances(..., mesh_mode=True):
+      instances = the config's extra spheres (their static matrices), then one instance per particle of the file with its OWN
+      geometry (one GAS per particle, :107-114), rough albedo = ramp[particle id] where the ramp has metadata.cache's
+      max-cell-count colours (:222-232), identity transform until the first frame."""
+    from . import scenes
+    cfg = load_config(config_path)
+    base = Path(base_dir) if base_dir is not None else Path(config_path).resolve().parent.parent / "bin"
+    resolve = lambda p: p if os.path.isabs(p) else os.path.normpath(str(base / p)) + ("/" if p.endswith("/") else "")   # noqa: E731
+    files, durations = read_series(resolve(cfg["series-path"]), cfg["series-name"])
+    cache_dir = resolve(cfg["cache-path"])
+    ramp = bake_color_ramp(cfg["particle-material-preset"], read_metadata_cache(cache_dir))
+    extra = []
+    for sp in cfg["spheres"]:
+        if sp["metal"]:
+            m = cfg["metals"][sp["material_index"]]
+            extra.append(scenes._sphere_instance([sp["center"]], [sp["radius"]], m[:3], "metal", float(m[3]), sp["transform"]))
+        else:
+            extra.append(scenes._sphere_instance([sp["center"]], [sp["radius"]], cfg["roughs"][sp["material_index"]], "rough", 0.0, sp["transform"]))
+    w, h = cfg["window"]
+    out_scenes, velocities = [], []
+    for k in range(len(files)):
+        particles = read_mesh_cache(os.path.join(cache_dir, f"particle{k}.cache"))
+        inst = [dict(e) for e in extra]
+        for p in particles:
+            inst.append({"geometry": "triangles", "vertices": p["vertices"], "normals": p["normals"], "material": "rough",
+                         "albedo": ramp[p["id"]].copy(), "fuzz": 0.0, "transform": scenes.IDENTITY.copy()})
+        out_scenes.append({"name": f"mesh-mode:{cfg['series-name']}:{k}", "instances": inst,
+                           "camera": {"center": cfg["camera-center"], "target": cfg["camera-target"], "up": cfg["up-direction"], "opengl": cfg["opengl"]},
+                           "background": scenes.BACKGROUND.copy(), "width": width or w, "height": height or h, "spp": 1})
+        velocities.append(np.array([p["velocity"] for p in particles], np.float32).reshape(-1, 3))
+    frames = [int(np.float32(d) * np.float32(cfg["fps"] * cfg["render-speed-ratio"])) for d in durations]   # RendererMesh.cu:366-367
+    return {"scenes": out_scenes, "config": cfg, "velocities": velocities, "durations": durations, "frame_counts": frames, "n_extra": len(cfg["spheres"])}
+
+
+def write_mesh_mode_sample(root, n_files=3, n_particles=12, seed=11, width=160, height=120, as_vtk=False):
+    """A small synthetic Mesh-mode data set in the reference's on-disk formats under `root` (the reference ships only a Time-mode
+    sample): bin/ (the "executable's" directory the config's paths are relative to), files/mesh.vtk.series, cache/particleN.cache +
+    cache/metadata.cache -- or, with as_vtk, files/mesh_N.vtk (triangle strips with CELL_DATA id / vel) for the cache run to convert --
+    and config.json.  Particles: small closed blobs (cache form) or zigzag ribbons of 6 points = 4 triangles (VTK form: one strip
+    per particle) that move between the files and drift within one; a ground sphere from the config.  Returns the config path."""
+    import json
+    from . import scenes
+    root = Path(root)
+    for d in ("bin", "files", "cache"):
+        (root / d).mkdir(parents=True, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    base_pos = rng.uniform(-1.2, 1.2, (n_particles, 3)).astype(np.float32) * np.array([1, 1, 0.4], np.float32)
+    vel = rng.uniform(-0.6, 0.6, (n_particles, 3)).astype(np.float32)
+    shapes = [scenes._blob_shape(1, 0.12 + 0.02 * (i % 4), seed + i) for i in range(n_particles)]
+    times = [0.0]
+    for k in range(n_files):
+        times.append(times[-1] + 0.01 * (k + 1))
+    max_cells = 0
+    for k in range(n_files):
+        particles = []
+        ids = rng.permutation(n_particles)                              # the files list the particles in no particular order
+        for i in range(n_particles):
+            v = (shapes[i] + (base_pos[i] + vel[i] * np.float32(times[k]))).astype(np.float32)
+            particles.append({"id": int(ids[i]), "velocity": vel[i], "vertices": v, "normals": scenes.face_normals(v)})
+        max_cells = max(max_cells, int(ids.max()) + 1)
+        if as_vtk:
+            ribbons = []
+            for i in range(n_particles):
+                j = np.arange(6, dtype=np.float32)
+                pts = np.stack([0.08 * j, 0.1 * (j % 2), 0.02 * j * (i % 3)], axis=1).astype(np.float32) + (base_pos[i] + vel[i] * np.float32(times[k])).astype(np.float32)
+                ribbons.append({"id": int(ids[i]), "velocity": vel[i], "points": pts})
+            _write_vtk_mesh_file(root / "files" / f"mesh_{k}.vtk", ribbons)
+        else:
+            write_mesh_cache(str(root / "cache" / f"particle{k}.cache"), particles)
+    if not as_vtk:
+        write_metadata_cache(str(root / "cache") + "/", max_cells)
+    series = {"file-series-version": "1.0", "files": [{"name": f"mesh_{k}.vtk", "time": times[k]} for k in range(n_files)]}
+    (root / "files" / "mesh.vtk.series").write_text(json.dumps(series, indent=1))
+    cfg = {"mesh": True, "series-path": "../files/", "series-name": "mesh.vtk.series", "cache-path": "../cache/", "stl-path": "../files/",
+           "cache": bool(as_vtk), "debug-mode": False, "cache-process-thread-count": 3, "particle-material-preset": "viridis",
+           "roughs": [{"albedo": [0.70, 0.60, 0.50]}], "metals": [{"albedo": [0.8, 0.85, 0.88], "fuzz": 0.1}],
+           "spheres": [{"center": [0.0, 0.0, 0.0], "radius": 100.0, "mat-type": "ROUGH", "mat-index": 0, "shift": [0.0, 0.0, -100.6],
+                        "rotate": [0.0, 0.0, 0.0], "scale": [1.0, 1.0, 1.0]}],
+           "triangles": [],
+           "loop-data": {"api": "VK", "window-width": width, "window-height": height, "fps": 100, "camera-center": [4.0, 0.5, 1.0],
+                         "camera-target": [0.0, 0.0, 0.0], "up-direction": [0.0, 0.0, 1.0], "camera-pitch-limit-degree": 85.0,
+                         "camera-speed-stride": 0.002, "camera-initial-speed-ratio": 10, "mouse-sensitivity": 0.002, "render-speed-ratio": 3,
+                         "particle-shift": [0.1, 0.0, 0.05], "particle-scale": [1.0, 1.0, 1.0]}}
+    path = root / "files" / "config.json"
+    path.write_text(json.dumps(cfg, indent=1))
+    return path
+
+
+def _write_vtk_mesh_file(path, ribbons):
+    """Legacy ASCII POLYDATA with one TRIANGLE_STRIP per particle and CELL_DATA id / vel: the input of the cache run
+    (vtk_reader::readVTKMeshFile, src/Util/VTKReaderImpl.cpp:24-137).  ribbons: dict(id, velocity, points (m,3)): strip k of m points
+    is m - 2 triangles."""
+    pts, strips = [], []
+    for r in ribbons:
+        b = len(pts)
+        pts.extend(np.asarray(r["points"], np.float32).tolist())
+        strips.append(list(range(b, len(pts))))
+    with open(path, "w") as f:
+        f.write("# vtk DataFile Version 3.0\nmesh-mode sample\nASCII\nDATASET POLYDATA\n")
+        f.write(f"POINTS {len(pts)} float\n")
+        for q in pts:
+            f.write("%.9g %.9g %.9g\n" % tuple(q))
+        f.write(f"TRIANGLE_STRIPS {len(strips)} {sum(len(s) + 1 for s in strips)}\n")
+        for s in strips:
+            f.write(" ".join(str(x) for x in [len(s)] + s) + "\n")
+        f.write(f"CELL_DATA {len(strips)}\nSCALARS id int 1\nLOOKUP_TABLE default\n")
+        f.write("\n".join(str(int(r["id"])) for r in ribbons) + "\n")
+        f.write("VECTORS vel float\n")
+        for r in ribbons:
+            f.write("%.9g %.9g %.9g\n" % tuple(np.asarray(r["velocity"], np.float32)))

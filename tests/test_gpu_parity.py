@@ -562,6 +562,62 @@ def test_real_data_time_mode_frames(hrt, oracle, renderer):
     assert np.array_equal(renderer.rng_states_numpy(), states)
 
 
+def test_mesh_mode_frames_and_cpp_driver(hrt, oracle, gpu_available, tmp_path):
+    """Mesh mode end to end (the reference's second program mode, src/Global/RendererMesh.cu; its launch site :416-419 is the one
+    the boundary replaces): a synthetic data set in the reference's on-disk formats (series, particleN.cache, metadata.cache,
+    config.json) -> io.mesh_mode_scene assembles what commitRendererData does -> per frame the Mesh-mode pose kernel, updateIAS,
+    launch.  Every frame of every file bit-exact against the oracle; then the C++ driver hrt_mesh_render (loader threads, device
+    GAS / IAS builds, the same frame loop) plays the same data and its last frame's bytes are the oracle's."""
+    import importlib
+    import subprocess
+    from pathlib import Path
+    if not gpu_available:
+        pytest.skip("no GPU")
+    io = importlib.import_module("nvidia-optix-ray-tracer_amd.io")
+    w, h, salt = 160, 120, hrt.scenes.SEED_SALT
+    cfg_path = io.write_mesh_mode_sample(tmp_path, n_files=3, n_particles=12, width=w, height=h)
+    mm = io.mesh_mode_scene(cfg_path)
+    cfg, n_extra = mm["config"], mm["n_extra"]
+    assert len(mm["scenes"]) == 3 and mm["frame_counts"] == [3, 6, 6]
+    r = hrt.Renderer(0, 0)
+    try:
+        states = None
+        for k, scene in enumerate(mm["scenes"]):
+            r.load_scene(scene)
+            if states is None:
+                r.set_frame(w, h, salt, linear=True)
+                states = oracle.rng_init(w, h, salt)
+            st = np.zeros((len(mm["velocities"][k]), 12), np.float32)
+            st[:, 7:10] = mm["velocities"][k]
+            for frame in range(mm["frame_counts"][k]):
+                r.pose_instances(st, st, float(mm["durations"][k]), frame, mm["frame_counts"][k], first_instance=n_extra,
+                                 offset=cfg["particle-shift"], scale=cfg["particle-scale"], mesh_mode=True)
+                r.render(1)
+                xf = r.instance_transforms()
+                assert np.array_equal(xf[0], scene["instances"][0]["transform"])
+                for it, m in zip(scene["instances"], xf):
+                    it["transform"] = m.copy()
+                ref = oracle.OracleScene(scene).render(w, h, states, 1)
+                assert np.array_equal(r.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32)), (k, frame)
+                assert ref["rays"] > w * h
+        assert np.array_equal(r.rng_states_numpy(), states)
+        want = np.zeros((h, w, 4), np.uint8)
+        oracle.lib().oracle_to_rgba8(np.ascontiguousarray(ref["color"]).ctypes.data, want.ctypes.data, w, h)
+    finally:
+        r.close()
+    exe = Path(__file__).resolve().parent.parent / "nvidia-optix-ray-tracer_amd" / "lib" / "hrt_mesh_render"
+    assert exe.exists(), "run `make tools`"
+    out = tmp_path / "last.ppm"
+    p = subprocess.run([str(exe), str(cfg_path), str(tmp_path / "bin"), "-1", str(out)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "15 frames 160x120" in p.stdout and "3 files loaded" in p.stdout, p.stdout
+    header = b"P6\n160 120\n255\n"
+    raw = out.read_bytes()
+    assert raw.startswith(header)
+    got = np.frombuffer(raw[len(header):], np.uint8).reshape(h, w, 3)
+    assert np.array_equal(got, want[..., :3])
+
+
 def test_tree_over_instances_parity(hrt, oracle, gpu_available, monkeypatch):
     """HRT_TLAS_INSTANCED=1: hrt_tlas_build makes a top tree over the instances whose leaves are per-instance copies of
     object-space template trees, and the device refit fills in every box and world-space record.  Same bits as the

@@ -315,3 +315,29 @@ def test_time_mode_scene_assembly(io):
     assert all(np.array_equal(it["albedo"], tm["ramp"][i]) for i, it in enumerate(sc["instances"][1:]))
     assert tm["frame_counts"] == [9, 9, 9]                     # size_t(0.01f * float(240 * 4)), RendererTime.cu:427-428
     assert sc["width"] == 1200 and sc["height"] == 800 and sc["camera"]["opengl"] is False
+
+
+def test_mesh_mode_cache_run_through_the_cpp_driver(io, tmp_path):
+    """hrt_mesh_render with "cache": true is RendererMesh::writeCacheFilesAndExit (src/Util/VTKMeshReader.cu:146-215): every VTK
+    file of the series -> particleN.cache, the largest cell count -> metadata.cache, with loader threads; no GPU involved.  The
+    files it writes are what the reader + writer give one by one, and the data set then assembles as a Mesh-mode scene."""
+    import subprocess
+    from pathlib import Path
+    exe = Path(__file__).resolve().parent.parent / "nvidia-optix-ray-tracer_amd" / "lib" / "hrt_mesh_render"
+    if not exe.exists():
+        pytest.skip("run `make tools`")
+    cfg_path = io.write_mesh_mode_sample(tmp_path, n_files=3, n_particles=7, as_vtk=True)
+    p = subprocess.run([str(exe), str(cfg_path), str(tmp_path / "bin")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert io.read_metadata_cache(str(tmp_path / "cache") + "/") == 7
+    for k in range(3):
+        particles, cells = io.read_vtk_mesh_file(tmp_path / "files" / f"mesh_{k}.vtk")
+        assert cells == 7 and all(len(q["vertices"]) == 4 for q in particles)          # strips of 6 points
+        io.write_mesh_cache(str(tmp_path / "expect.cache"), particles)
+        assert (tmp_path / "cache" / f"particle{k}.cache").read_bytes() == (tmp_path / "expect.cache").read_bytes()
+    # flip the config to the render run: the same directory now is a complete Mesh-mode data set
+    import json
+    cfg = json.loads(cfg_path.read_text()); cfg["cache"] = False; cfg_path.write_text(json.dumps(cfg))
+    mm = io.mesh_mode_scene(cfg_path)
+    assert len(mm["scenes"]) == 3 and all(len(s["instances"]) == 1 + 7 for s in mm["scenes"])
+    assert mm["velocities"][0].shape == (7, 3) and mm["frame_counts"] == [3, 6, 6]
