@@ -7,8 +7,10 @@
 // has finished waits, and once enough lanes of the wave wait a regeneration phase (wave-uniform branch) shades them in place
 // with the shared device functions of trav_common.h and starts the next ray in the same lane: the bounce, the next sample's
 // primary ray, or the next pixel.  No ray queues, no hit records, no stage barriers.
-// What is new is the traversal step between two regenerations: trav_lean.h, written for instruction count (the SIMD issues one
-// instruction of any kind per ~2.4 cycles and this kernel is bound by that: DESIGN.md section 4).
+// What is new: the traversal step between two regenerations -- trav_lean.h, written for instruction
+// count: the SIMD issues one instruction of any kind per ~2.4 cycles and this kernel is bound by exactly that --, one scatter body
+// for all programs, an issue priority per loop phase, and tail splitting once the tile is used up (lanes without a pixel take
+// subtrees off the busy lanes' stacks; the pieces of a ray share one best hit in LDS).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -24,7 +26,8 @@ namespace hrt {
 // A wave that is about to fetch -- the bookkeeping that chooses its next node and primitive, the loads themselves -- and a wave
 // in a regeneration go before a wave in its node step, and that before a wave in its primitive test: the fetches go out as
 // early as possible and the waves drift apart instead of queueing for memory together.  C4: 3180 -> 3390 Mrays/s
-// (profiles/r02_sweep_wave_priority.txt; every other assignment of the levels tried is within 3 % of this one, none at all -6 %).
+// (profiles/r02_sweep_wave_priority.txt; every other assignment of the levels tried is within 3 % of this one, no priorities at
+// all 6 % below).
 #ifndef HRT_PRIO_BOOK
 #define HRT_PRIO_BOOK 2      // bookkeeping + address arithmetic + load issue
 #define HRT_PRIO_PRIM 0      // primitive wait + test
@@ -34,7 +37,7 @@ namespace hrt {
 
 template <bool HAS_SPHERES>
 #ifndef HRT_FUSED_WAVES_PER_SIMD
-#define HRT_FUSED_WAVES_PER_SIMD 4      // 125 VGPRs and no spills: 3122 Mrays/s on C4; 5 waves (96 VGPRs, 95 spilled around the shading) 2560
+#define HRT_FUSED_WAVES_PER_SIMD 4      // 128 VGPRs, a dozen kernel constants spilled; 5 waves (96 VGPRs, 95 spilled around the shading): 2560 against 3122 Mrays/s
 #endif
 __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fused(TraverseArgs a) {
     static_assert(kTraverseBlock == 64, "one wave per workgroup: the stacks are per wave");
