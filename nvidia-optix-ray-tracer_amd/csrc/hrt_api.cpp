@@ -149,7 +149,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_FUSED_MAX_DEPTH")) { const int v = std::atoi(e); if (v >= 0 && v <= kFusedMaxDepth) ctx->fused_max_depth = v; }
     if (const char *e = std::getenv("HRT_TAIL_REGEN")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->fused_tail_regen = v; }
     if (const char *e = std::getenv("HRT_LEAF_QUORUM")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->leaf_quorum = v; }
-    if (const char *e = std::getenv("HRT_POSTPONE_PCT")) { const int v = std::atoi(e); if (v >= 0 && v <= 100) ctx->postpone_pct = v; }
+    if (const char *e = std::getenv("HRT_POSTPONE_PCT")) { const int v = std::atoi(e); if (v >= 0 && v <= 100) { ctx->postpone_pct = v; ctx->fused_postpone_pct = v; } }
     if (const char *e = std::getenv("HRT_REFILL_THRESHOLD")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) { ctx->refill_threshold = v; ctx->fused_refill_threshold = v; } }
     *out_ctx = ctx.release();
     return HRT_OK;
@@ -346,6 +346,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         const bool v1 = ctx->fused != 3;            // 3: the slot pipeline k_paths (paths.hip); otherwise a fused kernel: k_fused (fused.hip), 2: round 1's (kernels.hip)
         // k_fused keeps one sibling group per tree level in LDS and has no overflow path: deeper trees take round 1's kernel
         const bool lean = v1 && ctx->fused != 2 && fits_fused_kernel(ctx, *t);
+        if (lean) ta.postpone_pct = ctx->fused_postpone_pct;
         uint32_t blocks_per_cu = lean ? std::min<uint32_t>((uint32_t)ctx->fused_blocks_per_cu, (uint32_t)kFusedBlocksPerCu)
                                : v1 ? (uint32_t)ctx->fused_blocks_per_cu : std::min<uint32_t>((uint32_t)ctx->paths_blocks_per_cu, paths_blocks_that_fit(ctx->paths_slots));
         if (!v1) { ta.refill_threshold = ctx->paths_exchange_threshold; pa.shade_threshold = ctx->paths_shade_threshold; pa.low_water = ctx->paths_low_water; pa.min_batch = ctx->paths_min_batch; }
@@ -651,6 +652,7 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
         pa.trace_rays = rays; pa.trace_tuvp = tuvp; pa.trace_inst = inst; pa.trace_any = any_hit ? 1u : 0u;
         pa.rays_closest = &ctx->d_stats->rays_closest; pa.rays_any = &ctx->d_stats->rays_any;
         const bool lean = ctx->fused != 2 && fits_fused_kernel(ctx, *t);
+        if (lean) ta.postpone_pct = ctx->fused_postpone_pct;
         const uint32_t blocks_per_cu = lean ? std::min<uint32_t>((uint32_t)ctx->fused_blocks_per_cu, (uint32_t)kFusedBlocksPerCu) : (uint32_t)ctx->fused_blocks_per_cu;
         const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * blocks_per_cu, (n_rays + 63u) / 64u);
         Timer tm(ctx, s, HRT_K_PATHS);

@@ -135,11 +135,12 @@ struct HrtContext {
     double kernel_ms[HRT_K_COUNT] = {0}; uint64_t kernel_launches[HRT_K_COUNT] = {0};
     float4 *d_linear = nullptr;
     int refill_threshold = 16;                  // wavefront mode; fused mode: fused_refill_threshold
-    int fused_refill_threshold = 20, fused_fetch_chunk = 16;   // measured optimum of the fused path mode (profiles/r01_sweep_fused_*.txt, r02_sweep_fused_knobs.txt)
+    int fused_refill_threshold = 16, fused_fetch_chunk = 16;   // measured optimum of the fused path mode (profiles/r01_sweep_fused_*.txt, r02_sweep_fused_knobs.txt)
     int traverse_blocks_per_cu = 16;            // one-wave workgroups of the wavefront traverse kernel per CU
     int fused_blocks_per_cu = 20;               // ... of the fused path kernels: round 1's takes 5 waves per SIMD (96 VGPRs), k_fused is capped at kFusedBlocksPerCu
     bool traverse_blocks_auto = true;           // fused mode: fewer of them for small tiles (not when the env knob is set)
-    int postpone_pct = 25;
+    int postpone_pct = 25;                      // wavefront kernels and round 1 path kernel; k_fused: fused_postpone_pct
+    int fused_postpone_pct = 40;                // (r02_sweep_lanes_active.txt: same speed as 25, 65 % of the lanes active instead of 63.4 %)
     int fused_max_depth = kFusedMaxDepth;       // deeper trees take round 1's fused kernel (HRT_FUSED_MAX_DEPTH lowers it: tests)
     int fused_tail_regen = 12;                  // k_fused, tile used up: finished rays that wait before a regeneration (HRT_TAIL_REGEN; 1/8 of C4: 142 ms with 1, 129 with 8..16)
     int leaf_quorum = 1;                        // k_fused: lanes with nothing but leaf work wait until this many of them have gathered (HRT_LEAF_QUORUM)
