@@ -146,6 +146,8 @@ __device__ __forceinline__ void issue_node_loads_off(uint64_t mask, const void *
 //   lanes have nothing else to do (those wait)
 // Returns 1 in the lanes whose ray has nothing left to do.
 __device__ __forceinline__ uint32_t lean_bookkeeping_asm(LeanLane &L, uint2 child, uint2 tri, uint32_t ldsn, uint32_t ldsl, uint32_t pct, uint32_t quorum) {
+    static_assert(kLeafStackLds == 4 && kTraverseBlock == 64 && sizeof(uint2) == 8,
+                  "the sequence below has the leaf stack's depth (4, 'about to fill' = 3) and the stacks' row pitch (64 lanes x 8 bytes = 1 << 9) as literals");
     uint32_t fin, t0, t1, t2, c0, c1;
     uint64_t sv0, sv1, sv2, c2;
     const uint32_t k24 = 0x00ffffffu;
