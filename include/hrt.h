@@ -50,7 +50,9 @@ typedef struct HrtContext HrtContext;
                                     update, launch) then runs without a host synchronisation.  The caller promises what updateIAS requires anyway
                                     (OPTIX_BUILD_OPERATION_UPDATE, RendererImpl.cu:210-242): same BLAS handles, visibility bits and sbtOffsets as
                                     at the build.  A broken promise and a tree that has degraded past the rebuild ratio are both detected on the
-                                    device and acted on at the NEXT update (one frame late), which then takes the synchronous path and rebuilds. */
+                                    device and acted on at the NEXT update (one frame late), which then takes the synchronous path and rebuilds.  The FIRST update
+                                    after a build is synchronous in either mode (one small read-back per build): the reference builds every file's IAS
+                                    with identity transforms and poses it afterwards, so that update is the one that has to rebuild. */
 #define HRT_CTX_FAST_TRACE 0x4u  /* hrt_tlas_build prefers trace speed to build speed: the reference's OPTIX_BUILD_FLAG_PREFER_FAST_TRACE
                                     (its GAS builds, RendererImpl.cu:94,118,144).  The tree is then built by the host's binned-SAH builder
                                     from a host copy of the geometry (1 M triangles: ~0.65 s, ~17 % fewer node visits per ray) instead of by

@@ -528,7 +528,8 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
     if (n != t->n_instances) return fail(ctx, HRT_ERR_INVALID, "update must keep the instance count (%u != %u)", n, t->n_instances);
     if (n && !d_instances) return fail(ctx, HRT_ERR_INVALID, "d_instances is NULL");
     bool force_rebuild = false;
-    if ((ctx->flags & HRT_CTX_ASYNC_UPDATE) != 0 && ctx->refit != 0 && t->n_prims != 0u && n != 0u) {
+    // (the first update after a build takes the synchronous path below, which checks that refit on the spot: see there)
+    if ((ctx->flags & HRT_CTX_ASYNC_UPDATE) != 0 && ctx->refit != 0 && t->n_prims != 0u && n != 0u && t->refits_since_build != 0) {
         // ---- asynchronous update: nothing is read back now.  First the verdict of the previous one (long complete). ----
         if (t->area_pending) {
             HIP_TRY(ctx, hipEventSynchronize(t->area_ready));
@@ -587,6 +588,10 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
         ctx->tlas_refit_ratio = (double)*t->h_area;
         if (ctx->tlas_refit_ratio <= (double)ctx->refit_rebuild_ratio) return HRT_OK;
     }
+    if (std::getenv("HRT_BUILD_VERBOSE"))
+        std::fprintf(stderr, "[hrt] update %llu of this tree rebuilds: %s (area ratio %.3f, %llu refits since the build)\n", (unsigned long long)(t->refits + t->rebuilds),
+                     force_rebuild ? "verdict of the previous asynchronous refit" : "handles / visibility changed or the refit just done degraded the tree", ctx->tlas_refit_ratio,
+                     (unsigned long long)t->refits_since_build);
     HIP_TRY(ctx, hipDeviceSynchronize());                 // launches on other streams may still read the old tree
     // A rebuild in the middle of an animation.  Large scenes: the merged device build (10 ms for 2000 particles / 435 k
     // triangles, 13 ms for a million triangles: profiles/r02_build_bench.txt) -- the better tree.  Small scenes, where the
