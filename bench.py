@@ -125,7 +125,7 @@ def main():
 
     # The scene is static, so trace speed is preferred to build speed, as the reference does for its geometry
     # (OPTIX_BUILD_FLAG_PREFER_FAST_TRACE, RendererImpl.cu:94): HRT_CTX_FAST_TRACE = the host's binned-SAH tree (0.65 s, outside the timed
-    # region).  HRT_BENCH_DEVICE_BUILD=1 times the frame on the device-built PLOC tree instead (13 ms with the upload, 2.5 % more node
+    # region).  HRT_BENCH_DEVICE_BUILD=1 times the frame on the device-built PLOC tree instead (8 ms with the upload, 2.5 % more node
     # visits per ray, ~3.5 % fewer Mrays/s: profiles/r02_build_bench.txt).
     device_build = os.environ.get("HRT_BENCH_DEVICE_BUILD") == "1"
     r = hrt.Renderer(local_rank, hrt.CTX_TIMING | (0 if device_build else hrt.CTX_FAST_TRACE))

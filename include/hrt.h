@@ -56,7 +56,7 @@ typedef struct HrtContext HrtContext;
 #define HRT_CTX_FAST_TRACE 0x4u  /* hrt_tlas_build prefers trace speed to build speed: the reference's OPTIX_BUILD_FLAG_PREFER_FAST_TRACE
                                     (its GAS builds, RendererImpl.cu:94,118,144).  The tree is then built by the host's binned-SAH builder
                                     from a host copy of the geometry (1 M triangles: ~0.65 s, ~17 % fewer node visits per ray) instead of by
-                                    the device build (PLOC, ~20 ms, no geometry leaves the GPU).  Rebuilds inside hrt_tlas_update stay on the
+                                    the device build (PLOC, ~8 ms, no geometry leaves the GPU).  Rebuilds inside hrt_tlas_update stay on the
                                     device (the reference's IAS flags: ALLOW_UPDATE | PREFER_FAST_BUILD, RendererImpl.cu:180). */
 
 /* replaces createContext / destroyContext, src/Global/RendererImpl.cu:6-27 */

@@ -12,6 +12,7 @@ struct BuildCounters {
     uint32_t bmin[3], bmax[3];        // bounds of all valid primitives, same form
     uint32_t n_invalid;               // primitives with non-finite bounds (left out of the tree)
     uint32_t m_next, merges;          // PLOC round: clusters after the round, merges made
+    uint32_t m_cur, node_base;        // PLOC: clusters before the round, index of the next BVH2 node (advanced on the device between rounds)
     uint32_t next_node, next_prim;    // emission cursors
     float total_below;                // sum over BVH8 nodes of the primitives below them (refit quality weights)
 };
@@ -41,6 +42,7 @@ struct GpuBuildInput {
     unsigned char *out_nodes; uint32_t node_stride;      // room for n_prims nodes (worst case)
     unsigned char *out_prims; uint32_t prim_stride;      // room for n_prims records
     float *out_node_ref;                                 // 2 floats per node
+    void *scratch = nullptr; size_t scratch_bytes = 0;   // optional working memory (gpu_build_scratch_bytes): what does not fit is hipMalloc'ed
 };
 
 struct GpuBuildResult {
@@ -51,7 +53,9 @@ struct GpuBuildResult {
 };
 
 GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s);
-hipError_t gpu_blas_bounds(const float *d_src, uint32_t n_prims, uint32_t kind, float *lo, float *hi, hipStream_t s);
+size_t gpu_build_scratch_bytes(uint32_t n_prims);     // working memory of a build of n_prims primitives (an upper estimate)
+constexpr size_t kBoundsScratchBytes = 256;           // ... of gpu_blas_bounds
+hipError_t gpu_blas_bounds(const float *d_src, uint32_t n_prims, uint32_t kind, float *lo, float *hi, void *d_scratch, hipStream_t s);
 void launch_pack_spheres(const float *centers, const float *radii, uint32_t n, float *out, hipStream_t s);
 
 }  // namespace hrt

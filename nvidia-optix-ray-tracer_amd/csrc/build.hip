@@ -155,8 +155,12 @@ __device__ __forceinline__ float merged_half_area(const float4 alo, const float4
 }
 
 // nearest neighbour of every cluster within +-ploc_radius positions (ties: the lower position)
-__global__ __launch_bounds__(256) void k_ploc_nn(GpuBuildArgs a, const uint32_t *__restrict__ cl, uint32_t m) {
+// (the PLOC kernels take the number of clusters from the device counters: the host launches several rounds over an upper bound of
+// it before it reads the counters back)
+__global__ __launch_bounds__(256) void k_ploc_nn(GpuBuildArgs a, const uint32_t *__restrict__ cl) {
     __shared__ float4 s_lo[256 + 2 * kPlocMaxRadius], s_hi[256 + 2 * kPlocMaxRadius];
+    const uint32_t m = a.counters->m_cur;
+    if (blockIdx.x * 256u >= m) return;
     const int kPlocRadius = a.ploc_radius;
     const int base = (int)(blockIdx.x * 256u) - kPlocRadius;
     for (int t = (int)threadIdx.x; t < 256 + 2 * kPlocRadius; t += 256) {
@@ -179,9 +183,10 @@ __global__ __launch_bounds__(256) void k_ploc_nn(GpuBuildArgs a, const uint32_t 
 }
 
 // per position: valid << 32 | starts-a-merge
-__global__ __launch_bounds__(256) void k_ploc_flags(GpuBuildArgs a, uint32_t m) {
+__global__ __launch_bounds__(256) void k_ploc_flags(GpuBuildArgs a, uint32_t m_bound) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= m) return;
+    const uint32_t m = a.counters->m_cur;
+    if (i >= m) { if (i < m_bound) a.flags[i] = 0ull; return; }      // (the scan runs over the bound)
     const uint32_t j = a.nn[i];
     const bool mutual = j != kNone && a.nn[j] == i;
     uint64_t f = 1ull << 32;
@@ -189,9 +194,9 @@ __global__ __launch_bounds__(256) void k_ploc_flags(GpuBuildArgs a, uint32_t m) 
     a.flags[i] = f;
 }
 
-__global__ __launch_bounds__(256) void k_ploc_apply(GpuBuildArgs a, const uint32_t *__restrict__ cl_in, uint32_t *__restrict__ cl_out,
-                                                    uint32_t m, uint32_t node_base) {
+__global__ __launch_bounds__(256) void k_ploc_apply(GpuBuildArgs a, const uint32_t *__restrict__ cl_in, uint32_t *__restrict__ cl_out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t m = a.counters->m_cur, node_base = a.counters->node_base;
     if (i >= m) return;
     const uint64_t f = a.flags[i], sc = a.scan[i];
     if (i == m - 1u) { a.counters->m_next = (uint32_t)((sc + f) >> 32); a.counters->merges = (uint32_t)((sc + f) & 0xffffffffu); }
@@ -206,6 +211,12 @@ __global__ __launch_bounds__(256) void k_ploc_apply(GpuBuildArgs a, const uint32
     a.node_nprims[id] = a.node_nprims[l] + a.node_nprims[r];
     a.node_visit[id] = 0u;
     cl_out[pos] = id;
+}
+
+// between two rounds: what k_ploc_apply counted becomes the next round's input
+__global__ void k_ploc_advance(GpuBuildArgs a) {
+    BuildCounters *c = a.counters;
+    c->node_base += c->merges; c->m_cur = c->m_next;
 }
 
 // ---- optimal collapse: cost tables (bvh8_build.cpp, same recurrences) ----
@@ -458,11 +469,12 @@ void launch_pack_spheres(const float *centers, const float *radii, uint32_t n, f
 }
 
 // object-space bounds of a BLAS's geometry into lo[3] / hi[3] (synchronises the stream for 24 bytes)
-hipError_t gpu_blas_bounds(const float *d_src, uint32_t n_prims, uint32_t kind, float *lo, float *hi, hipStream_t s) {
+hipError_t gpu_blas_bounds(const float *d_src, uint32_t n_prims, uint32_t kind, float *lo, float *hi, void *d_scratch, hipStream_t s) {
+    static_assert(sizeof(BuildCounters) <= kBoundsScratchBytes, "the counters are the only working memory");
     for (int d = 0; d < 3; ++d) { lo[d] = INFINITY; hi[d] = -INFINITY; }
     if (n_prims == 0) return hipSuccess;
-    BuildCounters *c = nullptr;
-    hipError_t e = hipMalloc((void **)&c, sizeof(BuildCounters));
+    BuildCounters *c = reinterpret_cast<BuildCounters *>(d_scratch);
+    hipError_t e = c ? hipSuccess : hipMalloc((void **)&c, sizeof(BuildCounters));
     if (e != hipSuccess) return e;
     BuildCounters h{};
     for (int d = 0; d < 3; ++d) { h.bmin[d] = h.cmin[d] = 0xffffffffu; h.bmax[d] = h.cmax[d] = 0u; }
@@ -470,12 +482,15 @@ hipError_t gpu_blas_bounds(const float *d_src, uint32_t n_prims, uint32_t kind, 
     if (e == hipSuccess) { hipLaunchKernelGGL(k_blas_bounds, dim3(blocks(n_prims, 1024)), dim3(1024), 0, s, d_src, n_prims, kind, c); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipMemcpyAsync(&h, c, sizeof h, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(c);
+    if (!d_scratch) (void)hipFree(c);
     if (e != hipSuccess) return e;
     if (h.bmin[0] <= h.bmax[0] && h.bmax[0] != 0u)
         for (int d = 0; d < 3; ++d) { lo[d] = ord2f(h.bmin[d]); hi[d] = ord2f(h.bmax[d]); }
     return hipSuccess;
 }
+
+// every array of gpu_build_bvh8 below (296 bytes per primitive) + the radix sort's and the scan's temporaries + alignment
+size_t gpu_build_scratch_bytes(uint32_t n_prims) { return (size_t)n_prims * 340u + (1u << 20); }
 
 // The build.  in: instance tables + output buffers sized for the worst case (n nodes, n primitives).  Synchronises `s`
 // a few dozen times for a counter each (PLOC rounds, levels); no geometry crosses the bus.
@@ -488,7 +503,14 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     BuildCounters h{};
     uint32_t nv = 0, m = 0, node_base = 0, root = 0;
     std::vector<void *> owned;
-    auto alloc = [&](void **p, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(p, bytes ? bytes : 16); if (e == hipSuccess) owned.push_back(*p); return e; };
+    size_t scratch_used = 0;
+    // working memory comes out of the caller's arena while it lasts (a small build otherwise spends more time in ~25 hipMalloc /
+    // hipFree pairs, each of which synchronises the device, than in its kernels)
+    auto alloc = [&](void **p, size_t bytes) -> hipError_t {
+        bytes = (std::max<size_t>(bytes, 16) + 255u) & ~(size_t)255u;
+        if (in.scratch && scratch_used + bytes <= in.scratch_bytes) { *p = static_cast<char *>(in.scratch) + scratch_used; scratch_used += bytes; return hipSuccess; }
+        hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) owned.push_back(*p); return e;
+    };
 
     a.n = n; a.n_inst = in.n_inst; a.inst_first = in.d_inst_first; a.inst_kind = in.d_inst_kind; a.inst_src = in.d_inst_src;
     a.inst_xf = in.d_inst_xf; a.inst_identity = in.d_inst_identity;
@@ -533,19 +555,29 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     m = nv; node_base = nv;
     {
         uint32_t *cl_in = a.cl_a, *cl_out = cl_b;
+        h.m_cur = m; h.node_base = node_base; h.m_next = m; h.merges = 0u;
+        B_TRY(hipMemcpyAsync(a.counters, &h, sizeof h, hipMemcpyHostToDevice, s));
+        // A round merges at least one pair, typically 40 % of the clusters.  The host launches kRoundsPerBatch rounds over the
+        // cluster count it last read (a round past the end of the build copies the one cluster left) and only then synchronises:
+        // 6 read-backs for a million primitives instead of 44
+        constexpr int kRoundsPerBatch = 8;
         while (m > 1u) {
-            hipLaunchKernelGGL(k_ploc_nn, dim3(blocks(m, 256)), dim3(256), 0, s, a, cl_in, m);
-            hipLaunchKernelGGL(k_ploc_flags, dim3(blocks(m, 256)), dim3(256), 0, s, a, m);
-            B_TRY(hipcub::DeviceScan::ExclusiveSum(temp, scan_bytes, a.flags, a.scan, (int)m, s));
-            hipLaunchKernelGGL(k_ploc_apply, dim3(blocks(m, 256)), dim3(256), 0, s, a, cl_in, cl_out, m, node_base);
+            for (int k = 0; k < kRoundsPerBatch; ++k) {
+                hipLaunchKernelGGL(k_ploc_nn, dim3(blocks(m, 256)), dim3(256), 0, s, a, cl_in);
+                hipLaunchKernelGGL(k_ploc_flags, dim3(blocks(m, 256)), dim3(256), 0, s, a, m);
+                B_TRY(hipcub::DeviceScan::ExclusiveSum(temp, scan_bytes, a.flags, a.scan, (int)m, s));
+                hipLaunchKernelGGL(k_ploc_apply, dim3(blocks(m, 256)), dim3(256), 0, s, a, cl_in, cl_out);
+                hipLaunchKernelGGL(k_ploc_advance, dim3(1), dim3(1), 0, s, a);
+                std::swap(cl_in, cl_out);
+                ++res.ploc_rounds;
+            }
             B_TRY(hipGetLastError());
             B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
             B_TRY(hipStreamSynchronize(s));
-            if (h.m_next >= m || h.merges == 0u) { res.error = hipErrorUnknown; res.where = "PLOC made no progress"; goto done; }
-            node_base += h.merges; m = h.m_next;
-            std::swap(cl_in, cl_out);
-            ++res.ploc_rounds;
+            if (h.m_cur >= m) { res.error = hipErrorUnknown; res.where = "PLOC made no progress"; goto done; }
+            m = h.m_cur;
         }
+        node_base = h.node_base;
         B_TRY(hipMemcpyAsync(&root, cl_in, sizeof root, hipMemcpyDeviceToHost, s));
         B_TRY(hipStreamSynchronize(s));
     }

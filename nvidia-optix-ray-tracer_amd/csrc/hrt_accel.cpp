@@ -25,6 +25,38 @@ void invert_affine(const float *m, float *o) {
     o[8] = (float)n20; o[9] = (float)n21; o[10] = (float)n22; o[11] = (float)(-(n20 * tx + n21 * ty + n22 * tz));
 }
 
+// Working memory of the device builds.  A build takes the smallest free arena that is large enough (or allocates one, a quarter
+// larger than asked for) and gives it back when it is done; the context keeps up to eight of them, so loader threads building
+// side by side each find one.  Without this a 1500-triangle rebuild spent most of its 2 ms in hipMalloc / hipFree.
+ScratchArena scratch_acquire(HrtContext *ctx, size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lk(ctx->scratch_mu);
+        int best = -1;
+        for (int i = 0; i < (int)ctx->scratch_free.size(); ++i)
+            if (ctx->scratch_free[i].bytes >= bytes && (best < 0 || ctx->scratch_free[i].bytes < ctx->scratch_free[best].bytes)) best = i;
+        if (best >= 0) { const ScratchArena a = ctx->scratch_free[best]; ctx->scratch_free.erase(ctx->scratch_free.begin() + best); return a; }
+    }
+    ScratchArena a;
+    a.bytes = bytes + bytes / 4 + 4096;
+    if (hipMalloc(&a.p, a.bytes) != hipSuccess) { (void)hipGetLastError(); a = ScratchArena(); }
+    return a;
+}
+void scratch_release(HrtContext *ctx, ScratchArena a) {
+    if (!a.p) return;
+    ScratchArena drop;
+    {
+        std::lock_guard<std::mutex> lk(ctx->scratch_mu);
+        ctx->scratch_free.push_back(a);
+        if (ctx->scratch_free.size() > 8) {                // keep the large ones
+            size_t smallest = 0;
+            for (size_t i = 1; i < ctx->scratch_free.size(); ++i) if (ctx->scratch_free[i].bytes < ctx->scratch_free[smallest].bytes) smallest = i;
+            drop = ctx->scratch_free[smallest];
+            ctx->scratch_free.erase(ctx->scratch_free.begin() + (long)smallest);
+        }
+    }
+    if (drop.p) (void)hipFree(drop.p);
+}
+
 void free_tlas_device(Tlas &t) {
     if (t.d_nodes) (void)hipFree(t.d_nodes);
     if (t.d_prims) (void)hipFree(t.d_prims);
@@ -157,7 +189,10 @@ int ensure_template(HrtContext *ctx, Blas &b, hipStream_t s) {
     in.n_prims = n; in.n_inst = 1; in.d_inst_first = tb.first; in.d_inst_kind = tb.kind; in.d_inst_src = tb.src; in.d_inst_xf = tb.xf; in.d_inst_identity = tb.ident;
     in.max_leaf_prims = kMaxLeafPrims; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius;
     in.out_nodes = d_nodes; in.node_stride = sizeof(Bvh8Node); in.out_prims = d_prims; in.prim_stride = sizeof(PrimRecord); in.out_node_ref = d_ref;
-    const GpuBuildResult r = gpu_build_bvh8(in, s);
+    const ScratchArena arena = scratch_acquire(ctx, gpu_build_scratch_bytes(n));
+    in.scratch = arena.p; in.scratch_bytes = arena.bytes;
+    const GpuBuildResult r = gpu_build_bvh8(in, s);      // (synchronises the stream before it returns)
+    scratch_release(ctx, arena);
     if (r.error != hipSuccess) return fail(ctx, HRT_ERR_HIP, "device build of a BLAS template failed: %s (%s)", hipGetErrorString(r.error), r.where);
     if (r.n_prims == 0) { build_bvh8({}, b.tmpl, 1); b.tmpl_built = true; return HRT_OK; }
     b.tmpl.nodes.resize(r.n_nodes); b.tmpl.prims.resize(r.n_prims);
@@ -333,7 +368,10 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         in.d_inst_xf = t.d_inst_xf; in.d_inst_identity = t.d_inst_identity;
         in.max_leaf_prims = kMaxLeafPrims; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius;
         in.out_nodes = ra.nodes; in.node_stride = t.node_stride; in.out_prims = ra.prims; in.prim_stride = t.prim_stride; in.out_node_ref = t.d_node_ref;
-        const GpuBuildResult r = gpu_build_bvh8(in, s);
+        const ScratchArena arena = scratch_acquire(ctx, gpu_build_scratch_bytes(in.n_prims));
+        in.scratch = arena.p; in.scratch_bytes = arena.bytes;
+        const GpuBuildResult r = gpu_build_bvh8(in, s);      // (synchronises the stream before it returns)
+        scratch_release(ctx, arena);
         if (r.error != hipSuccess) return fail(ctx, r.error == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, "device build failed: %s (%s)", hipGetErrorString(r.error), r.where);
         t.bvh = Bvh8();
         if (r.n_prims == 0u) {
@@ -466,7 +504,10 @@ int hrt_blas_build_triangles(HrtContext *ctx, const HrtFloat3 *d_vertices, uint3
         const size_t bytes = sizeof(float) * 3 * (size_t)n_vertices;
         HIP_TRY(ctx, hipMalloc((void **)&b->d_verts, bytes));
         HIP_TRY(ctx, hipMemcpyAsync(b->d_verts, d_vertices, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-        HIP_TRY(ctx, gpu_blas_bounds(b->d_verts, b->n_prims, kPrimKindTriangle, b->lo, b->hi, (hipStream_t)stream));
+        const ScratchArena arena = scratch_acquire(ctx, kBoundsScratchBytes);
+        const hipError_t e = gpu_blas_bounds(b->d_verts, b->n_prims, kPrimKindTriangle, b->lo, b->hi, arena.p, (hipStream_t)stream);
+        scratch_release(ctx, arena);
+        HIP_TRY(ctx, e);
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const uint64_t h = ctx->next_handle++;
@@ -485,7 +526,10 @@ int hrt_blas_build_spheres(HrtContext *ctx, const HrtFloat3 *d_centers, const fl
         HIP_TRY(ctx, hipMalloc((void **)&b->d_verts, sizeof(float) * 4 * (size_t)n));        // {cx, cy, cz, r} per sphere
         launch_pack_spheres(reinterpret_cast<const float *>(d_centers), d_radii, n, b->d_verts, (hipStream_t)stream);
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, gpu_blas_bounds(b->d_verts, n, kPrimKindSphere, b->lo, b->hi, (hipStream_t)stream));
+        const ScratchArena arena = scratch_acquire(ctx, kBoundsScratchBytes);
+        const hipError_t e = gpu_blas_bounds(b->d_verts, n, kPrimKindSphere, b->lo, b->hi, arena.p, (hipStream_t)stream);
+        scratch_release(ctx, arena);
+        HIP_TRY(ctx, e);
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const uint64_t h = ctx->next_handle++;
@@ -593,8 +637,8 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
                      force_rebuild ? "verdict of the previous asynchronous refit" : "handles / visibility changed or the refit just done degraded the tree", ctx->tlas_refit_ratio,
                      (unsigned long long)t->refits_since_build);
     HIP_TRY(ctx, hipDeviceSynchronize());                 // launches on other streams may still read the old tree
-    // A rebuild in the middle of an animation.  Large scenes: the merged device build (10 ms for 2000 particles / 435 k
-    // triangles, 13 ms for a million triangles: profiles/r02_build_bench.txt) -- the better tree.  Small scenes, where the
+    // A rebuild in the middle of an animation.  Large scenes: the merged device build (6.6 ms for 2000 particles / 435 k
+    // triangles, 7.9 ms for a million triangles: profiles/r02_build_bench.txt) -- the better tree.  Small scenes, where the
     // device build's fixed cost (a stream synchronisation per PLOC round and per level, ~2 ms) would dominate, and host-build
     // contexts: the tree over instances, whose top tree the host assembles in well under a millisecond.
     uint64_t total = 0;

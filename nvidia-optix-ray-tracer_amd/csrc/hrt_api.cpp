@@ -176,6 +176,7 @@ int hrt_ctx_destroy(HrtContext *ctx) {
     }
     void *ptrs[] = {w.accum, w.slice_cost, w.slice_order, w.slots, w.rows, ctx->d_jump, ctx->d_stats, ctx->d_hitgroups, ctx->d_inst_program};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (const ScratchArena &a : ctx->scratch_free) (void)hipFree(a.p);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->sub_done) (void)hipEventDestroy(e);
     for (hipStream_t st : ctx->sub_streams) (void)hipStreamDestroy(st);

@@ -100,6 +100,9 @@ struct Workspace {
 
 struct TimedSpan { int kind; hipEvent_t a, b; };
 
+// working memory of the device builds, kept by the context between builds (a few arenas: builds may run on several loader threads)
+struct ScratchArena { void *p = nullptr; size_t bytes = 0; };
+
 }  // namespace hrt
 
 using namespace hrt;
@@ -113,6 +116,7 @@ struct HrtContext {
     std::unordered_map<uint64_t, std::shared_ptr<hrt::Blas>> blas;
     std::unordered_map<uint64_t, std::unique_ptr<hrt::Tlas>> tlas;
     uint64_t next_handle = 0x1000;
+    std::mutex scratch_mu; std::vector<hrt::ScratchArena> scratch_free;      // scratch_acquire / scratch_release (hrt_accel.cpp)
     // materials
     std::vector<HrtSbtRecord> records;
     HrtMissParams miss{{0.7f, 0.8f, 0.9f}};      // reference default, src/Global/RendererMesh.cu:262
@@ -203,6 +207,8 @@ struct Timer {
 void drain_spans(HrtContext *ctx);
 
 // hrt_accel.cpp
+hrt::ScratchArena scratch_acquire(HrtContext *ctx, size_t bytes);      // {nullptr, 0} when the device is out of memory
+void scratch_release(HrtContext *ctx, hrt::ScratchArena a);
 void free_tlas_device(Tlas &t);
 void free_tlas_host(Tlas &t);
 
