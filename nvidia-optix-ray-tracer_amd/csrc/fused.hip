@@ -211,14 +211,13 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
                 //      the lane that owns the ray: a piece publishes every improvement there (canonical order: the result does not
                 //      depend on who found what, or when) and adopts what the others found closer, so every piece culls with the
                 //      ray's best hit so far. ----
-                for (int round = 0; kTail && round < a.tail_split; ++round) {      // (tail_split: donations a busy lane may make per iteration)
+                if (kTail && a.tail_split) {          // (one donation per busy lane and iteration: more rounds of this change nothing, r02_sweep_tile_tail.txt)
                     const bool is_free = !alive && !waiting && !have_pixel && !shared;
                     const uint64_t free_m = __ballot(is_free);
                     const uint64_t donors = __ballot(alive && L.nsp > L.base);
                     const uint32_t n_free = (uint32_t)__popcll(free_m), n_don = (uint32_t)__popcll(donors);
                     const uint32_t n_pairs = n_free < n_don ? n_free : n_don;
-                    if (n_pairs == 0u) break;
-                    {
+                    if (n_pairs) {
                         const uint32_t drank = lane_prefix(donors), irank = lane_prefix(free_m);
                         const bool is_donor = alive && L.nsp > L.base && drank < n_pairs;
                         const bool is_recv = is_free && irank < n_pairs;
