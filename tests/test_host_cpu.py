@@ -157,3 +157,25 @@ def test_hand_issued_loads_are_not_touched_before_their_wait():
     r = subprocess.run([sys.executable, str(root / "tools" / "audit_asm_loads.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "0 hazardous instructions" in r.stdout and "hazardous instructions" in r.stdout
+
+
+def test_path_kernel_hot_loop_keeps_its_instruction_budget():
+    """k_fused is bound by instruction issue: its traversal loop is 470 instructions for triangles-only
+    scenes -- 171 of the single-pipe kind -- with no scratch access, at 4 waves per SIMD (<= 128 VGPRs).  tools/loop_stats.py
+    compiles fused.hip with the Makefile's flags and counts; a compiler, flag or source change that fattens the loop, spills inside
+    it or costs a wave of occupancy fails here, before anybody has to find it in a benchmark."""
+    import re
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "tools"))
+    import loop_stats
+    found = {name: (cs, ops) for name, cs, ops in loop_stats.loops("nvidia-optix-ray-tracer_amd/csrc/fused.hip", "_ZN3hrt7k_fused")}
+    tri = [v for k, v in found.items() if "ILb0E" in k]
+    assert len(found) == 2 and len(tri) == 1, sorted(found)
+    cs, ops = tri[0]
+    assert sum(cs.values()) <= 480, dict(cs)
+    assert cs["valu_complex"] <= 175 and cs["salu"] <= 110, dict(cs)
+    assert not any(op.startswith("scratch_") or op.startswith("buffer_") for op in ops), sorted(ops)
+    text = Path("/tmp/hrt_loops_fused.s").read_text()
+    assert all(int(v) <= 128 for v in re.findall(r"\.vgpr_count:\s+(\d+)", text))
