@@ -57,6 +57,7 @@ $(LIBDIR)/bvh8_build.o: $(CSRC)/bvh8_build.cpp $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.
 
 $(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/paths.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -pthread
+	@cat $(sort $(wildcard $(CSRC)/*.hip $(CSRC)/*.h $(CSRC)/*.hpp $(CSRC)/*.cpp include/*.h)) | sha256sum | cut -c1-16 > $(LIBDIR)/BUILD_ID
 
 # host-side readers of the reference's input formats (include/hrt_io.h): plain C++, no GPU
 $(LIBDIR)/libhrt_io.so: $(CSRC)/host/scene_io.cpp $(CSRC)/host/json_min.hpp include/hrt_io.h include/hrt_params.h
@@ -66,10 +67,19 @@ $(LIBDIR)/libhrt_io.so: $(CSRC)/host/scene_io.cpp $(CSRC)/host/json_min.hpp incl
 oracle:
 	$(MAKE) -C oracle
 
-tools: $(LIBDIR)/hrt_render $(LIBDIR)/hrt_time_render $(LIBDIR)/hrt_mesh_render
+# hrt_render is the multi-GPU host (csrc/host/multi_gpu.hpp calls RCCL directly): built only where RCCL is installed, so that
+# the default target works on a single-GPU host without it
+ROCM_PATH ?= /opt/rocm
+ifneq ($(wildcard $(ROCM_PATH)/include/rccl/rccl.h),)
+MULTI_GPU_TOOL := $(LIBDIR)/hrt_render
+else
+MULTI_GPU_TOOL :=
+$(info RCCL not found under $(ROCM_PATH): skipping hrt_render (the multi-GPU driver))
+endif
+tools: $(MULTI_GPU_TOOL) $(LIBDIR)/hrt_time_render $(LIBDIR)/hrt_mesh_render
 
 $(LIBDIR)/hrt_render: $(CSRC)/host/hrt_render.cpp $(CSRC)/host/renderer_host.hpp $(CSRC)/host/multi_gpu.hpp $(LIBDIR)/libhrt.so
-	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Iinclude -I$(CSRC) -I/opt/rocm/include -o $@ $< -L$(LIBDIR) -lhrt -L/opt/rocm/lib -lrccl -pthread -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Iinclude -I$(CSRC) -I$(ROCM_PATH)/include -o $@ $< -L$(LIBDIR) -lhrt -L$(ROCM_PATH)/lib -lrccl -pthread -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM_PATH)/lib
 
 $(LIBDIR)/hrt_time_render: $(CSRC)/host/hrt_time_render.cpp $(CSRC)/host/renderer_host.hpp $(LIBDIR)/libhrt.so $(LIBDIR)/libhrt_io.so
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Iinclude -I$(CSRC) -o $@ $< -L$(LIBDIR) -lhrt -lhrt_io -Wl,-rpath,'$$ORIGIN'

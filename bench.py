@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- Mrays/s of the render launch on the synthetic 1M-triangle scene at 1920x1080.
 
-Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N > 1 under torch.distributed.run)
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process a launcher: it starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child before anything touches the GPU
+(it never imports torch) and exits with the child's code.  Under torch.distributed.run (the driver's own
+N > 1 launch) the process is a worker and WORLD_SIZE must equal --gpus.
 One "step" = one hrt_render_launch of the whole frame at the configured spp (BASELINE config C4:
 1M random triangles, 1920x1080, 256 spp), scene/BVH/RNG states already resident in HBM.  For N > 1
 the frame is split into interleaved 8-row stripes (one tile per GPU, BVH replicated) and each step
@@ -38,8 +42,41 @@ def parse():
     ap.add_argument("--config", default="C4", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--spp", type=int, default=0, help="override the config's samples per pixel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-builder", action="store_true", help="skip the short run on the other builder's tree (config.alt_builder)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
+
+
+def launcher_argv(gpus, env, argv, port=None):
+    """The launcher decision, as a pure function (tests/test_bench_cpu.py): None when this process must do the work itself
+    (one GPU, or already a worker of torch.distributed.run), else the command line of the N-rank child."""
+    if gpus <= 1 or "WORLD_SIZE" in env or "RANK" in env or "LOCAL_RANK" in env:
+        return None
+    if port is None:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+
+
+def check_world(gpus, world):
+    """A worker whose WORLD_SIZE disagrees with --gpus would print a line labelled with the wrong GPU count."""
+    if world != gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} but WORLD_SIZE={world}: pass the same number to both (a bare "
+                         f"`python bench.py --gpus N` starts its N ranks by itself)")
+
+
+def build_id():
+    """What make wrote beside libhrt.so: a hash of the kernel sources the library was built from."""
+    try:
+        return (ROOT / "nvidia-optix-ray-tracer_amd" / "lib" / "BUILD_ID").read_text().strip()
+    except OSError:
+        return None
+
+
+ISSUE_FLOOR_CYCLES = 2.4        # SIMD cycles per instruction with >= 2 waves issuing side by side (profiles/r02_valu_pipes_microbench.txt)
 
 
 def cpu_baseline(hrt, scene, target_seconds, renderer=None):
@@ -91,10 +128,18 @@ def cpu_baseline(hrt, scene, target_seconds, renderer=None):
 
 def main():
     args = parse()
+    child = launcher_argv(args.gpus, os.environ, sys.argv[1:])
+    if child is not None:                       # launcher: nothing in this process has touched (or will touch) the GPU
+        import subprocess
+        rc = subprocess.call(child)
+        if rc != 0:
+            print(f"bench.py: the {args.gpus}-rank run failed with exit code {rc}", file=sys.stderr)
+        sys.exit(rc)
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    check_world(args.gpus, world)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal knobs for a box with fewer GPUs than ranks (never set by the driver): HRT_BENCH_BACKEND=gloo lets several
@@ -162,7 +207,7 @@ def main():
     # max over ranks of the time, sum over ranks of the rays
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     rays = torch.tensor([float(st.rays), float(st.rays_closest), st.kernel_ms[hrt.K_TRAVERSE],
-                         float(st.kernel_launches[hrt.K_TRAVERSE])], dtype=torch.float64, device=dev)
+                         float(st.kernel_launches[hrt.K_TRAVERSE]), 1.0], dtype=torch.float64, device=dev)   # [4]: one per rank
     if world > 1:
         if backend != "nccl":
             tt, rays = tt.cpu(), rays.cpu()
@@ -170,6 +215,9 @@ def main():
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     elapsed = float(tt.item())
     total_rays = float(rays[0].item())
+    ranks_seen = int(round(float(rays[4].item())))
+    if ranks_seen != args.gpus:
+        raise SystemExit(f"bench.py: {ranks_seen} ranks took part in the all_reduce, --gpus says {args.gpus}")
 
     # ---- per-ray node / primitive counts (canonical walk order): one extra untimed pass ----
     r.set_flags(hrt.CTX_COUNT)
@@ -205,38 +253,50 @@ def main():
         rays_per_launch = st.rays / trav_launches
         bytes_per_launch = (b_closest * st.rays_closest + b_any * st.rays_any) / trav_launches
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        # memory-side traffic and the VALU view come from the PMC passes committed for THIS workload (tools/profile_final.sh: separate
-        # --pmc runs, which cannot share a process with the timed region); the line names the files and the build they were taken on
-        traffic = traffic_source = valu = None
+        # memory-side traffic and the instruction-issue view come from the PMC passes committed for THIS workload (tools/profile_final.sh:
+        # separate --pmc runs, which cannot share a process with the timed region).  They are only quoted when the file was taken on
+        # the build that is running (lib/BUILD_ID = hash of the kernel sources); otherwise they are null and marked stale.
+        traffic = traffic_source = issue = None
+        running = build_id()
         if args.config == "C4" and world == 1 and fused and args.spp == 0:
-            for tf in sorted((ROOT / "profiles").glob("r*_traverse_traffic.json"), reverse=True)[:1]:
-                try:
-                    d = json.loads(tf.read_text())
-                    traffic = d.get("fabric_bytes_per_launch")
-                    traffic_source = {"file": f"profiles/{tf.name}", "build": d.get("provenance", {}).get("build"),
-                                      "what": "bytes the L2s requested from the fabric per launch (read + write); Infinity-Cache hits included: an upper bound on HBM bytes"}
-                except Exception:
-                    traffic = None
-            for pf in sorted((ROOT / "profiles").glob("r*_pmc_fused_kernel.json"), reverse=True)[:1]:
-                try:
-                    d = json.loads(pf.read_text())
-                    if "valu" in d:
-                        valu = {"issue_slot_frac": round(d["valu"]["issue_slot_frac"], 4), "lanes_active_frac": round(d["valu"]["lanes_active_frac"], 4),
-                                "wave_time_split": {k: round(v, 4) for k, v in (d["valu"].get("wave_time_split") or {}).items()},
-                                "file": f"profiles/{pf.name}", "build": d.get("provenance", {}).get("build"),
-                                "what": "SQ_INSTS_VALU x 4 cycles / (kernel cycles x 1024 SIMDs); SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)"}
-                        c = d.get("counters_mean_per_launch", {})
-                        if c.get("SQ_INSTS_VALU") and d["valu"].get("kernel_cycles"):
-                            n_inst = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"))
-                            valu["instructions_per_launch"] = n_inst
-                            valu["simd_cycles_per_instruction"] = round(d["valu"]["kernel_cycles"] * 1024.0 / n_inst, 3)
-                except Exception:
-                    valu = None
+            def newest(pattern):
+                for f in sorted((ROOT / "profiles").glob(pattern), reverse=True)[:1]:
+                    try:
+                        d = json.loads(f.read_text())
+                    except Exception:
+                        return None, None, None
+                    b = d.get("provenance", {}).get("build")
+                    return d, f"profiles/{f.name}", b
+                return None, None, None
+            d, name, b = newest("r*_traverse_traffic.json")
+            if d is not None:
+                stale = running is None or b != running
+                traffic = None if stale else d.get("fabric_bytes_per_launch")
+                traffic_source = {"file": name, "build": b, "running_build": running, "stale": stale, "tcc_hit_rate": None if stale else d.get("tcc_hit_rate"),
+                                  "what": "bytes the L2s requested from the fabric per launch (read + write); Infinity-Cache hits included: an upper bound on HBM bytes"}
+            d, name, b = newest("r*_pmc_fused_kernel.json")
+            if d is not None and "valu" in d:
+                stale = running is None or b != running
+                issue = {"file": name, "build": b, "running_build": running, "stale": stale}
+                c = d.get("counters_mean_per_launch", {})
+                cyc = d["valu"].get("kernel_cycles")
+                n_inst = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"))
+                if not stale and cyc and n_inst:
+                    cpi = cyc * 1024.0 / n_inst
+                    issue.update({
+                        "instructions_per_launch": n_inst, "simd_cycles_per_instruction": round(cpi, 3),
+                        "floor_cycles_per_instruction": ISSUE_FLOOR_CYCLES,
+                        "issue_frac": round(ISSUE_FLOOR_CYCLES / cpi, 4),
+                        "lanes_active_frac": round(d["valu"]["lanes_active_frac"], 4),
+                        "useful_lane_frac": round(ISSUE_FLOOR_CYCLES / cpi * d["valu"]["lanes_active_frac"], 4),
+                        "wave_time_split": {k: round(v, 4) for k, v in (d["valu"].get("wave_time_split") or {}).items()},
+                        "what": "issue_frac = 2.4 SIMD cycles per instruction (measured floor, any kind) / (kernel cycles x 1024 SIMDs / instructions); "
+                                "lanes_active = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); useful_lane_frac = their product"})
         out = {
             "metric": "Mrays/s at 1920x1080, 1M-tri scene",
             "value": round(total_rays / elapsed / 1e6, 3),
             "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
             "higher_is_better": True,
             "scaling": "strong",
@@ -248,21 +308,44 @@ def main():
                        "rays_per_step": int(total_rays / max(args.steps, 1)), "rays_per_path": round(st.rays / max(st.paths, 1), 4),
                        "bvh_nodes": int(st.bvh_nodes), "bvh_bytes": int(st.bvh_bytes), "bvh_build_s": round(build_s, 3),
                        "bvh_builder": "device PLOC (build.hip)" if device_build else "host binned SAH (HRT_CTX_FAST_TRACE)"},
-            # `achieved` / `frac` are the ALGORITHMIC bytes (80 B per node visit + 48 B per primitive test) over the launch
-            # time: the contract's figure.  They are NOT what limits the kernel: the bytes are served by L1 / L2 / Infinity Cache
-            # (`traffic` = what reached the fabric, `measured_frac` = that over launch time over the HBM peak), and the kernel is
-            # bound by instruction issue -- one instruction of any kind per ~2.7 SIMD cycles -- at ~60 % of the lanes active (`limited_by`,
-            # `valu`; DESIGN.md section 4.1 has the model and the experiments).
-            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+            # What bounds the kernel is INSTRUCTION ISSUE (`bound`, `issue_frac`, `useful_lane_frac`: DESIGN.md section 4.1), not memory:
+            # the tree of this scene is resident in L2 / Infinity Cache.  `achieved` / `peak` / `frac` stay the contract's figure
+            # (ALGORITHMIC bytes -- 80 B per node visit + 48 B per primitive test -- over the launch time over the HBM
+            # peak; repeated as `algorithmic_frac`), `traffic` / `measured_frac` are what reached the fabric.
+            "roofline": {"bound": "instruction-issue", "kernel": kernel_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "issue_frac": issue.get("issue_frac") if issue else None,
+                         "useful_lane_frac": issue.get("useful_lane_frac") if issue else None,
+                         "issue": issue,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "measured_frac": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_ms > 0 else None,
-                         "limited_by": "instruction-issue", "valu": valu, "algorithmic_gbps": round(achieved, 2),
+                         "note": "frac is algorithmic bytes over the HBM peak, served mostly by L2 / Infinity Cache (tree resident); the kernel is issue-bound",
                          "bytes_per_ray": round(b_closest, 1), "nodes_per_ray": round(nodes_per_ray, 3),
                          "prims_per_ray": round(prims_per_ray, 3), "bytes_per_any_hit_ray": round(b_any, 1),
                          "bytes_per_launch": round(bytes_per_launch, 0), "avg_launch_ms": round(avg_launch_ms, 4),
                          "rays_per_launch": round(rays_per_launch, 1), "launches": trav_launches},
             "kernel_ms": {hrt.KERNEL_NAMES[k]: round(st.kernel_ms[k], 3) for k in range(hrt.K_COUNT)},
         }
+        if world == 1 and not args.no_alt_builder:
+            # the same frame on the tree of the OTHER builder (a second context; a few steps are enough for a rate)
+            alt = hrt.Renderer(local_rank, hrt.CTX_TIMING | (hrt.CTX_FAST_TRACE if device_build else 0))
+            t0 = time.perf_counter()
+            alt.load_scene(scene)
+            alt_build_s = time.perf_counter() - t0
+            alt.set_frame(W, H, hrt.scenes.SEED_SALT, aov=False)
+            alt.render(spp, sync=True)
+            alt.reset_stats()
+            alt_steps = max(1, min(args.steps, 3))
+            t0 = time.perf_counter()
+            for _ in range(alt_steps):
+                alt.render(spp, sync=False)
+            torch.cuda.synchronize(dev)
+            alt_dt = time.perf_counter() - t0
+            sa = alt.stats()
+            out["config"]["alt_builder"] = {"bvh_builder": "host binned SAH (HRT_CTX_FAST_TRACE)" if device_build else "device PLOC (build.hip)",
+                                            "value": round(sa.rays / alt_dt / 1e6, 3), "unit": "Mrays/s", "steps": alt_steps,
+                                            "bvh_nodes": int(sa.bvh_nodes), "bvh_build_s": round(alt_build_s, 3)}
+            alt.close()
         if not args.no_cpu_baseline and world == 1:             # the CPU leg is timed at N = 1 only
             r.set_flags(0)                                      # production kernels for the parity render
             out["cpu_baseline"], out["parity"] = cpu_baseline(hrt, scene, args.cpu_seconds, r)

@@ -50,12 +50,13 @@ typedef struct HrtContext HrtContext;
                                     update, launch) then runs without a host synchronisation.  The caller promises what updateIAS requires anyway
                                     (OPTIX_BUILD_OPERATION_UPDATE, RendererImpl.cu:210-242): same BLAS handles, visibility bits and sbtOffsets as
                                     at the build.  A broken promise and a tree that has degraded past the rebuild ratio are both detected on the
-                                    device and acted on at the NEXT update (one frame late), which then takes the synchronous path and rebuilds.  The FIRST update
+                                    device and acted on at the NEXT update (one frame late), which then takes the synchronous path: a changed handle /
+                                    visibility bit or a degraded tree rebuilds, a changed sbtOffset refreshes the material tables.  The FIRST update
                                     after a build is synchronous in either mode (one small read-back per build): the reference builds every file's IAS
                                     with identity transforms and poses it afterwards, so that update is the one that has to rebuild. */
 #define HRT_CTX_FAST_TRACE 0x4u  /* hrt_tlas_build prefers trace speed to build speed: the reference's OPTIX_BUILD_FLAG_PREFER_FAST_TRACE
                                     (its GAS builds, RendererImpl.cu:94,118,144).  The tree is then built by the host's binned-SAH builder
-                                    from a host copy of the geometry (1 M triangles: ~0.65 s, ~17 % fewer node visits per ray) instead of by
+                                    from a host copy of the geometry (1 M triangles: ~0.65 s, ~2 % fewer node visits per ray) instead of by
                                     the device build (PLOC, ~8 ms, no geometry leaves the GPU).  Rebuilds inside hrt_tlas_update stay on the
                                     device (the reference's IAS flags: ALLOW_UPDATE | PREFER_FAST_BUILD, RendererImpl.cu:180). */
 
@@ -79,7 +80,8 @@ int  hrt_blas_destroy(HrtContext *ctx, HrtTraversable blas);
 
 /* replaces buildIAS / updateIAS, src/Global/RendererImpl.cu:174-242.  d_instances lives in
  * device memory (reference: cudaMemcpy H2D then build, src/Global/RendererMesh.cu:151-160).
- * hrt_tlas_build flattens the instances into one world-space BVH8 (host SAH build).  hrt_tlas_update takes
+ * hrt_tlas_build flattens the instances into one world-space BVH8, built on the device (Morton sort, PLOC, optimal
+ * 8-wide collapse: csrc/build.hip; the host's binned-SAH builder only under HRT_CTX_FAST_TRACE).  hrt_tlas_update takes
  * the same number of instances: when only transforms (and sbtOffsets) changed, the tree is refitted on the
  * device, asynchronously on `stream` after one small read-back of the instance array; a changed BLAS handle
  * or visibility mask, or a refitted tree whose boxes have grown too far, rebuilds it (as a tree over
@@ -159,6 +161,7 @@ typedef struct HrtStats {
     uint64_t tlas_refits, tlas_rebuilds;   /* hrt_tlas_update calls served by the device refit / builds + rebuilds    */
     double   tlas_refit_ratio;             /* quality sum of the last refitted tree checked / that of the built tree  */
     uint64_t bvh_depth;                    /* levels below the root of the TLAS last launched (trees deeper than 12 take round 1's path kernel) */
+    uint64_t bvh_alloc_bytes;              /* device memory the TLAS last launched holds for nodes, node boxes and records (bvh_bytes: the packed payload) */
 } HrtStats;
 
 int  hrt_stats_reset(HrtContext *ctx);

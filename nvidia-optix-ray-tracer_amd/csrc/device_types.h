@@ -171,9 +171,10 @@ struct InstanceTableArgs {
     const void *instances;         // HrtInstance[] (80 B each): transform[12], instanceId, sbtOffset, visibilityMask, flags, handle (u64), pad
     uint32_t n;
     const unsigned long long *sig_handle; const uint32_t *sig_visibility;   // what the tree was built with
+    const uint32_t *sig_sbt;       // the sbtOffsets the material tables were derived from
     const float *blas_box;         // 6 floats per instance: object-space bounds of its BLAS (lo > hi: empty)
     float *inst_xf, *inst_inv; uint32_t *inst_identity;
-    uint32_t *flags;               // [0]: scene scale (float bits, starts at 1.0f); [1]: set when a handle or visibility bit differs
+    uint32_t *flags;               // [0]: scene scale (float bits, starts at 1.0f); [1]: bit 0 set when a handle or visibility bit differs (-> rebuild), bit 1 when an sbtOffset does (-> synchronous update)
 };
 void launch_instance_tables(const InstanceTableArgs &a, hipStream_t s);
 void launch_refit_top(const RefitArgs &a, const RefitLevels &lv, hipStream_t s);

@@ -43,6 +43,7 @@ ScratchArena scratch_acquire(HrtContext *ctx, size_t bytes) {
 }
 void scratch_release(HrtContext *ctx, ScratchArena a) {
     if (!a.p) return;
+    if (a.bytes > ((size_t)2 << 30)) { (void)hipFree(a.p); return; }      // the working memory of a very large build is not kept
     ScratchArena drop;
     {
         std::lock_guard<std::mutex> lk(ctx->scratch_mu);
@@ -73,9 +74,10 @@ void free_tlas_device(Tlas &t) {
     t.d_inst_first = t.d_inst_kind = nullptr;
     if (t.d_sig_handle) (void)hipFree(t.d_sig_handle);
     if (t.d_sig_visibility) (void)hipFree(t.d_sig_visibility);
+    if (t.d_sig_sbt) (void)hipFree(t.d_sig_sbt);
     if (t.d_blas_box) (void)hipFree(t.d_blas_box);
     if (t.d_update_flags) (void)hipFree(t.d_update_flags);
-    t.d_sig_handle = nullptr; t.d_sig_visibility = nullptr; t.d_blas_box = nullptr; t.d_update_flags = nullptr;
+    t.d_sig_handle = nullptr; t.d_sig_visibility = nullptr; t.d_sig_sbt = nullptr; t.d_blas_box = nullptr; t.d_update_flags = nullptr;
     t.d_nodes = t.d_prims = nullptr; t.d_inst_inv = nullptr; t.d_inst_identity = nullptr;
     t.d_node_box = t.d_node_ref = t.d_inst_xf = t.d_area = nullptr; t.d_inst_src = nullptr; t.d_order = nullptr;
     t.area_pending = false;
@@ -314,20 +316,23 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
     t.n_instances = n;
     t.blas_refs = std::move(refs);
     t.node_stride = (uint32_t)ctx->node_stride; t.prim_stride = (uint32_t)ctx->prim_stride;
-    // a device build emits into buffers sized for the worst case (one node per primitive; typically a seventh is used)
-    const size_t n_nodes = on_device ? (size_t)first[n] : t.bvh.nodes.size(), n_prims = on_device ? (size_t)first[n] : t.bvh.prims.size();
+    // A device build emits its nodes into the build's working memory, sized for the worst case (one node per primitive;
+    // typically a seventh is used); the TLAS gets buffers of the size the build turned out to need (below).
+    const size_t n_nodes = on_device ? 0 : t.bvh.nodes.size(), n_prims = on_device ? (size_t)first[n] : t.bvh.prims.size();
     const size_t nb = (size_t)t.node_stride * n_nodes;
     const size_t pb = (size_t)t.prim_stride * std::max<size_t>(n_prims, 1);
     std::vector<const void *> src(std::max(n, 1u), nullptr);
     for (uint32_t i = 0; i < n; ++i) src[i] = t.blas_refs[i]->d_verts;
-    HIP_TRY(ctx, hipMalloc(&t.d_nodes, nb));
+    if (!on_device) HIP_TRY(ctx, hipMalloc(&t.d_nodes, nb));
     HIP_TRY(ctx, hipMalloc(&t.d_prims, pb));
     HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_inv, sizeof(float) * t.h_inv.size()));
     HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_xf, sizeof(float) * t.h_xf.size()));
     HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_identity, sizeof(uint32_t) * t.h_ident.size()));
     HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_src, sizeof(void *) * src.size()));
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_node_box, sizeof(float) * std::max<size_t>(6 * n_nodes, 6)));
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_node_ref, sizeof(float) * std::max<size_t>(2 * n_nodes, 2)));
+    if (!on_device) {
+        HIP_TRY(ctx, hipMalloc((void **)&t.d_node_box, sizeof(float) * std::max<size_t>(6 * n_nodes, 6)));
+        HIP_TRY(ctx, hipMalloc((void **)&t.d_node_ref, sizeof(float) * std::max<size_t>(2 * n_nodes, 2)));
+    }
     HIP_TRY(ctx, hipMalloc((void **)&t.d_area, sizeof(float)));
     if (!order.empty()) HIP_TRY(ctx, hipMalloc((void **)&t.d_order, sizeof(uint32_t) * order.size()));
     if (!t.h_area) HIP_TRY(ctx, hipHostMalloc((void **)&t.h_area, sizeof(float), hipHostMallocDefault));
@@ -343,12 +348,14 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         for (uint32_t i = 0; i < n; ++i) sigh[i] = t.sig_handle[i];
         HIP_TRY(ctx, hipMalloc((void **)&t.d_sig_handle, sizeof(unsigned long long) * sigh.size()));
         HIP_TRY(ctx, hipMalloc((void **)&t.d_sig_visibility, sizeof(uint32_t) * std::max(n, 1u)));
+        HIP_TRY(ctx, hipMalloc((void **)&t.d_sig_sbt, sizeof(uint32_t) * std::max(n, 1u)));
         HIP_TRY(ctx, hipMalloc((void **)&t.d_blas_box, sizeof(float) * bbox.size()));
         HIP_TRY(ctx, hipMalloc((void **)&t.d_update_flags, sizeof(uint32_t) * 2));
         if (!t.h_update_flags) HIP_TRY(ctx, hipHostMalloc((void **)&t.h_update_flags, sizeof(uint32_t) * 4, hipHostMallocDefault));
         t.h_update_flags[0] = t.h_update_flags[2] = 0x3f800000u; t.h_update_flags[1] = t.h_update_flags[3] = 0u;
         HIP_TRY(ctx, hipMemcpyAsync(t.d_sig_handle, sigh.data(), sizeof(unsigned long long) * sigh.size(), hipMemcpyHostToDevice, s));
         if (n) HIP_TRY(ctx, hipMemcpyAsync(t.d_sig_visibility, t.sig_visibility.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+        if (n) HIP_TRY(ctx, hipMemcpyAsync(t.d_sig_sbt, t.sbt_offset.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipMemcpyAsync(t.d_blas_box, bbox.data(), sizeof(float) * bbox.size(), hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));            // (the staging vectors go out of scope)
     }
@@ -367,12 +374,30 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         in.n_prims = first[n]; in.n_inst = n; in.d_inst_first = t.d_inst_first; in.d_inst_kind = t.d_inst_kind; in.d_inst_src = t.d_inst_src;
         in.d_inst_xf = t.d_inst_xf; in.d_inst_identity = t.d_inst_identity;
         in.max_leaf_prims = kMaxLeafPrims; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius;
-        in.out_nodes = ra.nodes; in.node_stride = t.node_stride; in.out_prims = ra.prims; in.prim_stride = t.prim_stride; in.out_node_ref = t.d_node_ref;
-        const ScratchArena arena = scratch_acquire(ctx, gpu_build_scratch_bytes(in.n_prims));
-        in.scratch = arena.p; in.scratch_bytes = arena.bytes;
+        // worst-case node output (one node and two reference floats per primitive) at the front of the working memory
+        const size_t stage_nodes = ((size_t)t.node_stride * in.n_prims + 255u) & ~(size_t)255u, stage_ref = (sizeof(float) * 2 * (size_t)in.n_prims + 255u) & ~(size_t)255u;
+        const ScratchArena arena = scratch_acquire(ctx, gpu_build_scratch_bytes(in.n_prims) + stage_nodes + stage_ref);
+        if (!arena.p) return fail(ctx, HRT_ERR_OOM, "device build: no working memory (%zu bytes)", gpu_build_scratch_bytes(in.n_prims) + stage_nodes + stage_ref);
+        struct Release { HrtContext *c; ScratchArena a; ~Release() { scratch_release(c, a); } } release{ctx, arena};
+        unsigned char *stage = static_cast<unsigned char *>(arena.p);
+        in.out_nodes = stage; in.node_stride = t.node_stride; in.out_node_ref = reinterpret_cast<float *>(stage + stage_nodes);
+        in.out_prims = ra.prims; in.prim_stride = t.prim_stride;
+        in.scratch = stage + stage_nodes + stage_ref; in.scratch_bytes = arena.bytes - stage_nodes - stage_ref;
         const GpuBuildResult r = gpu_build_bvh8(in, s);      // (synchronises the stream before it returns)
-        scratch_release(ctx, arena);
         if (r.error != hipSuccess) return fail(ctx, r.error == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, "device build failed: %s (%s)", hipGetErrorString(r.error), r.where);
+        {   // the tree's own buffers, as large as the build turned out to need
+            const size_t nn = std::max<size_t>(r.n_prims ? r.n_nodes : 1u, 1u);
+            HIP_TRY(ctx, hipMalloc(&t.d_nodes, (size_t)t.node_stride * nn));
+            HIP_TRY(ctx, hipMalloc((void **)&t.d_node_box, sizeof(float) * 6 * nn));
+            HIP_TRY(ctx, hipMalloc((void **)&t.d_node_ref, sizeof(float) * 2 * nn));
+            if (r.n_prims) {
+                HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, stage, (size_t)t.node_stride * nn, hipMemcpyDeviceToDevice, s));
+                HIP_TRY(ctx, hipMemcpyAsync(t.d_node_ref, in.out_node_ref, sizeof(float) * 2 * nn, hipMemcpyDeviceToDevice, s));
+                HIP_TRY(ctx, hipStreamSynchronize(s));         // the working memory goes back to the context when this scope ends
+            }
+            ra.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); ra.node_box = t.d_node_box; ra.node_ref = t.d_node_ref;
+            t.alloc_bytes = (uint64_t)t.node_stride * nn + sizeof(float) * 8 * nn + pb;
+        }
         t.bvh = Bvh8();
         if (r.n_prims == 0u) {
             // every primitive had non-finite bounds: the empty root (every ray misses)
@@ -418,6 +443,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
             HIP_TRY(ctx, hipGetLastError());
         }
         t.n_nodes = (uint32_t)t.bvh.nodes.size(); t.n_prims = (uint32_t)t.bvh.prims.size();
+        t.alloc_bytes = (uint64_t)nb + sizeof(float) * 8 * std::max<size_t>(n_nodes, 1) + pb;
         t.n_triangles = t.bvh.n_triangles; t.n_spheres = t.bvh.n_spheres; t.max_depth = t.bvh.max_depth;
         for (int a = 0; a < 3; ++a) { t.lo[a] = t.bvh.lo[a]; t.hi[a] = t.bvh.hi[a]; }
     }
@@ -571,7 +597,7 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
     { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->tlas.find(tlas); if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle"); t = it->second.get(); }
     if (n != t->n_instances) return fail(ctx, HRT_ERR_INVALID, "update must keep the instance count (%u != %u)", n, t->n_instances);
     if (n && !d_instances) return fail(ctx, HRT_ERR_INVALID, "d_instances is NULL");
-    bool force_rebuild = false;
+    bool force_rebuild = false, sbt_sync = false;
     // (the first update after a build takes the synchronous path below, which checks that refit on the spot: see there)
     if ((ctx->flags & HRT_CTX_ASYNC_UPDATE) != 0 && ctx->refit != 0 && t->n_prims != 0u && n != 0u && t->refits_since_build != 0) {
         // ---- asynchronous update: nothing is read back now.  First the verdict of the previous one (long complete). ----
@@ -579,12 +605,14 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
             HIP_TRY(ctx, hipEventSynchronize(t->area_ready));
             t->area_pending = false;
             ctx->tlas_refit_ratio = (double)*t->h_area;
-            if (!(ctx->tlas_refit_ratio <= (double)ctx->refit_rebuild_ratio) || t->h_update_flags[1] != 0u) force_rebuild = true;
+            if (!(ctx->tlas_refit_ratio <= (double)ctx->refit_rebuild_ratio) || (t->h_update_flags[1] & 1u) != 0u) force_rebuild = true;
+            else if ((t->h_update_flags[1] & 2u) != 0u) sbt_sync = true;      // an sbtOffset changed: the synchronous path below re-reads them
+            t->h_update_flags[1] = 0u;
         }
-        if (!force_rebuild) {
+        if (!force_rebuild && !sbt_sync) {
             HIP_TRY(ctx, hipMemcpyAsync(t->d_update_flags, t->h_update_flags + 2, sizeof(uint32_t) * 2, hipMemcpyHostToDevice, s));
             InstanceTableArgs ia{};
-            ia.instances = d_instances; ia.n = n; ia.sig_handle = t->d_sig_handle; ia.sig_visibility = t->d_sig_visibility; ia.blas_box = t->d_blas_box;
+            ia.instances = d_instances; ia.n = n; ia.sig_handle = t->d_sig_handle; ia.sig_visibility = t->d_sig_visibility; ia.sig_sbt = t->d_sig_sbt; ia.blas_box = t->d_blas_box;
             ia.inst_xf = t->d_inst_xf; ia.inst_inv = t->d_inst_inv; ia.inst_identity = t->d_inst_identity; ia.flags = t->d_update_flags;
             launch_instance_tables(ia, s);
             HIP_TRY(ctx, hipMemsetAsync(t->d_area, 0, sizeof(float), s));
@@ -619,7 +647,11 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
     if (same) {
         bool sbt_changed = false;
         for (uint32_t i = 0; i < n; ++i) if (inst[i].sbtOffset != t->sbt_offset[i]) { t->sbt_offset[i] = inst[i].sbtOffset; sbt_changed = true; }
-        if (sbt_changed) t->generation++;                 // the material tables are re-derived at the next launch
+        if (sbt_changed) {
+            t->generation++;                              // the material tables are re-derived at the next launch
+            HIP_TRY(ctx, hipMemcpyAsync(t->d_sig_sbt, t->sbt_offset.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+        }
         const bool first_after_build = t->refits_since_build == 0;
         const int rc = refit_tlas(ctx, *t, inst, s);
         if (rc != HRT_OK || !first_after_build) return rc;
@@ -634,7 +666,7 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
     }
     if (std::getenv("HRT_BUILD_VERBOSE"))
         std::fprintf(stderr, "[hrt] update %llu of this tree rebuilds: %s (area ratio %.3f, %llu refits since the build)\n", (unsigned long long)(t->refits + t->rebuilds),
-                     force_rebuild ? "verdict of the previous asynchronous refit" : "handles / visibility changed or the refit just done degraded the tree", ctx->tlas_refit_ratio,
+                     force_rebuild ? "verdict of the previous asynchronous refit" : "handles / visibility changed or the refit just done degraded the tree", ctx->tlas_refit_ratio.load(),
                      (unsigned long long)t->refits_since_build);
     HIP_TRY(ctx, hipDeviceSynchronize());                 // launches on other streams may still read the old tree
     // A rebuild in the middle of an animation.  Large scenes: the merged device build (6.6 ms for 2000 particles / 435 k

@@ -6,14 +6,31 @@
 
 namespace hrt {
 
-namespace { thread_local std::string g_create_error; }
+// Errors: *_build calls may run on several loader threads of one context (RendererMesh.cu:93-100), so a thread's last failure
+// is kept per thread; hrt_last_error answers with the calling thread's own failure on that context when it has one, else with
+// the context's most recent failure from any thread (copied under a lock).
+namespace {
+thread_local std::string g_create_error, g_thread_error, g_error_copy;
+thread_local const HrtContext *g_thread_error_ctx = nullptr;
+std::mutex g_error_mu;
+}
 const char *create_error() { return g_create_error.c_str(); }
 
 int fail(HrtContext *ctx, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    if (ctx) ctx->error = buf; else g_create_error = buf;
+    if (ctx) {
+        g_thread_error = buf; g_thread_error_ctx = ctx;
+        std::lock_guard<std::mutex> lk(g_error_mu);
+        ctx->error = buf;
+    } else g_create_error = buf;
     return code;
+}
+const char *last_error_of(const HrtContext *ctx) {
+    if (g_thread_error_ctx == ctx) return g_thread_error.c_str();
+    std::lock_guard<std::mutex> lk(g_error_mu);
+    g_error_copy = ctx->error;
+    return g_error_copy.c_str();
 }
 
 // ---- XORWOW sub-sequence jump matrices: T^(2^(67+k)), k = 0..31, 160 columns x 5 words ----
@@ -99,7 +116,7 @@ extern "C" {
 
 const char *hrt_version(void) { return "hrt 0.1 (gfx950 wavefront path tracer)"; }
 
-const char *hrt_last_error(const HrtContext *ctx) { return ctx ? ctx->error.c_str() : hrt::create_error(); }
+const char *hrt_last_error(const HrtContext *ctx) { return ctx ? hrt::last_error_of(ctx) : hrt::create_error(); }
 
 int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (!out_ctx) return fail(nullptr, HRT_ERR_INVALID, "out_ctx is NULL");
@@ -617,6 +634,7 @@ int hrt_stats_get(HrtContext *ctx, HrtStats *out) {
         const Tlas &tl = *it->second;
         out->bvh_nodes = tl.n_nodes; out->bvh_triangles = tl.n_triangles; out->bvh_spheres = tl.n_spheres; out->bvh_depth = tl.max_depth;
         out->bvh_bytes = (uint64_t)tl.n_nodes * sizeof(Bvh8Node) + (uint64_t)tl.n_prims * sizeof(PrimRecord);
+        out->bvh_alloc_bytes = tl.alloc_bytes;
     }
     return HRT_OK;
 }

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -53,6 +54,7 @@ struct Tlas {
     uint32_t *d_inst_identity = nullptr;
     bool has_spheres = false;
     uint32_t node_stride = 80, prim_stride = 48;
+    uint64_t alloc_bytes = 0;               // device memory of nodes + node boxes / reference areas + records, as allocated
     uint64_t generation = 0;
     // refit (hrt_tlas_update): what must stay the same, and the device tables the refit kernel reads
     std::vector<std::shared_ptr<Blas>> blas_refs;       // keeps the source geometry alive
@@ -62,8 +64,8 @@ struct Tlas {
     uint32_t *d_order = nullptr;                         // trees over instances: refit order (NULL: breadth-first index ranges)
     uint32_t *d_inst_first = nullptr, *d_inst_kind = nullptr;   // device build: global number of each instance's first primitive; geometry kind
     // asynchronous updates (HRT_CTX_ASYNC_UPDATE): what the tree was built with, for the device-side tables kernel, and its verdict
-    unsigned long long *d_sig_handle = nullptr; uint32_t *d_sig_visibility = nullptr; float *d_blas_box = nullptr;
-    uint32_t *d_update_flags = nullptr;                  // [0] scene scale (float bits), [1] handle / visibility changed
+    unsigned long long *d_sig_handle = nullptr; uint32_t *d_sig_visibility = nullptr, *d_sig_sbt = nullptr; float *d_blas_box = nullptr;
+    uint32_t *d_update_flags = nullptr;                  // [0] scene scale (float bits), [1] bit 0: handle / visibility changed, bit 1: an sbtOffset changed
     uint32_t *h_update_flags = nullptr;                  // pinned: [0..1] copy of the above after the last update, [2..3] their initial values
     std::vector<std::pair<uint32_t, uint32_t>> phases;   // (first, count) in processing order, children before parents
     bool instanced = false;
@@ -111,7 +113,7 @@ struct HrtContext {
     int device = 0;
     uint32_t flags = 0;
     int n_cu = 256;
-    std::string error;
+    std::string error;                          // last failure of any thread (under the error lock of hrt_api.cpp); a thread asks for its own first
     std::mutex mu;
     std::unordered_map<uint64_t, std::shared_ptr<hrt::Blas>> blas;
     std::unordered_map<uint64_t, std::unique_ptr<hrt::Tlas>> tlas;
@@ -169,7 +171,7 @@ struct HrtContext {
     float build_c_node = 1.0f, build_c_prim = 0.45f;   // collapse costs (bvh8_build.cpp has the same defaults)
     int refit = 1;                              // hrt_tlas_update: 1 = device refit when only transforms changed, 0 = always rebuild
     float refit_rebuild_ratio = 1.5f;           // rebuild when the refitted tree's weighted mean node area has grown by this factor
-    uint64_t tlas_refits = 0, tlas_rebuilds = 0; double tlas_refit_ratio = 1.0;
+    std::atomic<uint64_t> tlas_refits{0}, tlas_rebuilds{0}; std::atomic<double> tlas_refit_ratio{1.0};   // (builds run on several loader threads)
     int substreams = 0;                         // sub-tiles rendered on their own HIP streams so that one's tail overlaps another's bulk
     std::vector<hipStream_t> sub_streams; std::vector<hipEvent_t> sub_done; hipEvent_t ev_begin = nullptr;
 };
@@ -179,6 +181,7 @@ namespace hrt {
 // formats the message into ctx->error (or the creating thread's error when ctx is NULL) and returns code
 int fail(HrtContext *ctx, int code, const char *fmt, ...);
 const char *create_error();
+const char *last_error_of(const HrtContext *ctx);
 
 #define HIP_TRY(ctx, expr)                                                                   \
     do {                                                                                     \

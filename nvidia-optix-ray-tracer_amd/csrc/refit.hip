@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void k_instance_tables(InstanceTableArgs a) {
     const uint32_t visibility = u[14] & 1u;
     const unsigned long long handle = *reinterpret_cast<const unsigned long long *>(u + 16);
     if (handle != a.sig_handle[i] || visibility != a.sig_visibility[i]) atomicOr(&a.flags[1], 1u);
+    if (u[13] != a.sig_sbt[i]) atomicOr(&a.flags[1], 2u);         // sbtOffset: the next update refreshes the material tables
     float t[12];
     for (int k = 0; k < 12; ++k) { t[k] = m[k]; a.inst_xf[12 * (size_t)i + k] = t[k]; }
     const bool id = t[0] == 1.0f && t[1] == 0.0f && t[2] == 0.0f && t[3] == 0.0f && t[4] == 0.0f && t[5] == 1.0f && t[6] == 0.0f && t[7] == 0.0f &&

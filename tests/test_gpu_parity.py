@@ -450,6 +450,43 @@ def test_asynchronous_update_frames(hrt, oracle, gpu_available, monkeypatch):
         r.close()
 
 
+def test_asynchronous_update_notices_changed_sbt_offsets(hrt, oracle, gpu_available, monkeypatch):
+    """HRT_CTX_ASYNC_UPDATE and a changed sbtOffset (a hit-group record per instance, RendererMesh.cu:130-140): nothing is read
+    back during the update that carries the change, but k_instance_tables compares the offsets with the build's on the device,
+    and the NEXT update takes the synchronous path, re-reads them and re-derives the material tables -- no rebuild.  The frame
+    after that is the oracle's on the scene with the two instances' materials (and normal arrays) exchanged."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    import torch
+    monkeypatch.setenv("HRT_REFIT_REBUILD_RATIO", "1e30")
+    r = hrt.Renderer(0, hrt.CTX_ASYNC_UPDATE)
+    try:
+        w, h = 64, 48
+        scene = hrt.scenes.mixed_test_scene(900, 20, 5, w, h, 1)
+        r.load_scene(scene)
+        xf = [it["transform"] for it in scene["instances"]]
+        r.update_instances(xf)                                 # first update after the build: synchronous by design
+        r.update_instances(xf)                                 # asynchronous from here on
+        r._h_inst[0].sbtOffset, r._h_inst[2].sbtOffset = 2, 0
+        r._d_inst.copy_(torch.from_numpy(np.frombuffer(bytes(r._h_inst), dtype=np.uint8).copy()))
+        before = r.stats()
+        r._check(r.lib.hrt_tlas_update(r.ctx, r.tlas, r._d_inst.data_ptr(), len(xf), r._stream()), "update")   # detected on the device
+        r._check(r.lib.hrt_tlas_update(r.ctx, r.tlas, r._d_inst.data_ptr(), len(xf), r._stream()), "update")   # acted on
+        after = r.stats()
+        assert after.tlas_rebuilds == before.tlas_rebuilds and after.tlas_refits == before.tlas_refits + 2
+        a, b = scene["instances"][0], scene["instances"][2]
+        for key in ("material", "albedo", "fuzz", "normals"):
+            a[key], b[key] = b[key], a[key]
+        _moved_scene_matches_oracle(hrt, oracle, r, scene, w, h, 5)
+        # and the update after that is asynchronous again (the device's copy of the offsets was refreshed)
+        r._check(r.lib.hrt_tlas_update(r.ctx, r.tlas, r._d_inst.data_ptr(), len(xf), r._stream()), "update")
+        r._check(r.lib.hrt_tlas_update(r.ctx, r.tlas, r._d_inst.data_ptr(), len(xf), r._stream()), "update")
+        _moved_scene_matches_oracle(hrt, oracle, r, scene, w, h, 6)
+        assert r.stats().tlas_rebuilds == before.tlas_rebuilds
+    finally:
+        r.close()
+
+
 def test_pose_instances_matches_oracle(hrt, oracle, renderer):
     """hrt_pose_instances (slerp -> quatToEuler -> constructTransformMatrix on the device, RendererTime.cu:436-472)
     against the oracle, which calls float libm like the reference.  Bars: the translation column has no

@@ -9,9 +9,9 @@ set -u
 TAG=${1:-r02}
 OUT=gpurun_out/final; mkdir -p $OUT; export TMPDIR=/tmp
 BUILD_ID=$(cat nvidia-optix-ray-tracer_amd/lib/BUILD_ID 2>/dev/null || echo unknown)
-ARGS1="--steps 1 --warmup 0 --no-cpu-baseline"
+ARGS1="--steps 1 --warmup 0 --no-cpu-baseline --no-alt-builder"
 echo "build $BUILD_ID"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/kt.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt-builder > $OUT/kt.log 2>&1
 cp $OUT/kt/*/*kernel_stats.csv $OUT/${TAG}_kernel_stats_c4_256spp.csv 2>/dev/null
 pmc() { name=$1; shift; timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 bench.py $ARGS1 > $OUT/$name.log 2>&1 || echo "pass $name failed"; }
 pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY

@@ -17,6 +17,6 @@ for spec in "$@"; do
   combos=("${next[@]}")
 done
 for c in "${combos[@]}"; do
-  r=$(env $c python3 bench.py "${ARGS[@]}" --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'])")
+  r=$(env $c python3 bench.py "${ARGS[@]}" --no-cpu-baseline --no-alt-builder 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'])")
   echo "$c : $r" | tee -a "$OUT"
 done
