@@ -37,7 +37,7 @@ $(LIBDIR)/refit.o: $(CSRC)/refit.hip $(CSRC)/device_types.h $(CSRC)/bvh8_geom.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/pose.o: $(CSRC)/pose.hip $(CSRC)/device_types.h
+$(LIBDIR)/pose.o: $(CSRC)/pose.hip $(CSRC)/device_types.h $(CSRC)/cr_trig.h $(CSRC)/srgb_pow.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -60,7 +60,7 @@ $(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/paths.o $(L
 	@cat $(sort $(wildcard $(CSRC)/*.hip $(CSRC)/*.h $(CSRC)/*.hpp $(CSRC)/*.cpp include/*.h)) | sha256sum | cut -c1-16 > $(LIBDIR)/BUILD_ID
 
 # host-side readers of the reference's input formats (include/hrt_io.h): plain C++, no GPU
-$(LIBDIR)/libhrt_io.so: $(CSRC)/host/scene_io.cpp $(CSRC)/host/json_min.hpp include/hrt_io.h include/hrt_params.h
+$(LIBDIR)/libhrt_io.so: $(CSRC)/host/scene_io.cpp $(CSRC)/host/json_min.hpp $(CSRC)/cr_trig.h $(CSRC)/srgb_pow.h include/hrt_io.h include/hrt_params.h
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -shared -o $@ $<
 

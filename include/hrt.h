@@ -183,6 +183,13 @@ int  hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_ori
  * it bit-for-bit with the oracle.  Pass NULL to switch it off. */
 int  hrt_debug_set_linear_output(HrtContext *ctx, HrtFloat4 *d_linear);
 
+/* sinf (0) / cosf (1) / acosf (2) / asinf (3) / atan2f (4) as hrt_pose_instances evaluates them (csrc/cr_trig.h: the correctly
+ * rounded float of the exact value, the pin shared with the oracle), over n arguments: d_a[i] (atan2: y = d_a[i], x = d_b[i]), or,
+ * when d_a is NULL, the floats whose bit patterns are first_bits + i * stride_bits.  force_slow != 0 decides every value in
+ * double-double arithmetic (the path one call in ~500 000 takes). */
+int  hrt_debug_trig(HrtContext *ctx, int function, const float *d_a, const float *d_b, uint32_t first_bits, uint32_t stride_bits,
+                    uint64_t n, int force_slow, float *d_out, void *stream);
+
 /* Host-only BVH8 build over triangles given as 9 floats each (no GPU needed): returns the
  * packed node and primitive blobs the device kernels traverse.  Free with hrt_host_free. */
 typedef struct HrtBvhBlob {

@@ -102,7 +102,7 @@ EXPORTS = [
     "hrt_sbt_record_pack_header", "hrt_materials_set", "hrt_miss_set",
     "hrt_rng_init", "hrt_rng_free", "hrt_render_launch", "hrt_sync", "hrt_to_rgba8", "hrt_color_to_float4",
     "hrt_stats_reset", "hrt_stats_get", "hrt_trace_rays", "hrt_debug_set_linear_output",
-    "hrt_host_build_bvh8", "hrt_tlas_download", "hrt_host_free",
+    "hrt_host_build_bvh8", "hrt_tlas_download", "hrt_host_free", "hrt_debug_trig",
 ]
 
 
@@ -161,6 +161,7 @@ def load_library():
     lib.hrt_trace_rays.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float,
                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hrt_debug_set_linear_output.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hrt_debug_trig.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
     lib.hrt_host_build_bvh8.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(BvhBlob)]
     lib.hrt_tlas_download.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(BvhBlob)]
     lib.hrt_host_free.argtypes = [C.POINTER(BvhBlob)]

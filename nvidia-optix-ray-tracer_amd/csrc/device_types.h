@@ -189,6 +189,7 @@ struct PoseArgs {
     uint32_t mesh_mode;            // RendererMesh's drift-only update (no rotation, position not added)
 };
 void launch_pose_instances(const PoseArgs &a, hipStream_t s);
+void launch_debug_trig(int which, const float *a, const float *b, uint32_t first, uint32_t stride, uint64_t n, int force_slow, float *out, hipStream_t s);
 
 // host-callable launchers (defined in kernels.hip)
 void launch_rng_init(RngState *states, uint32_t n, uint64_t salt, const uint32_t *d_jump, hipStream_t s);

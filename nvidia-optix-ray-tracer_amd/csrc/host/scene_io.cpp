@@ -2,6 +2,7 @@
 // VTK / nlohmann dependency.  Each function cites the reference code whose observable result it reproduces.
 #include "hrt_io.h"
 #include "json_min.hpp"
+#include "../cr_trig.h"      // cos / sin of constructRotateMatrix: the correctly rounded pin the pose kernel and the oracle share
 
 #include <algorithm>
 #include <cctype>
@@ -80,7 +81,7 @@ Mat4 ident() { Mat4 r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) r
 Mat4 rotation(float degree, int axis) {
     const float pi = 3.1415926f;
     const float theta = degree * pi / 180.0f;
-    const float c = std::cos(theta), s = std::sin(theta);
+    const float c = hrt::cosf_cr(theta), s = hrt::sinf_cr(theta);
     Mat4 r = ident();
     if (axis == 0) { r.m[1][1] = c; r.m[1][2] = -s; r.m[2][1] = s; r.m[2][2] = c; }
     else if (axis == 1) { r.m[0][0] = c; r.m[0][2] = s; r.m[2][0] = -s; r.m[2][2] = c; }

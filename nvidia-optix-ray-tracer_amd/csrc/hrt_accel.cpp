@@ -699,6 +699,17 @@ int hrt_pose_instances(HrtContext *ctx, HrtInstance *d_instances, uint32_t first
     return HRT_OK;
 }
 
+int hrt_debug_trig(HrtContext *ctx, int function, const float *d_a, const float *d_b, uint32_t first_bits, uint32_t stride_bits, uint64_t n,
+                   int force_slow, float *d_out, void *stream) {
+    if (!ctx) return HRT_ERR_INVALID;
+    if (function < 0 || function > 4) return fail(ctx, HRT_ERR_INVALID, "hrt_debug_trig: function %d (0 sin, 1 cos, 2 acos, 3 asin, 4 atan2)", function);
+    if (n && (!d_out || (function == 4 && (!d_a || !d_b)))) return fail(ctx, HRT_ERR_INVALID, "hrt_debug_trig: NULL argument");
+    (void)hipSetDevice(ctx->device);
+    launch_debug_trig(function, d_a, d_b, first_bits, stride_bits, n, force_slow, d_out, (hipStream_t)stream);
+    HIP_TRY(ctx, hipGetLastError());
+    return HRT_OK;
+}
+
 int hrt_tlas_destroy(HrtContext *ctx, HrtTraversable tlas) {
     if (!ctx) return HRT_ERR_INVALID;
     (void)hipSetDevice(ctx->device);

@@ -14,11 +14,13 @@
 //   * the aggregate returns of slerp put the w-expression into .x, x into .y, y into .z, z into .w (:313-318,
 //     :334-339), and quatToEuler reads the result by name -- the components arrive rotated by one place;
 //   * the Euler angles are those of a Z*Y*X rotation but are composed as Rx*Ry*Rz (:127-130).
-// sin / cos / acos / asin / atan2 are evaluated in double and rounded once to float: the reference calls the
-// float libm functions, whose results these match except where libm itself is not correctly rounded (the
-// parity test states the tolerance).  One thread per particle; 48 + 48 B read, 48 B written.
+// sin / cos / acos / asin / atan2: the reference calls its platform's float functions -- third-party arithmetic that differs
+// by an ULP between platforms -- pinned here and in the oracle as the CORRECTLY ROUNDED float of the exact value
+// (csrc/cr_trig.h), so that every transform entry, and with it every frame rendered from posed instances, is bit-exact
+// against the oracle.  One thread per particle; 48 + 48 B read, 48 B written.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "cr_trig.h"
 #include "device_types.h"
 
 #pragma clang fp contract(off)
@@ -29,11 +31,11 @@ namespace {
 
 constexpr float kPi = 3.1415926f;                 // PI, include/Global/DeviceFunctions.cuh:19
 
-__device__ __forceinline__ float sin_f(float x) { return (float)sin((double)x); }
-__device__ __forceinline__ float cos_f(float x) { return (float)cos((double)x); }
-__device__ __forceinline__ float acos_f(float x) { return (float)acos((double)x); }
-__device__ __forceinline__ float asin_f(float x) { return (float)asin((double)x); }
-__device__ __forceinline__ float atan2_f(float y, float x) { return (float)atan2((double)y, (double)x); }
+__device__ __forceinline__ float sin_f(float x) { return sinf_cr(x); }
+__device__ __forceinline__ float cos_f(float x) { return cosf_cr(x); }
+__device__ __forceinline__ float acos_f(float x) { return acosf_cr(x); }
+__device__ __forceinline__ float asin_f(float x) { return asinf_cr(x); }
+__device__ __forceinline__ float atan2_f(float y, float x) { return atan2f_cr(y, x); }
 
 struct Quat { float x, y, z, w; };
 struct Mat4 { float m[4][4]; };
@@ -133,6 +135,28 @@ __global__ __launch_bounds__(256) void k_pose_instances(PoseArgs a) {
     out[0] = make_float4(t.m[0][0], t.m[0][1], t.m[0][2], t.m[0][3]);
     out[1] = make_float4(t.m[1][0], t.m[1][1], t.m[1][2], t.m[1][3]);
     out[2] = make_float4(t.m[2][0], t.m[2][1], t.m[2][2], t.m[2][3]);
+}
+
+// the five pinned functions over arrays (hrt_debug_trig: the parity tests sweep them against the oracle)
+__global__ __launch_bounds__(256) void k_debug_trig(int which, const float *a, const float *b, uint32_t first, uint32_t stride, uint64_t n, int force_slow, float *out) {
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256ull) {
+        const float x = a ? a[i] : __uint_as_float(first + (uint32_t)(i * stride));
+        const float y = b ? b[i] : 0.0f;
+        float r;
+        switch (which) {
+            case 0: r = sinf_cr(x, force_slow != 0); break;
+            case 1: r = cosf_cr(x, force_slow != 0); break;
+            case 2: r = acosf_cr(x, force_slow != 0); break;
+            case 3: r = asinf_cr(x, force_slow != 0); break;
+            default: r = atan2f_cr(x, y, force_slow != 0); break;
+        }
+        out[i] = r;
+    }
+}
+void launch_debug_trig(int which, const float *a, const float *b, uint32_t first, uint32_t stride, uint64_t n, int force_slow, float *out, hipStream_t s) {
+    if (n == 0) return;
+    const uint64_t blocks = (n + 255u) / 256u;
+    hipLaunchKernelGGL(k_debug_trig, dim3((uint32_t)(blocks < 65536u ? blocks : 65536u)), dim3(256), 0, s, which, a, b, first, stride, n, force_slow, out);
 }
 
 void launch_pose_instances(const PoseArgs &a, hipStream_t s) {

@@ -876,10 +876,84 @@ void oracle_bvh8_trace(const void *nodes_blob, const void *prims_blob,
 /* ------------------------------------------------------------------------------------------
  * Time-mode pose pipeline: src/Global/RendererTime.cu:436-472 per particle --
  * slerp :296-340, quatToEuler :343-370, constructTransformMatrix include/Global/DeviceFunctions.cuh:43-148.
- * Float libm calls (acosf, sinf, cosf, asinf, atan2f) where the reference calls the float overloads.
+ * acosf, sinf, cosf, asinf, atan2f where the reference calls the float overloads: pinned as correctly rounded (below).
  * Reference behaviour kept: the aggregate returns of slerp fill a float4 positionally with the
  * {w, x, y, z} expressions (so they land in .x .y .z .w), and the Z*Y*X Euler angles are composed as Rx*Ry*Rz.
  * ------------------------------------------------------------------------------------------ */
+/* sinf / cosf / acosf / asinf / atan2f of slerp, quatToEuler and constructRotateMatrix.  The reference calls its platform's
+ * float functions (CUDA's on the device build, the host libm's in the frame loop), third-party arithmetic that is not in the
+ * tree and differs between platforms by an ULP -- enough to flip hits in a path tracer.  They are pinned here, like powf
+ * above, as the CORRECTLY ROUNDED float of the exact value: libm's double function rounded to float, and where that double
+ * lies within 2^-45 (relative) of the midpoint of two adjacent floats the decision is taken in __float128 (libquadmath).
+ * The product's csrc/cr_trig.h reaches the same definition with double-double arithmetic; the float libm functions stay
+ * available as a tolerance cross-check (oracle_trig_libm). */
+static int near_float_midpoint(double r) {
+    const float c = (float)r;
+    uint32_t cb; memcpy(&cb, &c, 4);
+    const uint32_t ub = cb + 1u, db = cb - 1u;
+    float cu, cd; memcpy(&cu, &ub, 4); memcpy(&cd, &db, 4);
+    const double mu = 0.5 * ((double)c + (double)cu), md = 0.5 * ((double)c + (double)cd), tol = fabs(r) * 0x1p-45;
+    return fabs(r - mu) < tol || fabs(r - md) < tol;
+}
+static float nearest_float_q(__float128 q, double r) {         /* the float nearest q, among (float)r and its two neighbours */
+    const float c = (float)r;
+    uint32_t cb; memcpy(&cb, &c, 4);
+    const uint32_t ub = cb + 1u, db = cb - 1u;
+    float cu, cd; memcpy(&cu, &ub, 4); memcpy(&cd, &db, 4);
+    float best = c; __float128 bd = fabsq(q - (__float128)c);
+    if (cu == cu && fabsq(q - (__float128)cu) < bd) { bd = fabsq(q - (__float128)cu); best = cu; }
+    if (cd == cd && fabsq(q - (__float128)cd) < bd) { bd = fabsq(q - (__float128)cd); best = cd; }
+    return best;
+}
+static int trig_settled(double r) { return r == 0.0 || !(fabs(r) <= 1.0e300) || !near_float_midpoint(r); }
+static float sinf_cr(float x) { const double r = sin((double)x); return trig_settled(r) ? (float)r : nearest_float_q(sinq((__float128)x), r); }
+static float cosf_cr(float x) { const double r = cos((double)x); return trig_settled(r) ? (float)r : nearest_float_q(cosq((__float128)x), r); }
+static float acosf_cr(float x) { const double r = acos((double)x); return trig_settled(r) ? (float)r : nearest_float_q(acosq((__float128)x), r); }
+static float asinf_cr(float x) { const double r = asin((double)x); return trig_settled(r) ? (float)r : nearest_float_q(asinq((__float128)x), r); }
+static float atan2f_cr(float y, float x) {
+    const double r = atan2((double)y, (double)x);
+    return trig_settled(r) ? (float)r : nearest_float_q(atan2q((__float128)y, (__float128)x), r);
+}
+/* which: 0 sin, 1 cos, 2 acos, 3 asin, 4 atan2(x = y-argument, y = x-argument ... see below).  force_exact: decide every value
+ * in __float128 (what the pin means, without the shortcut) */
+static float trig_one(int which, float a, float b, int force_exact) {
+    if (!force_exact) {
+        switch (which) { case 0: return sinf_cr(a); case 1: return cosf_cr(a); case 2: return acosf_cr(a); case 3: return asinf_cr(a); default: return atan2f_cr(a, b); }
+    }
+    double r; __float128 q;
+    switch (which) {
+        case 0: r = sin((double)a); q = sinq((__float128)a); break;
+        case 1: r = cos((double)a); q = cosq((__float128)a); break;
+        case 2: r = acos((double)a); q = acosq((__float128)a); break;
+        case 3: r = asin((double)a); q = asinq((__float128)a); break;
+        default: r = atan2((double)a, (double)b); q = atan2q((__float128)a, (__float128)b); break;
+    }
+    if (r == 0.0 || !(fabs(r) <= 1.0e300)) return (float)r;
+    return nearest_float_q(q, r);
+}
+/* n values: out[i] = f(a[i]) (atan2: f(a[i], b[i]), a = the y argument) */
+void oracle_trig(int which, const float *a, const float *b, uint64_t n, int force_exact, float *out) {
+#pragma omp parallel for schedule(static)
+    for (uint64_t i = 0; i < n; ++i) out[i] = trig_one(which, a[i], b ? b[i] : 0.0f, force_exact);
+}
+/* ... over the floats whose bit patterns are first, first + stride, ... (count of them); one-argument functions */
+void oracle_trig_bits(int which, uint32_t first, uint32_t stride, uint64_t count, int force_exact, float *out) {
+#pragma omp parallel for schedule(static)
+    for (uint64_t i = 0; i < count; ++i) {
+        const uint32_t bits = first + (uint32_t)(i * stride);
+        float x; memcpy(&x, &bits, 4);
+        out[i] = trig_one(which, x, 0.0f, force_exact);
+    }
+}
+/* the platform's float libm (tolerance cross-check only) */
+void oracle_trig_libm(int which, const float *a, const float *b, uint64_t n, float *out) {
+    for (uint64_t i = 0; i < n; ++i)
+        switch (which) {
+            case 0: out[i] = sinf(a[i]); break; case 1: out[i] = cosf(a[i]); break; case 2: out[i] = acosf(a[i]); break;
+            case 3: out[i] = asinf(a[i]); break; default: out[i] = atan2f(a[i], b[i]); break;
+        }
+}
+
 #define ORACLE_PI 3.1415926f                      /* PI, DeviceFunctions.cuh:19 */
 typedef struct { float x, y, z, w; } quat4;
 typedef struct { float m[4][4]; } mat4;
@@ -901,7 +975,7 @@ static mat4 m4_identity(void) {
 }
 static mat4 m4_rotation(float degree, int axis) {           /* constructRotateMatrix, :88-123 */
     const float theta = degree * ORACLE_PI / 180.0f;        /* degreeToRadian :27-29 */
-    const float c = cosf(theta), s = sinf(theta);
+    const float c = cosf_cr(theta), s = sinf_cr(theta);
     mat4 r = m4_identity();
     if (axis == 0) { r.m[1][1] = c; r.m[1][2] = -s; r.m[2][1] = s; r.m[2][2] = c; }
     else if (axis == 1) { r.m[0][0] = c; r.m[0][2] = s; r.m[2][0] = -s; r.m[2][2] = c; }
@@ -918,11 +992,11 @@ static quat4 pose_slerp(quat4 q1, quat4 q2, float t) {      /* RendererTime.cu:2
         return r;
     }
     {
-        const float theta_0 = acosf(dot);
+        const float theta_0 = acosf_cr(dot);
         const float theta = theta_0 * t;
-        const float sin_theta = sinf(theta);
-        const float sin_theta_0 = sinf(theta_0);
-        const float s0 = cosf(theta) - dot * sin_theta / sin_theta_0;
+        const float sin_theta = sinf_cr(theta);
+        const float sin_theta_0 = sinf_cr(theta_0);
+        const float s0 = cosf_cr(theta) - dot * sin_theta / sin_theta_0;
         const float s1 = sin_theta / sin_theta_0;
         quat4 r = {(s0 * q1.w) + (s1 * q2.w), (s0 * q1.x) + (s1 * q2.x), (s0 * q1.y) + (s1 * q2.y), (s0 * q1.z) + (s1 * q2.z)};
         return r;
@@ -931,12 +1005,12 @@ static quat4 pose_slerp(quat4 q1, quat4 q2, float t) {      /* RendererTime.cu:2
 static void pose_quat_to_euler(quat4 q, float *deg) {       /* RendererTime.cu:343-370 */
     const float sinr_cosp = 2.0f * (q.w * q.x + q.y * q.z);
     const float cosr_cosp = 1.0f - 2.0f * (q.x * q.x + q.y * q.y);
-    const float roll = atan2f(sinr_cosp, cosr_cosp);
+    const float roll = atan2f_cr(sinr_cosp, cosr_cosp);
     const float sinp = 2.0f * (q.w * q.y - q.z * q.x);
-    const float pitch = fabsf(sinp) >= 1.0f ? copysignf(ORACLE_PI / 2.0f, sinp) : asinf(sinp);
+    const float pitch = fabsf(sinp) >= 1.0f ? copysignf(ORACLE_PI / 2.0f, sinp) : asinf_cr(sinp);
     const float siny_cosp = 2.0f * (q.w * q.z + q.x * q.y);
     const float cosy_cosp = 1.0f - 2.0f * (q.y * q.y + q.z * q.z);
-    const float yaw = atan2f(siny_cosp, cosy_cosp);
+    const float yaw = atan2f_cr(siny_cosp, cosy_cosp);
     deg[0] = roll * 180.0f / ORACLE_PI; deg[1] = pitch * 180.0f / ORACLE_PI; deg[2] = yaw * 180.0f / ORACLE_PI;   /* radianToDegree :30-32 */
 }
 

@@ -62,6 +62,9 @@ def lib():
     L.oracle_quat_to_euler.argtypes = [C.c_void_p, C.c_void_p]
     L.oracle_pose_transforms.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32,
                                          C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_trig.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+    L.oracle_trig_bits.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]
+    L.oracle_trig_libm.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.oracle_num_threads.restype = C.c_int
     L.oracle_set_threads.argtypes = [C.c_int]
     L.oracle_init()
@@ -190,6 +193,30 @@ def pose_transforms(current, nxt, duration, frame, frame_count, offset=(0, 0, 0)
     out = np.zeros((cur.shape[0], 12), np.float32)
     lib().oracle_pose_transforms(_p(cur), _p(nx), cur.shape[0], float(duration), int(frame), int(frame_count), _p(off), _p(sc), _p(out))
     return out
+
+
+TRIG_SIN, TRIG_COS, TRIG_ACOS, TRIG_ASIN, TRIG_ATAN2 = range(5)
+
+
+def trig(which, a, b=None, force_exact=False, libm=False):
+    """The pose pipeline's float transcendentals as the oracle pins them (correctly rounded): f(a) or atan2(a, b) elementwise.
+    force_exact decides every value in __float128; libm=True is the platform's float libm (tolerance cross-check)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = None if b is None else np.ascontiguousarray(b, dtype=np.float32)
+    out = np.empty(a.shape, np.float32)
+    if libm:
+        lib().oracle_trig_libm(which, _p(a), _p(b if b is not None else a), a.size, _p(out))
+    else:
+        lib().oracle_trig(which, _p(a), _p(b), a.size, int(force_exact), _p(out))
+    return out
+
+
+def trig_bits(which, first, stride, count, force_exact=False, out=None):
+    """... over the floats whose bit patterns are first, first + stride, ... (one-argument functions)."""
+    if out is None:
+        out = np.empty(count, np.float32)
+    lib().oracle_trig_bits(which, int(first) & 0xFFFFFFFF, int(stride), int(count), int(force_exact), _p(out))
+    return out[:count]
 
 
 def rng_init(width, height, salt):

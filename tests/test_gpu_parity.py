@@ -3,6 +3,10 @@
 Bars (stated per test):
   * integer / index work (RNG states, hit primitive + instance, ray counts): bit-exact
   * hit t,u,v and the linear radiance: bit-exact (all control-flow arithmetic is pinned)
+  * instance transforms from the pose kernel: bit-exact.  sinf / cosf / acosf / asinf / atan2f are pinned on both sides as the
+    correctly rounded float (oracle: libm double + __float128 near ties; kernel: csrc/cr_trig.h), checked over every float
+    (test_trig_pin_every_float_on_the_gpu); frames rendered from posed instances are compared with the oracle rendering
+    from ITS OWN transforms.  No parity test carries a tolerance.
   * sRGB colour (float and 8-bit): bit-exact.  The shader's powf(c, 1/2.4f) is pinned on both sides as the correctly
     rounded float of c^y (oracle: libm double pow + __float128 near ties; kernels: csrc/srgb_pow.h), checked over every
     float in [0, 1] (test_color_conversion_all_floats_bit_exact); libm's powf itself is within 1 ULP of that
@@ -489,10 +493,9 @@ def test_asynchronous_update_notices_changed_sbt_offsets(hrt, oracle, gpu_availa
 
 def test_pose_instances_matches_oracle(hrt, oracle, renderer):
     """hrt_pose_instances (slerp -> quatToEuler -> constructTransformMatrix on the device, RendererTime.cu:436-472)
-    against the oracle, which calls float libm like the reference.  Bars: the translation column has no
-    transcendental in it and is bit-exact; rotation / scale entries within 1e-5 absolute (north_star's float
-    tolerance) and 2e-7 in the median: the kernel rounds double-precision sin/cos/acos/asin/atan2 once, libm's
-    float versions are within 1 ULP of that, and atan2 amplifies a 1-ULP difference by 1/cos(pitch) near the poles."""
+    against the oracle: EVERY entry of every transform bit-exact.  sinf / cosf / acosf / asinf / atan2f are pinned on both
+    sides as the correctly rounded float of the exact value (csrc/cr_trig.h; oracle: libm double + __float128), the rest
+    is float arithmetic in the reference's order."""
     n = 300
     scene = hrt.scenes.particle_scene(n, 32, 32, 1, subdiv=0)
     renderer.load_scene(scene)
@@ -503,20 +506,93 @@ def test_pose_instances_matches_oracle(hrt, oracle, renderer):
     nxt[2, :4] = -cur[2, :4]                                  # dot < 0: negated
     cur[3, :4] = nxt[3, :4] = np.float32([s, 0, s, 0]) * np.float32(1.0000002)   # |sinp| >= 1 after the placement shuffle
     cur[4, :4] = nxt[4, :4] = [0, 0, 1, 0]                    # identity as quatToEuler sees it
-    identical = total = 0
     for dur, frame, count, off, sc in ((0.5, 0, 120, (0, 0, 0), (1, 1, 1)), (0.5, 59, 120, (0, 0, 0), (1, 1, 1)),
                                        (0.5, 119, 120, (0.1, 0.2, -0.3), (1.5, 0.5, 2.0)), (2.0, 0, 1, (0, 0, 0), (1, 1, 1))):
         renderer.pose_instances(cur, nxt, dur, frame, count, first_instance=1, offset=off, scale=sc, update=False)
         got = renderer.instance_transforms()
         want = oracle.pose_transforms(cur, nxt, dur, frame, count, off, sc)
         assert np.array_equal(got[0], scene["instances"][0]["transform"])           # the extra geometry is not touched
-        g, w = got[1:].reshape(n, 3, 4), want.reshape(n, 3, 4)
-        assert np.array_equal(g[:, :, 3].view(np.uint32), w[:, :, 3].view(np.uint32)), "translation must be bit-exact"
-        err = np.abs(g[:, :, :3] - w[:, :, :3])
-        assert err.max() <= 1e-5 and np.median(err) <= 2e-7
-        identical += int((g.view(np.uint32) == w.view(np.uint32)).sum())
-        total += g.size
-    assert identical / total > 0.8, identical / total        # measured: 85 % of the entries are the same bits
+        assert np.array_equal(got[1:].view(np.uint32), want.view(np.uint32)), (dur, frame, count)
+    # many more particles, arbitrary unit quaternions
+    rng = np.random.default_rng(17)
+    n2 = 20000
+    scene = hrt.scenes.particle_scene(n2, 32, 32, 1, subdiv=0)
+    renderer.load_scene(scene)
+    cur, nxt = hrt.scenes.particle_states(n2, 0), hrt.scenes.particle_states(n2, 1)
+    for st in (cur, nxt):
+        q = rng.normal(size=(n2, 4))
+        st[:, :4] = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    for frame in (0, 7, 29):
+        renderer.pose_instances(cur, nxt, 0.25, frame, 30, first_instance=1, update=False)
+        want = oracle.pose_transforms(cur, nxt, 0.25, frame, 30)
+        assert np.array_equal(renderer.instance_transforms()[1:].view(np.uint32), want.view(np.uint32)), frame
+
+
+def _gpu_trig(hrt, r, which, a=None, b=None, first=0, stride=1, count=0, slow=False):
+    import torch
+    if a is not None:
+        ta = torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(r.device)
+        tb = torch.from_numpy(np.ascontiguousarray(b, np.float32)).to(r.device) if b is not None else None
+        count = ta.numel()
+    else:
+        ta = tb = None
+    out = torch.empty(count, dtype=torch.float32, device=r.device)
+    r._check(r.lib.hrt_debug_trig(r.ctx, which, ta.data_ptr() if ta is not None else None, tb.data_ptr() if tb is not None else None,
+                                  first, stride, count, int(slow), out.data_ptr(), r._stream()), "hrt_debug_trig")
+    return out.cpu().numpy()
+
+
+def test_trig_pin_every_float_on_the_gpu(hrt, oracle, gpu_available):
+    """The pose kernel's sinf / cosf over ALL 2^32 float bit patterns, acosf / asinf over every float in [-1, 1] (and a strided
+    sweep of the rest: NaN), atan2f over 20 M pairs: the device's values (ocml double + the double-double slow path of
+    csrc/cr_trig.h) are the oracle's (libm double + __float128) bit for bit.  Then strided sweeps with every value forced
+    through the slow path."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    from test_pose_cpu import atan2_test_pairs, _same_bits
+    r = hrt.Renderer(0, 0)
+    try:
+        chunk = 1 << 26
+        ref = np.empty(chunk, np.float32)
+        for which in (oracle.TRIG_SIN, oracle.TRIG_COS):
+            for first in range(0, 1 << 32, chunk):
+                got = _gpu_trig(hrt, r, which, first=first, count=chunk)
+                assert _same_bits(got, oracle.trig_bits(which, first, 1, chunk, out=ref)), (which, hex(first))
+        for which in (oracle.TRIG_ACOS, oracle.TRIG_ASIN):
+            for sign in (0, 0x80000000):
+                for first in range(0, 0x3F800000 + 1, chunk):
+                    n = min(chunk, 0x3F800000 + 1 - first)
+                    got = _gpu_trig(hrt, r, which, first=sign + first, count=n)
+                    assert _same_bits(got, oracle.trig_bits(which, sign + first, 1, n, out=ref)), (which, hex(sign + first))
+            got = _gpu_trig(hrt, r, which, first=0, stride=1021, count=(1 << 32) // 1021)
+            assert _same_bits(got, oracle.trig_bits(which, 0, 1021, (1 << 32) // 1021)), which
+        y, x = atan2_test_pairs(20_000_000, 11)
+        assert _same_bits(_gpu_trig(hrt, r, oracle.TRIG_ATAN2, y, x), oracle.trig(oracle.TRIG_ATAN2, y, x))
+        # every value through the double-double path
+        for which in (oracle.TRIG_SIN, oracle.TRIG_COS):
+            got = _gpu_trig(hrt, r, which, first=0, stride=61, count=(1 << 32) // 61, slow=True)
+            assert _same_bits(got, oracle.trig_bits(which, 0, 61, (1 << 32) // 61)), which
+        for which in (oracle.TRIG_ACOS, oracle.TRIG_ASIN):
+            for sign in (0, 0x80000000):
+                n = 0x3F800000 // 17 + 1
+                got = _gpu_trig(hrt, r, which, first=sign, stride=17, count=n, slow=True)
+                assert _same_bits(got, oracle.trig_bits(which, sign, 17, n)), (which, sign)
+        y, x = atan2_test_pairs(4_000_000, 12)
+        assert _same_bits(_gpu_trig(hrt, r, oracle.TRIG_ATAN2, y, x, slow=True), oracle.trig(oracle.TRIG_ATAN2, y, x))
+    finally:
+        r.close()
+
+
+def _mesh_mode_transforms(oracle, velocities, dur, frame, count, off, sc):
+    """Mesh mode's update on the oracle side (RendererMesh.cu:379-391): shift = offset + (velocity * duration / frames) * frame,
+    rotation (0, 0, 0), through the oracle's constructTransformMatrix."""
+    f = np.float32
+    out = np.zeros((len(velocities), 12), np.float32)
+    for i, vel in enumerate(np.asarray(velocities, np.float32)):
+        per_frame = ((vel * f(dur)).astype(f) / f(count)).astype(f)
+        shift = (np.asarray(off, f) + (per_frame * f(frame)).astype(f)).astype(f)
+        out[i] = oracle.construct_transform(shift, (0, 0, 0), sc)
+    return out
 
 
 def test_pose_instances_mesh_mode(hrt, oracle, renderer):
@@ -553,10 +629,9 @@ def test_time_mode_frames_pose_refit_render(hrt, oracle, renderer):
         for frame in (0, 3, 5):
             renderer.pose_instances(steps[step], steps[step + 1], 0.05, frame, 6, first_instance=1)
             renderer.render(1)
-            xf = renderer.instance_transforms()
             want = oracle.pose_transforms(steps[step], steps[step + 1], 0.05, frame, 6)
-            assert np.abs(xf[1:] - want).max() <= 1e-5
-            for it, m in zip(scene["instances"], xf):
+            assert np.array_equal(renderer.instance_transforms()[1:].view(np.uint32), want.view(np.uint32))
+            for it, m in zip(scene["instances"][1:], want):
                 it["transform"] = m.copy()
             ref = oracle.OracleScene(scene).render(w, h, states, 1)
             assert np.array_equal(renderer.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32)), (step, frame)
@@ -568,7 +643,8 @@ def test_real_data_time_mode_frames(hrt, oracle, renderer):
     """The reference's shipped sample (tests/golden/files: config.json, STL shapes, particle VTK steps, series) through
     the whole chain: readers -> scene as RendererTime::commitRendererData assembles it -> per frame pose kernel,
     updateIAS (refit), launch.  Window reduced to 300x200 (config: 1200x800) so the scalar oracle finishes in seconds;
-    every frame bit-exact against the oracle rendering with the transforms the pose kernel produced."""
+    every frame bit-exact against the oracle rendering with its OWN transforms (oracle.pose_transforms), which the pose
+    kernel's equal bit for bit."""
     import importlib
     from pathlib import Path
     io = importlib.import_module("nvidia-optix-ray-tracer_amd.io")
@@ -588,9 +664,10 @@ def test_real_data_time_mode_frames(hrt, oracle, renderer):
         xf = renderer.instance_transforms()
         want = oracle.pose_transforms(cur, nxt, float(tm["durations"][file_index]), frame, tm["frame_counts"][file_index],
                                       cfg["particle-shift"], cfg["particle-scale"])
-        assert np.abs(xf[1:] - want).max() <= 1e-5
+        n_extra = tm["n_extra"]
+        assert np.array_equal(xf[n_extra:].view(np.uint32), want.view(np.uint32))
         assert np.array_equal(xf[0], scene["instances"][0]["transform"])
-        for it, m in zip(scene["instances"], xf):
+        for it, m in zip(scene["instances"][n_extra:], want):
             it["transform"] = m.copy()
         ref = oracle.OracleScene(scene).render(w, h, states, 1)
         assert np.array_equal(renderer.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32)), (file_index, frame)
@@ -632,7 +709,10 @@ def test_mesh_mode_frames_and_cpp_driver(hrt, oracle, gpu_available, tmp_path):
                 r.render(1)
                 xf = r.instance_transforms()
                 assert np.array_equal(xf[0], scene["instances"][0]["transform"])
-                for it, m in zip(scene["instances"], xf):
+                want = _mesh_mode_transforms(oracle, mm["velocities"][k], float(mm["durations"][k]), frame, mm["frame_counts"][k],
+                                             cfg["particle-shift"], cfg["particle-scale"])
+                assert np.array_equal(xf[n_extra:].view(np.uint32), want.view(np.uint32))
+                for it, m in zip(scene["instances"][n_extra:], want):      # the oracle renders from its own transforms
                     it["transform"] = m.copy()
                 ref = oracle.OracleScene(scene).render(w, h, states, 1)
                 assert np.array_equal(r.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32)), (k, frame)

@@ -186,3 +186,106 @@ def test_pose_golden_vectors(oracle):
         got = oracle.pose_transforms(cur, nxt, case["duration"], case["frame"], case["frame_count"], case["offset"], case["scale"])
         want = np.array(case["transforms_hex"], dtype=np.uint32).view(np.float32).reshape(-1, 12)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ---- the correctly rounded sinf / cosf / acosf / asinf / atan2f pin (csrc/cr_trig.h on the product side) ----
+def _host_trig():
+    """Host compile of the product's csrc/cr_trig.h (tests/helpers/cr_trig_host.cpp)."""
+    import ctypes as C
+    import subprocess
+    src = Path(__file__).resolve().parent / "helpers" / "cr_trig_host.cpp"
+    so = src.with_name("libcr_trig_host.so")
+    hdrs = [src.parents[2] / "nvidia-optix-ray-tracer_amd" / "csrc" / h for h in ("cr_trig.h", "srgb_pow.h")]
+    if not so.exists() or so.stat().st_mtime < max(f.stat().st_mtime for f in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", str(src), "-o", str(so)])
+    H = C.CDLL(str(so))
+    H.host_trig.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+    H.host_trig_bits.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]
+    return H
+
+
+def _same_bits(a, b):
+    return np.array_equal(a.view(np.uint32)[~(np.isnan(a) & np.isnan(b))], b.view(np.uint32)[~(np.isnan(a) & np.isnan(b))])
+
+
+def atan2_test_pairs(n, seed):
+    """(y, x) pairs for atan2: arbitrary bit patterns, comparable magnitudes, the axes, tiny and huge ratios, signed zeros."""
+    rng = np.random.default_rng(seed)
+    y = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32).copy()
+    x = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32).copy()
+    q = n // 4
+    y[:q] = rng.normal(size=q).astype(np.float32); x[:q] = rng.normal(size=q).astype(np.float32)
+    y[q:2 * q] = (rng.normal(size=q) * 10.0 ** rng.uniform(-30, 30, q)).astype(np.float32)
+    x[q:2 * q] = (rng.normal(size=q) * 10.0 ** rng.uniform(-30, 30, q)).astype(np.float32)
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 3.4e38, -3.4e38, 1e-30, 0.5], np.float32)
+    sy, sx = np.meshgrid(special, special)
+    k = sy.size
+    y[2 * q:2 * q + k] = sy.ravel(); x[2 * q:2 * q + k] = sx.ravel()
+    return y, x
+
+
+def test_trig_pin_host_compile_of_the_product_header_matches_the_oracle(oracle):
+    """sinf / cosf / acosf / asinf / atan2f of the pose pipeline are pinned on both sides as the correctly rounded float.  The
+    oracle gets there with libm doubles + __float128, the product (csrc/cr_trig.h) with the platform's double function + a
+    double-double slow path.  Sweeps over bit patterns of ALL floats (strided), dense in [-1, 1] for the inverse functions,
+    for the normal path AND with every value forced through the slow path (which in production one call in ~500 000 takes)."""
+    H = _host_trig()
+    for which in (oracle.TRIG_SIN, oracle.TRIG_COS):
+        for slow, stride in ((0, 509), (1, 8191)):
+            count = (1 << 32) // stride
+            got = np.empty(count, np.float32)
+            H.host_trig_bits(which, 0, stride, count, slow, got.ctypes.data)
+            assert _same_bits(got, oracle.trig_bits(which, 0, stride, count)), (which, slow)
+        # the pose pipeline's own range, densely: |x| <= 4
+        for sign in (0, 0x80000000):
+            for slow, stride in ((0, 127), (1, 2039)):
+                count = 0x40800000 // stride
+                got = np.empty(count, np.float32)
+                H.host_trig_bits(which, sign, stride, count, slow, got.ctypes.data)
+                assert _same_bits(got, oracle.trig_bits(which, sign, stride, count)), (which, sign, slow)
+    for which in (oracle.TRIG_ACOS, oracle.TRIG_ASIN):
+        for sign in (0, 0x80000000):
+            for slow, stride in ((0, 127), (1, 2039)):
+                count = 0x3F800000 // stride + 1
+                got = np.empty(count, np.float32)
+                H.host_trig_bits(which, sign, stride, count, slow, got.ctypes.data)
+                assert _same_bits(got, oracle.trig_bits(which, sign, stride, count)), (which, sign, slow)
+        ends = np.array([1.0, -1.0, 0.99999994, -0.99999994, 1.0000001, 0.0, -0.0, 1e-45, 2.0, np.nan], np.float32)
+        for slow in (0, 1):
+            got = np.empty_like(ends)
+            H.host_trig(which, ends.ctypes.data, None, ends.size, slow, got.ctypes.data)
+            assert _same_bits(got, oracle.trig(which, ends)), (which, slow)
+    for slow, n in ((0, 1_000_000), (1, 200_000)):
+        y, x = atan2_test_pairs(n, 5)
+        got = np.empty(n, np.float32)
+        H.host_trig(oracle.TRIG_ATAN2, y.ctypes.data, x.ctypes.data, n, slow, got.ctypes.data)
+        assert _same_bits(got, oracle.trig(oracle.TRIG_ATAN2, y, x)), slow
+
+
+def test_trig_pin_is_the_nearest_float_and_libm_is_within_an_ulp(oracle):
+    """(1) The oracle's shortcut (libm double, __float128 only near a midpoint) gives the value decided in __float128
+    everywhere sampled, (2) known answers, (3) the platform's float libm -- what a build of the reference would call -- is
+    within 1 ULP of the pin on the pose pipeline's ranges (tolerance cross-check; it is NOT what parity is defined on)."""
+    stride = 4099
+    count = (1 << 32) // stride
+    for which in (oracle.TRIG_SIN, oracle.TRIG_COS, oracle.TRIG_ACOS, oracle.TRIG_ASIN):
+        assert _same_bits(oracle.trig_bits(which, 0, stride, count), oracle.trig_bits(which, 0, stride, count, force_exact=True)), which
+    y, x = atan2_test_pairs(200_000, 9)
+    assert _same_bits(oracle.trig(oracle.TRIG_ATAN2, y, x), oracle.trig(oracle.TRIG_ATAN2, y, x, force_exact=True))
+    f = np.float32
+    pi = f(np.pi)
+    assert oracle.trig(oracle.TRIG_SIN, [0.0])[0] == 0 and oracle.trig(oracle.TRIG_COS, [0.0])[0] == 1
+    assert oracle.trig(oracle.TRIG_ACOS, [1.0])[0] == 0 and oracle.trig(oracle.TRIG_ACOS, [-1.0])[0] == pi
+    assert oracle.trig(oracle.TRIG_ASIN, [1.0])[0] == f(np.pi / 2) and oracle.trig(oracle.TRIG_ACOS, [0.0])[0] == f(np.pi / 2)
+    assert oracle.trig(oracle.TRIG_ATAN2, [0.0], [-1.0])[0] == pi and oracle.trig(oracle.TRIG_ATAN2, [1.0], [1.0])[0] == f(np.pi / 4)
+    assert oracle.trig(oracle.TRIG_ATAN2, [-1.0], [0.0])[0] == f(-np.pi / 2)
+    rng = np.random.default_rng(2)
+    ang = rng.uniform(-4, 4, 200_000).astype(np.float32)
+    unit = rng.uniform(-1, 1, 200_000).astype(np.float32)
+
+    def ulps(a, b):
+        return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64)).max()
+    for which, arg in ((oracle.TRIG_SIN, ang), (oracle.TRIG_COS, ang), (oracle.TRIG_ACOS, unit), (oracle.TRIG_ASIN, unit)):
+        assert ulps(oracle.trig(which, arg), oracle.trig(which, arg, libm=True)) <= 1, which
+    yy, xx = rng.normal(size=200_000).astype(np.float32), rng.normal(size=200_000).astype(np.float32)
+    assert ulps(oracle.trig(oracle.TRIG_ATAN2, yy, xx), oracle.trig(oracle.TRIG_ATAN2, yy, xx, libm=True)) <= 1
