@@ -164,6 +164,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_SUBSTREAM_MIN_PIXELS")) { const int v = std::atoi(e); if (v >= 1024) ctx->substream_min_pixels = v; }
     if (const char *e = std::getenv("HRT_SUBSTREAMS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) ctx->substreams = v; }
     if (const char *e = std::getenv("HRT_FUSED_MAX_DEPTH")) { const int v = std::atoi(e); if (v >= 0 && v <= kFusedMaxDepth) ctx->fused_max_depth = v; }
+    if (const char *e = std::getenv("HRT_FUSED_MAX_BYTES")) { const unsigned long long v = std::strtoull(e, nullptr, 0); if (v >= 1 && v <= (1ull << 32)) ctx->fused_max_bytes = v; }
     if (const char *e = std::getenv("HRT_TAIL_REGEN")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->fused_tail_regen = v; }
     if (const char *e = std::getenv("HRT_LEAF_QUORUM")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->leaf_quorum = v; }
     if (const char *e = std::getenv("HRT_POSTPONE_PCT")) { const int v = std::atoi(e); if (v >= 0 && v <= 100) { ctx->postpone_pct = v; ctx->fused_postpone_pct = v; } }
@@ -259,8 +260,8 @@ int hrt_rng_free(HrtContext *ctx, HrtRngState *d_states, void *stream) {
 // k_fused (fused.hip) keeps one sibling group per tree level in LDS without an overflow path and addresses the records with
 // 32-bit byte offsets; a tree outside either limit takes round 1's fused kernel (kernels.hip), which has neither.
 static bool fits_fused_kernel(const HrtContext *ctx, const Tlas &t) {
-    return t.max_depth <= (uint32_t)ctx->fused_max_depth && (uint64_t)t.n_nodes * t.node_stride < (1ull << 32) &&
-           (uint64_t)std::max(t.n_prims, 1u) * t.prim_stride < (1ull << 32);
+    return t.max_depth <= (uint32_t)ctx->fused_max_depth && (uint64_t)t.n_nodes * t.node_stride < ctx->fused_max_bytes &&
+           (uint64_t)std::max(t.n_prims, 1u) * t.prim_stride < ctx->fused_max_bytes;
 }
 static int refresh_tables(HrtContext *ctx, uint64_t handle, Tlas *t, hipStream_t s) {
     if (ctx->table_tlas == handle && ctx->table_tlas_gen == t->generation && ctx->table_mat_gen == ctx->materials_generation) return HRT_OK;
@@ -365,6 +366,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         // k_fused keeps one sibling group per tree level in LDS and has no overflow path: deeper trees take round 1's kernel
         const bool lean = v1 && ctx->fused != 2 && fits_fused_kernel(ctx, *t);
         if (lean) ta.postpone_pct = ctx->fused_postpone_pct;
+        else if (v1 && ctx->fused != 2) ctx->fused_fallback_launches++;        // the tree does not fit k_fused
         uint32_t blocks_per_cu = lean ? std::min<uint32_t>((uint32_t)ctx->fused_blocks_per_cu, (uint32_t)kFusedBlocksPerCu)
                                : v1 ? (uint32_t)ctx->fused_blocks_per_cu : std::min<uint32_t>((uint32_t)ctx->paths_blocks_per_cu, paths_blocks_that_fit(ctx->paths_slots));
         if (!v1) { ta.refill_threshold = ctx->paths_exchange_threshold; pa.shade_threshold = ctx->paths_shade_threshold; pa.low_water = ctx->paths_low_water; pa.min_batch = ctx->paths_min_batch; }
@@ -636,6 +638,7 @@ int hrt_stats_get(HrtContext *ctx, HrtStats *out) {
         out->bvh_bytes = (uint64_t)tl.n_nodes * sizeof(Bvh8Node) + (uint64_t)tl.n_prims * sizeof(PrimRecord);
         out->bvh_alloc_bytes = tl.alloc_bytes;
     }
+    out->fused_fallback_launches = ctx->fused_fallback_launches;
     return HRT_OK;
 }
 
@@ -672,6 +675,7 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
         pa.rays_closest = &ctx->d_stats->rays_closest; pa.rays_any = &ctx->d_stats->rays_any;
         const bool lean = ctx->fused != 2 && fits_fused_kernel(ctx, *t);
         if (lean) ta.postpone_pct = ctx->fused_postpone_pct;
+        else if (ctx->fused != 2) ctx->fused_fallback_launches++;
         const uint32_t blocks_per_cu = lean ? std::min<uint32_t>((uint32_t)ctx->fused_blocks_per_cu, (uint32_t)kFusedBlocksPerCu) : (uint32_t)ctx->fused_blocks_per_cu;
         const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * blocks_per_cu, (n_rays + 63u) / 64u);
         Timer tm(ctx, s, HRT_K_PATHS);

@@ -179,6 +179,18 @@ def soup_1m(width=1920, height=1080, spp=256):
     return random_soup(1_000_000, 0.014, 2, width, height, spp, "C4-soup-1M")
 
 
+def soup_law_edge(n_triangles):
+    """Edge scale of the soup law C3 / C4 follow: constant expected overlap, edge ~ n^(-1/3) (0.03 at 100 k, 0.014 at 1 M)."""
+    return round(0.03 * (1.0e5 / n_triangles) ** (1.0 / 3.0), 4)
+
+
+def soup_large(n_triangles, width=1920, height=1080, spp=16):
+    """C4's law at 8 M / 32 M triangles: tree + records exceed the 256 MiB Infinity Cache (the out-of-cache datapoints
+    of profiles/r03_large_scenes.txt).  Seed = 2 + log2(n / 1 M)."""
+    seed = 2 + max(0, int(round(np.log2(n_triangles / 1.0e6))))
+    return random_soup(n_triangles, soup_law_edge(n_triangles), seed, width, height, spp, f"soup-{n_triangles // 1_000_000}M")
+
+
 def soup_1m_8mat(width=1920, height=1080, spp=1024, n_triangles=1_000_000):
     """C5: the C4 geometry dealt round-robin into 8 instances: 4 rough (config.json albedos) +
     4 metal (fuzz 0, 0.1, 0.3, 0.5; albedo 0.8, 0.85, 0.88).  The reference has neither glass nor

@@ -1188,6 +1188,78 @@ def test_deep_trees_at_and_beyond_the_path_kernels_node_stack(hrt, oracle, gpu_a
         assert depths == [12, 13], depths          # = kFusedMaxDepth and one more: both kernels ran
 
 
+def test_record_arrays_beyond_32_bit_offsets_take_round_ones_kernel(hrt, oracle, gpu_available, monkeypatch):
+    """k_fused addresses nodes and records by 32-bit byte offsets; arrays of 4 GiB and more take round 1's path kernel, which
+    uses 64-bit addresses (csrc/hrt_api.cpp: fits_fused_kernel).  HRT_FUSED_MAX_BYTES lowers the limit so that a small scene
+    drives that fallback: image, RNG states, ray count and hit records are the oracle's, and the fallback did run."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    monkeypatch.setenv("HRT_FUSED_MAX_BYTES", "65536")
+    r = hrt.Renderer(0, 0)
+    try:
+        w, h, spp = 96, 64, 2
+        scene = hrt.scenes.mixed_test_scene(6000, 40, 5, w, h, spp)
+        r.load_scene(scene)
+        assert r.stats().fused_fallback_launches == 0
+        _moved_scene_matches_oracle(hrt, oracle, r, scene, w, h, 23, spp)
+        st = r.stats()
+        assert st.bvh_bytes > 65536 and st.fused_fallback_launches >= 2          # the render and hrt_trace_rays
+        assert np.array_equal(r.rng_states_numpy(), _oracle_states_after(oracle, scene, w, h, 23, spp))
+    finally:
+        r.close()
+    monkeypatch.delenv("HRT_FUSED_MAX_BYTES")
+    r = hrt.Renderer(0, 0)
+    try:
+        r.load_scene(scene)
+        _moved_scene_matches_oracle(hrt, oracle, r, scene, w, h, 23, spp)
+        assert r.stats().fused_fallback_launches == 0
+    finally:
+        r.close()
+
+
+def _oracle_states_after(oracle, scene, w, h, salt, spp):
+    st = oracle.rng_init(w, h, salt)
+    oracle.OracleScene(scene).render(w, h, st, spp)
+    return st
+
+
+def test_eight_million_triangles_out_of_the_infinity_cache(hrt, oracle, gpu_available):
+    """C4's law at 8 M triangles: 96 MB of nodes + 512 MB of records (+ 288 MB of normals) -- the tree no longer fits the 256 MiB
+    Infinity Cache, so the kernel's loads meet HBM (profiles/r03_large_scenes.txt has the rates).  Device build, then a row
+    subset of the 1920x1080 frame at 1 spp against the oracle (bit-exact, RNG states of the rendered rows included) and
+    5000 rays against the oracle's brute force over all 8 M triangles."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    W, H = 1920, 1080
+    scene = hrt.scenes.soup_large(8_000_000, W, H, 1)
+    r = hrt.Renderer(0, 0)
+    try:
+        r.load_scene(scene)
+        r.set_frame(W, H, hrt.scenes.SEED_SALT, aov=False, linear=True)
+        tile = hrt.Tile(7, H, 1, 45, 0)                        # rows 7, 52, 97, ...
+        rows = np.arange(7, H, 45, dtype=np.uint32)
+        r.reset_stats()
+        r.render(1, tile=tile)
+        st = r.stats()
+        assert st.bvh_triangles == 8_000_000 and st.bvh_bytes > 450e6 and st.fused_fallback_launches == 0
+        osc = oracle.OracleScene(scene)
+        states = oracle.rng_init(W, H, hrt.scenes.SEED_SALT)
+        ref = osc.render(W, H, states, 1, rows=rows)
+        assert st.rays == ref["rays"] and ref["rays"] > 2 * len(rows) * W
+        assert np.array_equal(r.linear.cpu().numpy()[rows].view(np.uint32), ref["linear"][rows].view(np.uint32))
+        assert np.array_equal(r.color.cpu().numpy()[rows].view(np.uint32), ref["color"][rows].view(np.uint32))
+        got_states = r.rng_states_numpy().reshape(H, W, 12)
+        assert np.array_equal(got_states[rows], states.reshape(H, W, 12)[rows])
+        o, d = oracle.random_rays(5000, 41)
+        t, u, v, prim, inst = r.trace_rays(o, d)
+        rt, ru, rv, rprim, rinst = oracle.OracleScene(scene, force_brute=True).trace(o, d)
+        assert (prim != 0xFFFFFFFF).sum() > 2500
+        assert np.array_equal(prim, rprim) and np.array_equal(inst, rinst)
+        assert np.array_equal(t.view(np.uint32), rt.view(np.uint32)) and np.array_equal(u.view(np.uint32), ru.view(np.uint32)) and np.array_equal(v.view(np.uint32), rv.view(np.uint32))
+    finally:
+        r.close()
+
+
 def test_cost_ordered_slices_bit_exact(hrt, oracle, gpu_available):
     """Few pixels per lane and many samples: the first samples run as a probe launch that measures the slices, the rest
     of the render hands the slices out slowest first.  The order is free -- image, RNG states and ray count are those of
