@@ -68,8 +68,10 @@ struct Bvh8 {
 // assignment -> outward-rounded 8-bit quantisation).  threads <= 0: hardware concurrency.
 // scene_scale > 0 overrides the largest |coordinate| the padding is derived from; max_leaf_prims (1..3) caps the
 // primitives per leaf slot (1 for the tree over instances, whose "primitives" are whole subtrees).
+// spatial_splits: SBVH -- a primitive may then be referenced from several leaves (one record each), each answering for the
+// part of it inside its leaf's box.
 void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads = 0, float scene_scale = 0.0f,
-                uint32_t max_leaf_prims = kMaxLeafPrims);
+                uint32_t max_leaf_prims = kMaxLeafPrims, bool spatial_splits = false);
 
 // A tree over instances: a top tree built over the instances' world boxes, whose leaf slots point at per-instance
 // copies of object-space template trees (one template per BLAS, shared by all its instances).  Only the TOPOLOGY is

@@ -3,7 +3,8 @@
 // Stands in for optixAccelBuild (reference: src/Global/RendererImpl.cu:30-88 buildASImpl,
 // :174-208 buildIAS).  OptiX's builder is closed; this one is:
 //   1. binned-SAH BVH2 over padded primitive bounds (16 bins x 3 axes) down to single primitives,
-//      big subtrees built on worker threads (topology does not depend on thread timing);
+//      big subtrees built on worker threads (topology does not depend on thread timing), optionally with
+//      spatial splits (SBVH: references cut by planes where that is cheaper, for static scenes);
 //   2. optimal SAH collapse to 8-wide nodes by dynamic programming (Ylitie, Karras, Laine 2017,
 //      sec. 4.1): C(n, i) = cheapest way to represent subtree n as a forest of at most i roots,
 //      c_node = 1, c_prim = 0.3, leaves <= 3 primitives.  (A first greedy version -- always open
@@ -26,10 +27,10 @@ namespace hrt {
 namespace {
 
 struct B2 {
-    float lo[3], hi[3];
+    float lo[3], hi[3];       // padded bounds of the references below
     uint32_t left, right;     // inner
-    uint32_t first, count;    // leaf when count > 0
-    uint32_t nprims;          // primitives in the subtree: idx[first, first + nprims)
+    uint32_t first, count;    // leaf when count > 0: ONE reference, first = its primitive
+    uint32_t nprims;          // references in the subtree
 };
 
 inline float half_area(const float *lo, const float *hi) {
@@ -37,115 +38,245 @@ inline float half_area(const float *lo, const float *hi) {
     return dx * dy + dy * dz + dz * dx;
 }
 
+// A reference: a primitive and the (unpadded) box of the part of it this subtree is responsible for.  Without spatial splits
+// that is the primitive's own box and every primitive has one reference.
+struct Ref { uint32_t prim; float lo[3], hi[3]; };
+
+constexpr float kInfF = std::numeric_limits<float>::infinity();
+
+struct Box3 {
+    float lo[3] = {kInfF, kInfF, kInfF}, hi[3] = {-kInfF, -kInfF, -kInfF};
+    void grow(const float *l, const float *h) { for (int c = 0; c < 3; ++c) { lo[c] = std::min(lo[c], l[c]); hi[c] = std::max(hi[c], h[c]); } }
+    void grow(const Box3 &b) { grow(b.lo, b.hi); }
+    bool valid() const { return lo[0] <= hi[0]; }
+    float area() const { return valid() ? half_area(lo, hi) : 0.0f; }
+};
+
 struct Builder {
     const std::vector<BuildPrim> &in;
-    std::vector<float> plo, phi, cen;   // padded bounds + centroid, 3 per prim
-    std::vector<uint32_t> idx;
+    float pad = 0.0f;
     std::vector<B2> nodes;
     std::atomic<uint32_t> n_nodes{0};
     int max_par_depth = 0;
-    bool split_to_single = true;      // build the BVH2 down to one primitive per leaf and let the collapse form the leaves (+7 %)
+    // spatial splits (Stich, Friedrich, Dietrich 2009, "Spatial splits in bounding volume hierarchies"): a node may cut its
+    // references with an axis-aligned plane instead of partitioning them -- a reference that straddles the plane goes to both
+    // sides with its box clipped -- when that is cheaper by the SAH and the object split's children overlap enough.  Duplicate
+    // references are harmless to the canonical closest hit (min t, then min (instance, primitive)).
+    bool spatial = false;
+    int n_bins = 16;                     // object-split bins per axis
+    float alpha = 1e-5f;                 // spatial splits are tried when area(left ∩ right) / area(root) exceeds this
+    float root_area = 0.0f;
+    std::atomic<int64_t> budget{0};      // references the spatial splits may still add
 
     explicit Builder(const std::vector<BuildPrim> &p) : in(p) {}
 
     uint32_t alloc2() { return n_nodes.fetch_add(2); }
 
-    void bounds_of(uint32_t b, uint32_t e, float *lo, float *hi, float *clo, float *chi) const {
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = clo[a] = std::numeric_limits<float>::infinity();
-            hi[a] = chi[a] = -std::numeric_limits<float>::infinity();
+    // bounds of the part of reference r between the planes x[a] = p0 and x[a] = p1: the triangle clipped to the reference's box
+    // and the slab (Sutherland-Hodgman, double arithmetic, rounded outwards by one float ULP); other primitives: box ∩ slab
+    void clip_ref(const Ref &r, int a, float p0, float p1, float *lo, float *hi) const {
+        const BuildPrim &bp = in[r.prim];
+        float blo[3], bhi[3];
+        for (int c = 0; c < 3; ++c) { blo[c] = r.lo[c]; bhi[c] = r.hi[c]; }
+        blo[a] = std::max(blo[a], p0); bhi[a] = std::min(bhi[a], p1);
+        if (bp.rec.kind != kPrimKindTriangle) { for (int c = 0; c < 3; ++c) { lo[c] = blo[c]; hi[c] = bhi[c]; } return; }
+        double poly[2][16][3]; int np = 3, cur = 0;
+        for (int c = 0; c < 3; ++c) {
+            poly[0][0][c] = bp.rec.a[c];
+            poly[0][1][c] = (double)bp.rec.a[c] + (double)bp.rec.b[c];
+            poly[0][2][c] = (double)bp.rec.a[c] + (double)bp.rec.c[c];
         }
-        for (uint32_t i = b; i < e; ++i) {
-            const uint32_t p = idx[i];
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = std::min(lo[a], plo[3 * p + a]);
-                hi[a] = std::max(hi[a], phi[3 * p + a]);
-                clo[a] = std::min(clo[a], cen[3 * p + a]);
-                chi[a] = std::max(chi[a], cen[3 * p + a]);
+        // (the record keeps v0, e1, e2 in float: v1 = v0 + e1 in double is the vertex to within half an ULP, which the outward
+        // rounding and the padding below cover)
+        for (int c = 0; c < 3 && np > 0; ++c)
+            for (int side = 0; side < 2 && np > 0; ++side) {
+                const double plane = side == 0 ? (double)blo[c] : (double)bhi[c];
+                const double sgn = side == 0 ? 1.0 : -1.0;
+                int nq = 0;
+                for (int i = 0; i < np; ++i) {
+                    const double *u = poly[cur][i], *v = poly[cur][(i + 1) % np];
+                    const double du = sgn * (u[c] - plane), dv = sgn * (v[c] - plane);
+                    if (du >= 0.0) { for (int k = 0; k < 3; ++k) poly[cur ^ 1][nq][k] = u[k]; ++nq; }
+                    if ((du > 0.0 && dv < 0.0) || (du < 0.0 && dv > 0.0)) {
+                        const double t = du / (du - dv);
+                        for (int k = 0; k < 3; ++k) poly[cur ^ 1][nq][k] = k == c ? plane : u[k] + t * (v[k] - u[k]);
+                        ++nq;
+                    }
+                }
+                np = nq; cur ^= 1;
             }
+        if (np == 0) { for (int c = 0; c < 3; ++c) { lo[c] = blo[c]; hi[c] = bhi[c]; } return; }      // (numerically empty: stay conservative)
+        for (int c = 0; c < 3; ++c) {
+            double l = poly[cur][0][c], h = l;
+            for (int i = 1; i < np; ++i) { l = std::min(l, poly[cur][i][c]); h = std::max(h, poly[cur][i][c]); }
+            float fl = (float)l, fh = (float)h;
+            fl = std::nextafter(fl, -kInfF); fh = std::nextafter(fh, kInfF);
+            lo[c] = std::max(blo[c], fl); hi[c] = std::min(bhi[c], fh);
+            if (lo[c] > hi[c]) { lo[c] = blo[c]; hi[c] = bhi[c]; }
         }
     }
 
-    void build(uint32_t node, uint32_t b, uint32_t e, int depth) {
-        B2 &n = nodes[node];
-        float clo[3], chi[3];
-        bounds_of(b, e, n.lo, n.hi, clo, chi);
-        const uint32_t cnt = e - b;
-        n.left = n.right = 0; n.first = b; n.count = 0; n.nprims = cnt;
-        if (cnt == 1) { n.count = 1; return; }
+    void build(uint32_t node, std::vector<Ref> refs, int depth) {
+        const uint32_t cnt = (uint32_t)refs.size();
+        Box3 nb, cb;
+        for (const Ref &r : refs) {
+            nb.grow(r.lo, r.hi);
+            float c3[3]; for (int c = 0; c < 3; ++c) c3[c] = 0.5f * (r.lo[c] + r.hi[c]);
+            cb.grow(c3, c3);
+        }
+        {
+            B2 &n = nodes[node];
+            for (int c = 0; c < 3; ++c) { n.lo[c] = nb.lo[c] - pad; n.hi[c] = nb.hi[c] + pad; }
+            n.left = n.right = 0; n.first = refs[0].prim; n.count = 0; n.nprims = cnt;
+            if (cnt == 1) { n.count = 1; return; }
+        }
+        const float *clo = cb.lo, *chi = cb.hi;
 
-        constexpr int NB = 16;
-        float best_cost = std::numeric_limits<float>::infinity();
+        // ---- object split: binned SAH over the reference centroids (16 bins x 3 axes), boxes padded ----
+        constexpr int NBMAX = 64; const int NB = n_bins;
+        float best_cost = kInfF;
         int best_axis = -1, best_bin = -1;
+        Box3 best_l, best_r;
         for (int a = 0; a < 3; ++a) {
             const float ext = chi[a] - clo[a];
             if (!(ext > 0.0f)) continue;
             const float scale = (float)NB / ext;
-            uint32_t bc[NB] = {0};
-            float blo[NB][3], bhi[NB][3];
-            for (int k = 0; k < NB; ++k)
-                for (int c = 0; c < 3; ++c) { blo[k][c] = std::numeric_limits<float>::infinity(); bhi[k][c] = -blo[k][c]; }
-            for (uint32_t i = b; i < e; ++i) {
-                const uint32_t p = idx[i];
-                int k = (int)((cen[3 * p + a] - clo[a]) * scale);
+            uint32_t bc[NBMAX] = {0};
+            Box3 bb[NBMAX];
+            for (const Ref &r : refs) {
+                int k = (int)((0.5f * (r.lo[a] + r.hi[a]) - clo[a]) * scale);
                 k = std::min(std::max(k, 0), NB - 1);
                 bc[k]++;
-                for (int c = 0; c < 3; ++c) { blo[k][c] = std::min(blo[k][c], plo[3 * p + c]); bhi[k][c] = std::max(bhi[k][c], phi[3 * p + c]); }
+                float l[3], h[3]; for (int c = 0; c < 3; ++c) { l[c] = r.lo[c] - pad; h[c] = r.hi[c] + pad; }
+                bb[k].grow(l, h);
             }
-            float racc_lo[3], racc_hi[3], rarea[NB]; uint32_t rcnt[NB];
-            for (int c = 0; c < 3; ++c) { racc_lo[c] = std::numeric_limits<float>::infinity(); racc_hi[c] = -racc_lo[c]; }
-            uint32_t rc = 0;
+            Box3 racc[NBMAX]; float rarea[NBMAX]; uint32_t rcnt[NBMAX];
+            Box3 acc; uint32_t rc = 0;
             for (int k = NB - 1; k > 0; --k) {
                 rc += bc[k];
-                for (int c = 0; c < 3; ++c) { racc_lo[c] = std::min(racc_lo[c], blo[k][c]); racc_hi[c] = std::max(racc_hi[c], bhi[k][c]); }
-                rcnt[k] = rc; rarea[k] = rc ? half_area(racc_lo, racc_hi) : 0.0f;
+                if (bb[k].valid()) acc.grow(bb[k]);
+                racc[k] = acc; rcnt[k] = rc; rarea[k] = rc ? half_area(acc.lo, acc.hi) : 0.0f;
             }
-            float lacc_lo[3], lacc_hi[3];
-            for (int c = 0; c < 3; ++c) { lacc_lo[c] = std::numeric_limits<float>::infinity(); lacc_hi[c] = -lacc_lo[c]; }
-            uint32_t lc = 0;
+            Box3 lacc; uint32_t lc = 0;
             for (int k = 0; k < NB - 1; ++k) {
                 lc += bc[k];
-                for (int c = 0; c < 3; ++c) { lacc_lo[c] = std::min(lacc_lo[c], blo[k][c]); lacc_hi[c] = std::max(lacc_hi[c], bhi[k][c]); }
+                if (bb[k].valid()) lacc.grow(bb[k]);
                 if (lc == 0 || rcnt[k + 1] == 0) continue;
-                const float cost = half_area(lacc_lo, lacc_hi) * (float)lc + rarea[k + 1] * (float)rcnt[k + 1];
-                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
+                const float cost = half_area(lacc.lo, lacc.hi) * (float)lc + rarea[k + 1] * (float)rcnt[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; best_l = lacc; best_r = racc[k + 1]; }
             }
         }
 
-        if (cnt <= kMaxLeafPrims && !split_to_single) {
-            // leaf unless splitting is clearly cheaper (c_prim = 0.3, c_inner = 0.5)
-            const float area = half_area(n.lo, n.hi);
-            const float split_cost = best_axis >= 0 && area > 0.0f ? 0.3f * best_cost / area + 0.5f
-                                                                    : std::numeric_limits<float>::infinity();
-            if (!(split_cost < 0.3f * (float)cnt)) { n.count = cnt; return; }
+        // ---- spatial split candidate ----
+        int sp_axis = -1; float sp_pos = 0.0f, sp_cost = kInfF;
+        Box3 sp_l, sp_r; uint32_t sp_nl = 0, sp_nr = 0;
+        if (spatial && budget.load(std::memory_order_relaxed) > 0) {
+            bool try_spatial = best_axis < 0;
+            if (!try_spatial) {
+                float il[3], ih[3]; bool overlap = true;
+                for (int c = 0; c < 3; ++c) { il[c] = std::max(best_l.lo[c], best_r.lo[c]); ih[c] = std::min(best_l.hi[c], best_r.hi[c]); if (!(il[c] < ih[c])) overlap = false; }
+                try_spatial = overlap && half_area(il, ih) > alpha * root_area;
+            }
+            if (try_spatial) {
+                constexpr int NS = 32;
+                for (int a = 0; a < 3; ++a) {
+                    const float lo_a = nb.lo[a], ext = nb.hi[a] - nb.lo[a];
+                    if (!(ext > 0.0f)) continue;
+                    const float scale = (float)NS / ext, width = ext / (float)NS;
+                    Box3 bb[NS]; uint32_t enter[NS] = {0}, leave[NS] = {0};
+                    auto bin_of = [&](float x) { int k = (int)((x - lo_a) * scale); return std::min(std::max(k, 0), NS - 1); };
+                    for (const Ref &r : refs) {
+                        const int k0 = bin_of(r.lo[a]), k1 = bin_of(r.hi[a]);
+                        enter[k0]++; leave[k1]++;
+                        if (k0 == k1) { bb[k0].grow(r.lo, r.hi); continue; }
+                        for (int k = k0; k <= k1; ++k) {
+                            const float p0 = k == k0 ? -kInfF : lo_a + width * (float)k, p1 = k == k1 ? kInfF : lo_a + width * (float)(k + 1);
+                            float l[3], h[3];
+                            clip_ref(r, a, p0, p1, l, h);
+                            bb[k].grow(l, h);
+                        }
+                    }
+                    Box3 racc[NS]; uint32_t rcnt[NS];
+                    Box3 acc; uint32_t rc = 0;
+                    for (int k = NS - 1; k > 0; --k) { rc += leave[k]; if (bb[k].valid()) acc.grow(bb[k]); racc[k] = acc; rcnt[k] = rc; }
+                    Box3 lacc; uint32_t lc = 0;
+                    for (int k = 0; k < NS - 1; ++k) {
+                        lc += enter[k];
+                        if (bb[k].valid()) lacc.grow(bb[k]);
+                        if (lc == 0 || rcnt[k + 1] == 0 || !lacc.valid() || !racc[k + 1].valid()) continue;
+                        // padded areas, as everywhere
+                        float ll[3], lh[3], rl[3], rh[3];
+                        for (int c = 0; c < 3; ++c) { ll[c] = lacc.lo[c] - pad; lh[c] = lacc.hi[c] + pad; rl[c] = racc[k + 1].lo[c] - pad; rh[c] = racc[k + 1].hi[c] + pad; }
+                        const float cost = half_area(ll, lh) * (float)lc + half_area(rl, rh) * (float)rcnt[k + 1];
+                        if (cost < sp_cost && (lc < cnt || rcnt[k + 1] < cnt)) { sp_cost = cost; sp_axis = a; sp_pos = lo_a + width * (float)(k + 1); sp_l = lacc; sp_r = racc[k + 1]; sp_nl = lc; sp_nr = rcnt[k + 1]; }
+                    }
+                }
+            }
         }
 
-        uint32_t mid;
-        if (best_axis >= 0) {
-            const float ext = chi[best_axis] - clo[best_axis];
-            const float scale = (float)NB / ext;
-            const float c0 = clo[best_axis];
-            const int a = best_axis, bb = best_bin;
-            auto it = std::partition(idx.begin() + b, idx.begin() + e, [&](uint32_t p) {
-                int k = (int)((cen[3 * p + a] - c0) * scale);
-                k = std::min(std::max(k, 0), NB - 1);
-                return k <= bb;
-            });
-            mid = (uint32_t)(it - idx.begin());
-        } else {
-            mid = b + cnt / 2;      // all centroids coincide: split by index
+        std::vector<Ref> left, right;
+        bool done = false;
+        if (sp_axis >= 0 && sp_cost < best_cost) {
+            // ---- spatial split: references wholly on one side go there; a straddling one is cut, or -- when that is cheaper by
+            //      the SAH of the two children as they stand -- kept whole on one side ("reference unsplitting") ----
+            const int a = sp_axis;
+            // the two children as the binning pass found them (every straddling reference cut): B1, B2, N1, N2 of the paper's
+            // unsplitting test; a reference moved whole to one side grows that side's box and leaves the other's count
+            Box3 lb = sp_l, rb = sp_r; uint32_t nl = sp_nl, nr = sp_nr;
+            int64_t added = 0;
+            for (const Ref &r : refs) {
+                if (r.hi[a] <= sp_pos) { left.push_back(r); continue; }
+                if (r.lo[a] >= sp_pos) { right.push_back(r); continue; }
+                Box3 l_whole = lb, r_whole = rb;
+                l_whole.grow(r.lo, r.hi); r_whole.grow(r.lo, r.hi);
+                const float c_split = lb.area() * (float)nl + rb.area() * (float)nr;
+                const float c_left = l_whole.area() * (float)nl + rb.area() * (float)(nr - 1u);
+                const float c_right = lb.area() * (float)(nl - 1u) + r_whole.area() * (float)nr;
+                if (c_split <= c_left && c_split <= c_right) {
+                    Ref rl = r, rr = r;
+                    clip_ref(r, a, -kInfF, sp_pos, rl.lo, rl.hi);
+                    clip_ref(r, a, sp_pos, kInfF, rr.lo, rr.hi);
+                    left.push_back(rl); right.push_back(rr); ++added;
+                } else if (c_left <= c_right) { left.push_back(r); lb = l_whole; --nr; }
+                else { right.push_back(r); rb = r_whole; --nl; }
+            }
+            if (!left.empty() && !right.empty() && left.size() < cnt + (size_t)added && right.size() < cnt + (size_t)added &&
+                (left.size() < cnt || right.size() < cnt)) {
+                budget.fetch_sub(added, std::memory_order_relaxed);
+                done = true;
+            } else { left.clear(); right.clear(); }
         }
-        if (mid == b || mid == e) mid = b + cnt / 2;
+        if (!done) {
+            uint32_t mid;
+            if (best_axis >= 0) {
+                const float ext = chi[best_axis] - clo[best_axis];
+                const float scale = (float)NB / ext;
+                const float c0 = clo[best_axis];
+                const int a = best_axis, bb = best_bin;
+                auto it = std::partition(refs.begin(), refs.end(), [&](const Ref &r) {
+                    int k = (int)((0.5f * (r.lo[a] + r.hi[a]) - c0) * scale);
+                    k = std::min(std::max(k, 0), NB - 1);
+                    return k <= bb;
+                });
+                mid = (uint32_t)(it - refs.begin());
+            } else {
+                mid = cnt / 2;      // all centroids coincide: split by index
+            }
+            if (mid == 0 || mid == cnt) mid = cnt / 2;
+            left.assign(refs.begin(), refs.begin() + mid);
+            right.assign(refs.begin() + mid, refs.end());
+        }
+        std::vector<Ref>().swap(refs);
 
         const uint32_t l = alloc2();
         nodes[node].left = l; nodes[node].right = l + 1;
         if (depth < max_par_depth && cnt > 65536) {
-            std::thread t([&, l, b, mid, depth] { build(l, b, mid, depth + 1); });
-            build(l + 1, mid, e, depth + 1);
+            std::thread t([this, l, depth, lv = std::move(left)]() mutable { build(l, std::move(lv), depth + 1); });
+            build(l + 1, std::move(right), depth + 1);
             t.join();
         } else {
-            build(l, b, mid, depth + 1);
-            build(l + 1, mid, e, depth + 1);
+            build(l, std::move(left), depth + 1);
+            build(l + 1, std::move(right), depth + 1);
         }
     }
 };
@@ -154,7 +285,7 @@ inline uint8_t unary_count(uint32_t n) { return (uint8_t)((1u << n) - 1u); }
 
 }  // namespace
 
-void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, float scene_scale, uint32_t max_leaf_prims) {
+void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, float scene_scale, uint32_t max_leaf_prims, bool spatial_splits) {
     max_leaf_prims = std::min(std::max(max_leaf_prims, 1u), kMaxLeafPrims);
     out = Bvh8();
     const uint32_t n = (uint32_t)prims.size();
@@ -171,7 +302,6 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
     }
 
     Builder B(prims);
-    B.plo.resize(3 * (size_t)n); B.phi.resize(3 * (size_t)n); B.cen.resize(3 * (size_t)n); B.idx.resize(n);
     float smax = 1.0f;
     for (uint32_t i = 0; i < n; ++i)
         for (int a = 0; a < 3; ++a) smax = std::max(smax, std::max(std::fabs(prims[i].lo[a]), std::fabs(prims[i].hi[a])));
@@ -180,23 +310,33 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
     if (scene_scale > 0.0f) smax = std::max(1.0f, scene_scale);
     const float pad = 4e-6f * smax;
     out.pad = pad;
+    B.pad = pad;
+    std::vector<Ref> refs(n);
+    Box3 scene_box;
     for (uint32_t i = 0; i < n; ++i) {
-        B.idx[i] = i;
-        for (int a = 0; a < 3; ++a) {
-            B.plo[3 * i + a] = prims[i].lo[a] - pad;
-            B.phi[3 * i + a] = prims[i].hi[a] + pad;
-            B.cen[3 * i + a] = 0.5f * (prims[i].lo[a] + prims[i].hi[a]);
-        }
+        refs[i].prim = i;
+        for (int a = 0; a < 3; ++a) { refs[i].lo[a] = prims[i].lo[a]; refs[i].hi[a] = prims[i].hi[a]; }
+        scene_box.grow(prims[i].lo, prims[i].hi);
     }
-    B.nodes.resize(2 * (size_t)n + 2);
+    // spatial splits: the caller's choice (hrt_tlas_build under HRT_CTX_FAST_TRACE), HRT_SBVH = 0 / 1 overrides; at most
+    // HRT_SBVH_BUDGET x n extra references (default 1.0), tried where the object split's children overlap by more than
+    // HRT_SBVH_ALPHA of the scene's area (default 1e-5, the paper's)
+    B.spatial = spatial_splits && max_leaf_prims == kMaxLeafPrims;
+    if (const char *e = std::getenv("HRT_SBVH")) B.spatial = std::atoi(e) != 0 && max_leaf_prims == kMaxLeafPrims;
+    double budget_frac = 1.0;
+    if (const char *e = std::getenv("HRT_SBVH_BUDGET")) budget_frac = std::max(0.0, std::atof(e));
+    if (const char *e = std::getenv("HRT_SBVH_ALPHA")) B.alpha = (float)std::atof(e);
+    const int64_t extra = B.spatial ? (int64_t)std::min<double>(budget_frac * (double)n, 3.0e9 - 2.0 * (double)n) : 0;
+    B.budget = extra;
+    if (const char *e = std::getenv("HRT_BVH_BINS")) B.n_bins = std::min(std::max(std::atoi(e), 2), 64);
+    B.root_area = scene_box.area();
+    B.nodes.resize(2 * ((size_t)n + (size_t)std::max<int64_t>(extra, 0)) + 64 * 1024);      // (threads may overshoot the budget by a few references each)
     B.n_nodes = 1;
     int hw = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
     if (hw < 1) hw = 1;
     B.max_par_depth = 0;
-    if (const char *e = std::getenv("HRT_BVH2_SINGLE")) B.split_to_single = std::atoi(e) != 0;
-    if (max_leaf_prims < kMaxLeafPrims) B.split_to_single = true;
     while ((1 << B.max_par_depth) < hw && B.max_par_depth < 6) B.max_par_depth++;
-    B.build(0, 0, n, 0);
+    B.build(0, std::move(refs), 0);
 
     for (int a = 0; a < 3; ++a) { out.lo[a] = B.nodes[0].lo[a]; out.hi[a] = B.nodes[0].hi[a]; }
 
@@ -257,8 +397,8 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
     std::vector<Item> queue;
     queue.reserve(n);
     out.nodes.reserve(n / 2 + 8);
-    out.prims.reserve(n);
-    out.prim_bounds.reserve(6 * (size_t)n);
+    out.prims.reserve(B.nodes[0].nprims);
+    out.prim_bounds.reserve(6 * (size_t)B.nodes[0].nprims);
 
     queue.push_back({0u, 0u});
     out.nodes.emplace_back();
@@ -335,14 +475,26 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
             const B2 &c = B.nodes[ch[k]];
             for (int a = 0; a < 3; ++a) quantise_axis(nd.p[a], nd.e[a], c.lo[a], c.hi[a], &nd.qlo[a][s], &nd.qhi[a][s]);
             if (ch_leaf[k]) {
-                nd.meta[s] = (uint8_t)((unary_count(c.nprims) << 5) | prim_off);
-                for (uint32_t i = 0; i < c.nprims; ++i) {
-                    const uint32_t p = B.idx[c.first + i];
-                    out.prims.push_back(prims[p].rec);
-                    for (int a = 0; a < 3; ++a) out.prim_bounds.push_back(prims[p].lo[a]);
-                    for (int a = 0; a < 3; ++a) out.prim_bounds.push_back(prims[p].hi[a]);
+                // the <= 3 references of the leaf: walk its little BVH2 subtree, left first; the same primitive twice (both
+                // halves of a spatial split ended up here) is stored once
+                uint32_t st[8]; int sp = 0; st[sp++] = ch[k];
+                uint32_t lp[kMaxLeafPrims]; const B2 *lb[kMaxLeafPrims]; uint32_t nl = 0;
+                while (sp > 0) {
+                    const B2 &x = B.nodes[st[--sp]];
+                    if (x.count > 0) {
+                        bool dup = false;
+                        for (uint32_t q = 0; q < nl; ++q) if (lp[q] == x.first) dup = true;
+                        if (!dup && nl < kMaxLeafPrims) { lp[nl] = x.first; lb[nl] = &x; ++nl; }
+                    } else { st[sp++] = x.right; st[sp++] = x.left; }
                 }
-                prim_off += c.nprims;
+                nd.meta[s] = (uint8_t)((unary_count(nl) << 5) | prim_off);
+                for (uint32_t i = 0; i < nl; ++i) {
+                    out.prims.push_back(prims[lp[i]].rec);
+                    // (host-side checks: the part of the primitive this leaf answers for, unpadded side of the reference's box)
+                    for (int a = 0; a < 3; ++a) out.prim_bounds.push_back(lb[i]->lo[a] + pad);
+                    for (int a = 0; a < 3; ++a) out.prim_bounds.push_back(lb[i]->hi[a] - pad);
+                }
+                prim_off += nl;
             } else {
                 nd.meta[s] = (uint8_t)(0x20u | (24u + (uint32_t)s));
                 nd.imask |= (uint8_t)(1u << s);

@@ -305,7 +305,9 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
                 prims.push_back(bp);
             }
         }
-        build_bvh8(prims, t.bvh, 0, scene_scale);
+        // HRT_CTX_FAST_TRACE: the static-scene tree, with spatial splits (a later refit recomputes the boxes from whole primitives:
+        // valid, conservative, and without the splits' benefit -- the quality guard of hrt_tlas_update then rebuilds on the device)
+        build_bvh8(prims, t.bvh, 0, scene_scale, kMaxLeafPrims, fast_trace);
         for (size_t l = t.bvh.level_begin.size() - 1; l-- > 0;) t.phases.emplace_back(t.bvh.level_begin[l], t.bvh.level_begin[l + 1] - t.bvh.level_begin[l]);
     }
     const bool on_device = device_merged && first[n] != 0u;

@@ -1236,7 +1236,7 @@ def test_eight_million_triangles_out_of_the_infinity_cache(hrt, oracle, gpu_avai
     try:
         r.load_scene(scene)
         r.set_frame(W, H, hrt.scenes.SEED_SALT, aov=False, linear=True)
-        tile = hrt.Tile(7, H, 1, 45, 0)                        # rows 7, 52, 97, ...
+        tile = hrt.Tile(0, H, 1, 45, 7)                        # rows 7, 52, 97, ...
         rows = np.arange(7, H, 45, dtype=np.uint32)
         r.reset_stats()
         r.render(1, tile=tile)

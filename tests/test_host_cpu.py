@@ -95,6 +95,37 @@ def test_host_bvh8_degenerate_inputs(hrt, oracle):
     lib.hrt_host_free(C.byref(blob))
 
 
+@pytest.mark.parametrize("n,edge", [(3, 0.5), (40, 0.6), (3000, 0.25), (20000, 0.08)])
+def test_host_bvh8_spatial_splits_keep_the_canonical_hit(hrt, oracle, monkeypatch, n, edge):
+    """SBVH (HRT_SBVH=1; what hrt_tlas_build uses under HRT_CTX_FAST_TRACE): nodes may cut their references with a plane, so a
+    triangle can be referenced from several leaves, each holding the box of its part.  The builder's own validation (every
+    reference's box inside every ancestor slot) passes, large overlapping triangles do get split, and the CPU walk of the tree
+    still gives the brute-force closest hit for every ray, any-hit included: duplicates cannot change (t, instance, primitive)."""
+    scene = hrt.scenes.random_soup(n, edge, 21)
+    monkeypatch.setenv("HRT_SBVH", "1")
+    lib, blob = _build(hrt, scene["instances"][0]["vertices"])
+    assert blob.n_triangles >= n
+    if n >= 3000:
+        assert blob.n_triangles > 1.02 * n                         # references were duplicated
+    o, d = oracle.random_rays(6000, n)
+    want = oracle.OracleScene(scene, force_brute=True).trace(o, d)
+    got = oracle.bvh8_trace(blob.nodes, blob.triangles, o, d)
+    assert all(np.array_equal(a, b) for a, b in zip(got[:5], want))
+    any_w = oracle.OracleScene(scene, force_brute=True).trace(o, d, any_hit=True)
+    any_g = oracle.bvh8_trace(blob.nodes, blob.triangles, o, d, any_hit=True)
+    assert np.array_equal(any_g[3] != 0xFFFFFFFF, any_w[3] != 0xFFFFFFFF)
+    split_nodes, split_counts = got[5], got[6]
+    lib.hrt_host_free(C.byref(blob))
+    monkeypatch.setenv("HRT_SBVH", "0")
+    lib, blob = _build(hrt, scene["instances"][0]["vertices"])
+    assert blob.n_triangles == n
+    plain = oracle.bvh8_trace(blob.nodes, blob.triangles, o, d)
+    assert all(np.array_equal(a, b) for a, b in zip(plain[:5], want))
+    if n >= 3000:
+        assert split_nodes < plain[5]                             # and the split tree is the cheaper one to walk
+    lib.hrt_host_free(C.byref(blob))
+
+
 def test_empty_bvh(hrt, oracle):
     lib = hrt.load_library()
     blob = hrt.BvhBlob()

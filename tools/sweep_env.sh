@@ -17,6 +17,6 @@ for spec in "$@"; do
   combos=("${next[@]}")
 done
 for c in "${combos[@]}"; do
-  r=$(env $c python3 bench.py "${ARGS[@]}" --no-cpu-baseline --no-alt-builder 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'])")
+  r=$(env $c python3 bench.py "${ARGS[@]}" --no-cpu-baseline --no-alt-builder 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'], 'nodes/ray', d['roofline']['nodes_per_ray'], 'prims/ray', d['roofline']['prims_per_ray'], 'bvh_nodes', d['config']['bvh_nodes'], 'build_s', d['config']['bvh_build_s'])")
   echo "$c : $r" | tee -a "$OUT"
 done
