@@ -55,7 +55,11 @@ $(LIBDIR)/bvh8_build.o: $(CSRC)/bvh8_build.cpp $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
-$(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/paths.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o
+$(LIBDIR)/bvh8_host_api.o: $(CSRC)/bvh8_host_api.cpp $(CSRC)/bvh8.h include/hrt.h include/hrt_params.h
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -c $< -o $@
+
+$(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/paths.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o $(LIBDIR)/bvh8_host_api.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -pthread
 	@cat $(sort $(wildcard $(CSRC)/*.hip $(CSRC)/*.h $(CSRC)/*.hpp $(CSRC)/*.cpp include/*.h)) | sha256sum | cut -c1-16 > $(LIBDIR)/BUILD_ID
 
@@ -99,13 +103,35 @@ $(LIBDIR)/libhrt_stats.so: $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/paths.h
 	$(HIPCC) $(HIPFLAGS) -DHRT_LANE_STATS -c $(CSRC)/kernels.hip -o $(LIBDIR)/kernels_stats.o
 	$(HIPCC) $(HIPFLAGS) -DHRT_LANE_STATS -c $(CSRC)/fused.hip -o $(LIBDIR)/fused_stats.o
 	$(HIPCC) $(HIPFLAGS) -DHRT_LANE_STATS -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_stats.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LIBDIR)/kernels_stats.o $(LIBDIR)/fused_stats.o $(LIBDIR)/paths_stats.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LIBDIR)/kernels_stats.o $(LIBDIR)/fused_stats.o $(LIBDIR)/paths_stats.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o $(LIBDIR)/bvh8_host_api.o -pthread
 
 # bound-finding experiments on k_paths (tools only, never shipped): twice the slab arithmetic / twice the node loads
 exp: $(LIBDIR)/libhrt.so
 	$(HIPCC) $(HIPFLAGS) -DHRT_EXP_VALU2 -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_valu2.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_valu2.so $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/paths_valu2.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_valu2.so $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/paths_valu2.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o $(LIBDIR)/bvh8_host_api.o -pthread
 	$(HIPCC) $(HIPFLAGS) -DHRT_EXP_LOAD2 -DHRT_EXP_LOAD2_SAME -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_load2s.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_load2s.so $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/paths_load2s.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_load2s.so $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/paths_load2s.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o $(LIBDIR)/bvh8_host_api.o -pthread
 	$(HIPCC) $(HIPFLAGS) -DHRT_EXP_LOAD2 -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_load2.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_load2.so $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/paths_load2.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_load2.so $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/paths_load2.o $(LIBDIR)/build.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o $(LIBDIR)/bvh8_host_api.o -pthread
+
+# ---- sanitizer build (CPU only; GPU AddressSanitizer is not available and is never attempted): the host-side code that takes
+# untrusted files or builds trees on the host -- the format readers, the host BVH8 builder, the test oracle -- compiled with
+# AddressSanitizer + UndefinedBehaviorSanitizer into $(LIBDIR)/asan/, and `make asan-test` runs the CPU tests that exercise
+# them (truncated / garbage inputs included: tests/test_fuzz_inputs_cpu.py) against those libraries.
+ASAN_DIR   := $(LIBDIR)/asan
+ASAN_FLAGS := -O1 -g -std=c++17 -fPIC -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined -Iinclude -I$(CSRC) -Wall -pthread
+asan: $(ASAN_DIR)/libhrt_io.so $(ASAN_DIR)/libhrt_host_bvh.so $(ASAN_DIR)/liboracle.so
+$(ASAN_DIR)/libhrt_io.so: $(CSRC)/host/scene_io.cpp $(CSRC)/host/json_min.hpp $(CSRC)/cr_trig.h $(CSRC)/srgb_pow.h include/hrt_io.h include/hrt_params.h
+	@mkdir -p $(ASAN_DIR)
+	$(CXX) $(ASAN_FLAGS) -shared -o $@ $<
+$(ASAN_DIR)/libhrt_host_bvh.so: $(CSRC)/bvh8_build.cpp $(CSRC)/bvh8_host_api.cpp $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.h include/hrt.h
+	@mkdir -p $(ASAN_DIR)
+	$(CXX) $(ASAN_FLAGS) -DHRT_HOST_ONLY -shared -o $@ $(CSRC)/bvh8_build.cpp $(CSRC)/bvh8_host_api.cpp
+$(ASAN_DIR)/liboracle.so: oracle/oracle.c
+	@mkdir -p $(ASAN_DIR)
+	gcc -O1 -g -std=c11 -fPIC -shared -fopenmp -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined -o $@ $< -lquadmath -lm
+asan-test: asan
+	LD_PRELOAD="$$(gcc -print-file-name=libasan.so) $$(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1 \
+	HRT_IO_LIB=$(CURDIR)/$(ASAN_DIR)/libhrt_io.so HRT_HOST_BVH_LIB=$(CURDIR)/$(ASAN_DIR)/libhrt_host_bvh.so HRT_ORACLE_LIB=$(CURDIR)/$(ASAN_DIR)/liboracle.so \
+	python3 -m pytest tests/test_fuzz_inputs_cpu.py tests/test_io_cpu.py tests/test_oracle_cpu.py tests/test_host_cpu.py -x -q -p no:cacheprovider -k "not pow_pin and not cpp_driver and not exports_every and not no_cpu_fallback and not sbt_header and not sanitizer_job"
+.PHONY: asan asan-test

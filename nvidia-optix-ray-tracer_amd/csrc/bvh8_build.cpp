@@ -64,6 +64,7 @@ struct Builder {
     // references are harmless to the canonical closest hit (min t, then min (instance, primitive)).
     bool spatial = false;
     int n_bins = 16;                     // object-split bins per axis
+    float spatial_bias = 1.0f;           // < 1 favours spatial splits over object splits of equal SAH cost
     float alpha = 1e-5f;                 // spatial splits are tried when area(left ∩ right) / area(root) exceeds this
     float root_area = 0.0f;
     std::atomic<int64_t> budget{0};      // references the spatial splits may still add
@@ -216,7 +217,7 @@ struct Builder {
 
         std::vector<Ref> left, right;
         bool done = false;
-        if (sp_axis >= 0 && sp_cost < best_cost) {
+        if (sp_axis >= 0 && sp_cost * spatial_bias < best_cost) {
             // ---- spatial split: references wholly on one side go there; a straddling one is cut, or -- when that is cheaper by
             //      the SAH of the two children as they stand -- kept whole on one side ("reference unsplitting") ----
             const int a = sp_axis;
@@ -326,6 +327,7 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
     double budget_frac = 1.0;
     if (const char *e = std::getenv("HRT_SBVH_BUDGET")) budget_frac = std::max(0.0, std::atof(e));
     if (const char *e = std::getenv("HRT_SBVH_ALPHA")) B.alpha = (float)std::atof(e);
+    if (const char *e = std::getenv("HRT_SBVH_BIAS")) B.spatial_bias = (float)std::atof(e);
     const int64_t extra = B.spatial ? (int64_t)std::min<double>(budget_frac * (double)n, 3.0e9 - 2.0 * (double)n) : 0;
     B.budget = extra;
     if (const char *e = std::getenv("HRT_BVH_BINS")) B.n_bins = std::min(std::max(std::atoi(e), 2), 64);
@@ -437,8 +439,36 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
             }
         }
         int slot_child[8]; for (int s = 0; s < 8; ++s) slot_child[s] = -1;
+        static const int assign_mode = std::getenv("HRT_BVH_ASSIGN") ? std::atoi(std::getenv("HRT_BVH_ASSIGN")) : 0;
+        bool assigned = false;
+        if (assign_mode == 1) {
+            // exact assignment (minimum total cost) by dynamic programming over the set of used slots: child k = popcount(set)
+            float dp[256]; int8_t from[256];
+            for (int m = 0; m < 256; ++m) { dp[m] = std::numeric_limits<float>::infinity(); from[m] = -1; }
+            dp[0] = 0.0f;
+            bool ok = true;
+            for (int k = 0; k < nch && ok; ++k) for (int s = 0; s < 8; ++s) if (!(cost[k][s] == cost[k][s])) ok = false;
+            if (ok) {
+                for (int m = 0; m < 256; ++m) {
+                    const int k = __builtin_popcount((unsigned)m);
+                    if (k >= nch || !(dp[m] < std::numeric_limits<float>::infinity())) continue;
+                    for (int s = 0; s < 8; ++s) {
+                        if (m & (1 << s)) continue;
+                        const float v = dp[m] + cost[k][s];
+                        if (v < dp[m | (1 << s)]) { dp[m | (1 << s)] = v; from[m | (1 << s)] = (int8_t)s; }
+                    }
+                }
+                int best_m = -1; float best_v = std::numeric_limits<float>::infinity();
+                for (int m = 0; m < 256; ++m) if (__builtin_popcount((unsigned)m) == nch && dp[m] < best_v) { best_v = dp[m]; best_m = m; }
+                if (best_m >= 0) {
+                    int m = best_m;
+                    for (int k = nch - 1; k >= 0; --k) { const int s = from[m]; slot_child[s] = k; m &= ~(1 << s); }
+                    assigned = true;
+                }
+            }
+        }
         bool child_done[8] = {false, false, false, false, false, false, false, false};
-        for (int round = 0; round < nch; ++round) {
+        for (int round = 0; round < nch && !assigned; ++round) {
             int bk = -1, bs = -1; float bc = std::numeric_limits<float>::infinity();
             for (int k = 0; k < nch; ++k) {
                 if (child_done[k]) continue;

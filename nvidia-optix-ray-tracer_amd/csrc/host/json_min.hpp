@@ -60,12 +60,14 @@ private:
     [[noreturn]] void fail(const char *what) const { throw std::runtime_error(std::string("JSON parse error at byte ") + std::to_string(p_) + ": " + what); }
     void ws() { while (p_ < s_.size() && (s_[p_] == ' ' || s_[p_] == '\t' || s_[p_] == '\n' || s_[p_] == '\r')) ++p_; }
     bool eat(char c) { ws(); if (p_ < s_.size() && s_[p_] == c) { ++p_; return true; } return false; }
+    int depth_ = 0;
+    struct Nest { int &d; explicit Nest(int &x) : d(x) { ++d; } ~Nest() { --d; } };
     Json value() {
         ws();
         if (p_ >= s_.size()) fail("unexpected end");
         const char c = s_[p_];
-        if (c == '{') return object();
-        if (c == '[') return array();
+        // containers recurse: a file of 100 000 '[' would otherwise run the stack out (the formats read here nest 3 deep)
+        if (c == '{' || c == '[') { if (depth_ >= 64) fail("nesting deeper than 64"); Nest n(depth_); return c == '{' ? object() : array(); }
         if (c == '"') { Json j; j.kind = Json::String; j.str = string(); return j; }
         if (s_.compare(p_, 4, "true") == 0) { p_ += 4; Json j; j.kind = Json::Bool; j.b = true; return j; }
         if (s_.compare(p_, 5, "false") == 0) { p_ += 5; Json j; j.kind = Json::Bool; j.b = false; return j; }

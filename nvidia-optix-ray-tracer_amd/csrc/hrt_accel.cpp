@@ -724,49 +724,14 @@ int hrt_tlas_destroy(HrtContext *ctx, HrtTraversable tlas) {
     return HRT_OK;
 }
 
-static int alloc_blob(size_t n_nodes, size_t n_prims, const float *lo, const float *hi, HrtBvhBlob *out) {
-    std::memset(out, 0, sizeof *out);
-    out->n_nodes = n_nodes; out->n_triangles = n_prims;
-    out->nodes = std::malloc(std::max<size_t>(1, sizeof(Bvh8Node) * n_nodes));
-    out->triangles = std::malloc(std::max<size_t>(1, sizeof(PrimRecord) * n_prims));
-    if (!out->nodes || !out->triangles) { std::free(out->nodes); std::free(out->triangles); std::memset(out, 0, sizeof *out); return HRT_ERR_OOM; }
-    for (int a = 0; a < 3; ++a) { out->bounds[a] = lo[a]; out->bounds[3 + a] = hi[a]; }
-    return HRT_OK;
-}
-static int fill_blob(const Bvh8 &b, HrtBvhBlob *out) {
-    const int rc = alloc_blob(b.nodes.size(), b.prims.size(), b.lo, b.hi, out);
-    if (rc != HRT_OK) return rc;
-    std::memcpy(out->nodes, b.nodes.data(), sizeof(Bvh8Node) * b.nodes.size());
-    std::memcpy(out->triangles, b.prims.data(), sizeof(PrimRecord) * b.prims.size());
-    return HRT_OK;
-}
-
-int hrt_host_build_bvh8(const float *h_triangles, uint32_t n_triangles, HrtBvhBlob *out) {
-    if (!out || (n_triangles && !h_triangles)) return HRT_ERR_INVALID;
-    std::vector<BuildPrim> prims(n_triangles);
-    for (uint32_t p = 0; p < n_triangles; ++p) {
-        BuildPrim &bp = prims[p]; std::memset(&bp, 0, sizeof bp);
-        const float *v = h_triangles + 9 * (size_t)p;
-        for (int a = 0; a < 3; ++a) {
-            bp.rec.a[a] = v[a]; bp.rec.b[a] = v[3 + a] - v[a]; bp.rec.c[a] = v[6 + a] - v[a];
-            bp.lo[a] = std::fmin(v[a], std::fmin(v[3 + a], v[6 + a]));
-            bp.hi[a] = std::fmax(v[a], std::fmax(v[3 + a], v[6 + a]));
-        }
-        bp.rec.prim = p; bp.rec.inst = 0; bp.rec.kind = kPrimKindTriangle;
-    }
-    Bvh8 b;
-    build_bvh8(prims, b, 0);
-    const char *err = validate_bvh8(b);
-    if (err[0]) return fail(nullptr, HRT_ERR_STATE, "bvh8 validation: %s", err);
-    return fill_blob(b, out);
-}
+int alloc_bvh_blob(size_t n_nodes, size_t n_prims, const float *lo, const float *hi, HrtBvhBlob *out);      // bvh8_host_api.cpp
 
 int hrt_tlas_download(HrtContext *ctx, HrtTraversable tlas, HrtBvhBlob *out) {
     if (!ctx || !out) return HRT_ERR_INVALID;
     (void)hipSetDevice(ctx->device);
     Tlas *t;
     { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->tlas.find(tlas); if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle"); t = it->second.get(); }
-    const int rc = alloc_blob(t->n_nodes, t->n_prims, t->lo, t->hi, out);
+    const int rc = alloc_bvh_blob(t->n_nodes, t->n_prims, t->lo, t->hi, out);
     if (rc != HRT_OK) return rc;
     // the device copy is the truth: device builds exist nowhere else, and a refit rewrites the tree in place
     HIP_TRY(ctx, hipDeviceSynchronize());
@@ -774,12 +739,6 @@ int hrt_tlas_download(HrtContext *ctx, HrtTraversable tlas, HrtBvhBlob *out) {
     HIP_TRY(ctx, hipMemcpy2D(out->nodes, sizeof(Bvh8Node), t->d_nodes, t->node_stride, sizeof(Bvh8Node), n_nodes, hipMemcpyDeviceToHost));
     if (n_prims) HIP_TRY(ctx, hipMemcpy2D(out->triangles, sizeof(PrimRecord), t->d_prims, t->prim_stride, sizeof(PrimRecord), n_prims, hipMemcpyDeviceToHost));
     return HRT_OK;
-}
-
-void hrt_host_free(HrtBvhBlob *blob) {
-    if (!blob) return;
-    std::free(blob->nodes); std::free(blob->triangles);
-    std::memset(blob, 0, sizeof *blob);
 }
 
 }  // extern "C"

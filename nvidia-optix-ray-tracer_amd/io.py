@@ -57,7 +57,8 @@ class IoMeshCache(C.Structure):
 def lib():
     global _LIB
     if _LIB is None:
-        path = Path(__file__).resolve().parent / "lib" / "libhrt_io.so"
+        import os
+        path = Path(os.environ["HRT_IO_LIB"]) if os.environ.get("HRT_IO_LIB") else Path(__file__).resolve().parent / "lib" / "libhrt_io.so"   # HRT_IO_LIB: the sanitizer build (make asan-test)
         if not path.exists():
             raise RuntimeError(f"{path} is missing: run `make lib` (or __graft_entry__.build())")
         L = C.CDLL(str(path))
@@ -83,7 +84,7 @@ class IoError(RuntimeError):
 
 def _check(rc):
     if rc != 0:
-        raise IoError(lib().hrt_io_last_error().decode())
+        raise IoError(lib().hrt_io_last_error().decode(errors="replace"))
 
 
 def _arr(ptr, n, dtype):

@@ -789,11 +789,11 @@ void oracle_bvh8_trace(const void *nodes_blob, const void *prims_blob,
                        const float *origins, const float *dirs, uint32_t n_rays,
                        float tmin, float tmax, int any_hit,
                        float *t_out, float *u_out, float *v_out, uint32_t *prim_out, uint32_t *inst_out,
-                       uint64_t *out_counters /* node visits, prim tests */, uint32_t *per_ray_nodes /* or NULL */) {
+                       uint64_t *out_counters /* [4]: node visits, prim tests, node visits that found nothing to enter or test, 0 */, uint32_t *per_ray_nodes /* or NULL */) {
     const uint32_t *nodes = (const uint32_t *)nodes_blob;          /* 20 words per node */
     const prim48 *prims = (const prim48 *)prims_blob;
-    uint64_t tot_nodes = 0, tot_prims = 0;
-    #pragma omp parallel for schedule(dynamic, 256) reduction(+:tot_nodes, tot_prims)
+    uint64_t tot_nodes = 0, tot_prims = 0, tot_empty = 0;
+    #pragma omp parallel for schedule(dynamic, 256) reduction(+:tot_nodes, tot_prims, tot_empty)
     for (long ri = 0; ri < (long)n_rays; ++ri) {
         const f3 o = mk3(origins[3 * ri], origins[3 * ri + 1], origins[3 * ri + 2]);
         const f3 d = mk3(dirs[3 * ri], dirs[3 * ri + 1], dirs[3 * ri + 2]);
@@ -844,6 +844,7 @@ void oracle_bvh8_trace(const void *nodes_blob, const void *prims_blob,
                 }
                 cur_x = nd[4]; cur_y = (hitmask & 0xff000000u) | (e_imask >> 24);
                 tri_x = nd[5]; tri_y = hitmask & 0x00ffffffu;
+                if (hitmask == 0u) ++tot_empty;
             }
             while (tri_y) {
                 const uint32_t k = (uint32_t)__builtin_ctz(tri_y);
@@ -870,7 +871,7 @@ void oracle_bvh8_trace(const void *nodes_blob, const void *prims_blob,
         prim_out[ri] = best.hit ? best.prim : 0xffffffffu; inst_out[ri] = best.hit ? best.inst : 0xffffffffu;
         if (per_ray_nodes) per_ray_nodes[ri] = my_nodes;
     }
-    if (out_counters) { out_counters[0] = tot_nodes; out_counters[1] = tot_prims; }
+    if (out_counters) { out_counters[0] = tot_nodes; out_counters[1] = tot_prims; out_counters[2] = tot_empty; out_counters[3] = 0; }
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -29,7 +29,8 @@ def lib():
         return _lib
     if not LIB.exists():
         subprocess.check_call(["make", "-C", str(ROOT / "oracle")])
-    L = C.CDLL(str(LIB))
+    import os
+    L = C.CDLL(os.environ.get("HRT_ORACLE_LIB") or str(LIB))      # HRT_ORACLE_LIB: the sanitizer build (make asan-test)
     L.oracle_scene_create.restype = C.c_void_p
     L.oracle_scene_create.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.oracle_scene_destroy.argtypes = [C.c_void_p]
@@ -234,9 +235,10 @@ def bvh8_trace(nodes_ptr, prims_ptr, origins, directions, tmin=1e-6, tmax=1e16, 
     n = o.shape[0]
     t, u, v = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
     prim, inst = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
-    cnt = np.zeros(2, np.uint64)
+    cnt = np.zeros(4, np.uint64)
     L.oracle_bvh8_trace(nodes_ptr, prims_ptr, _p(inst_inv), _p(inst_identity), _p(o), _p(d), n, tmin, tmax, int(any_hit),
                         _p(t), _p(u), _p(v), _p(prim), _p(inst), _p(cnt), _p(per_ray_nodes))
+    bvh8_trace.last_empty_visits = int(cnt[2])       # node visits that found nothing to enter or test (tools/tree_quality.py)
     return t, u, v, prim, inst, int(cnt[0]), int(cnt[1])
 
 

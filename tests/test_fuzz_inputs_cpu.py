@@ -1,0 +1,201 @@
+"""Truncated and garbage inputs for every reader of include/hrt_io.h (STL, particle VTK, Mesh-mode VTK, .vtk.series, config.json,
+particleN.cache, metadata.cache) and degenerate input for the host BVH8 builder: a reader either fails with an error message or
+returns a well-formed result -- it never crashes, reads out of bounds or overflows.  `make asan-test` runs this file (and the other
+CPU tests of the readers, the host builder and the oracle) against AddressSanitizer + UBSan builds of those libraries."""
+import ctypes as C
+import importlib
+import json
+import struct
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+FILES = Path(__file__).resolve().parent / "golden" / "files"
+
+
+@pytest.fixture(scope="module")
+def io():
+    return importlib.import_module("nvidia-optix-ray-tracer_amd.io")
+
+
+def _mutations(data: bytes, rng, n_random=24):
+    """Prefixes at many lengths, random byte flips, deleted and duplicated chunks, number tokens replaced by junk."""
+    out = [data[:k] for k in sorted(set([0, 1, 2, 7, 64] + [len(data) * i // 17 for i in range(1, 17)] + [max(len(data) - 1, 0)]))]
+    for _ in range(n_random):
+        b = bytearray(data)
+        for _ in range(int(rng.integers(1, 12))):
+            if b:
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        out.append(bytes(b))
+        if len(data) > 16:
+            i, j = sorted(int(x) for x in rng.integers(0, len(data), 2))
+            out.append(data[:i] + data[j:])
+            out.append(data[:j] + data[i:j] + data[j:])
+    for junk in (b"nan", b"-1", b"1e999", b"99999999999999999999", b"0x10", b"", b"\x00"):
+        parts = data.split(b" ")
+        if len(parts) > 3:
+            k = int(rng.integers(1, len(parts) - 1))
+            out.append(b" ".join(parts[:k] + [junk] + parts[k + 1:]))
+    return out
+
+
+def _try(io, fn, *args):
+    try:
+        return fn(*args)
+    except io.IoError as e:
+        assert str(e)                                   # a failure carries a message
+        return None
+
+
+def test_stl_reader_survives_garbage(io, tmp_path):
+    rng = np.random.default_rng(1)
+    src = (FILES / "shape" / "separated" / "shape_0000000002.stl").read_bytes()
+    p = tmp_path / "m.stl"
+    ok = 0
+    for blob in _mutations(src, rng):
+        p.write_bytes(blob)
+        r = _try(io, io.read_stl, p)
+        if r is not None:
+            ok += 1
+            assert r["vertices"].ndim == 3 and r["vertices"].shape[1:] == (3, 3) and r["normals"].shape == r["vertices"].shape
+    assert ok >= 1                                      # (the empty prefix parses as an empty solid)
+
+
+def test_particle_vtk_reader_survives_garbage(io, tmp_path):
+    rng = np.random.default_rng(2)
+    src = (FILES / "particle" / "particle_000000000000000.vtk").read_bytes()
+    p = tmp_path / "p.vtk"
+    for blob in _mutations(src, rng):
+        p.write_bytes(blob)
+        r = _try(io, io.read_particle_vtk, p)
+        if r is not None:
+            assert r["states"].shape[1] == 12 and len(r["ids"]) == len(r["states"]) == len(r["shape_ids"])
+    # counts that promise more than the file holds, or nothing at all
+    text = src.decode()
+    for bad in (text.replace("POINTS 25", "POINTS 2500000000"), text.replace("POINTS 25", "POINTS 0"), text.replace("POINTS 25", "POINTS -3"),
+                text.replace("POINT_DATA 25", "POINT_DATA 18446744073709551615")):
+        p.write_text(bad)
+        _try(io, io.read_particle_vtk, p)
+
+
+def test_series_and_config_readers_survive_garbage(io, tmp_path):
+    rng = np.random.default_rng(3)
+    src = (FILES / "particle.vtk.series").read_bytes()
+    for k, blob in enumerate(_mutations(src, rng)):
+        (tmp_path / "s.series").write_bytes(blob)
+        r = _try(io, io.read_series, str(tmp_path) + "/", "s.series")
+        if r is not None:
+            files, dur = r
+            assert len(files) == len(dur)
+    cfg = (FILES / "config.json").read_bytes()
+    p = tmp_path / "c.json"
+    for blob in _mutations(cfg, rng, n_random=40):
+        p.write_bytes(blob)
+        _try(io, io.load_config, p)
+    # well-formed JSON of the wrong shape
+    base = json.loads(cfg)
+    for path, value in ((("loop-data", "window-width"), "wide"), (("loop-data", "window-width"), -5), (("loop-data",), []), (("roughs",), 7),
+                        (("spheres",), [{"center": [1, 2]}]), (("spheres",), [[1, 2, 3]]), (("metals",), [[1, 2]]), (("roughs",), [[1e999, 0, 0]]),
+                        (("loop-data", "fps"), 1e30), (("series-path",), 5), (("cache",), "yes")):
+        d = json.loads(cfg)
+        node = d
+        for key in path[:-1]:
+            node = node.get(key, {}) if isinstance(node, dict) else {}
+        if isinstance(node, dict):
+            node[path[-1]] = value
+        p.write_text(json.dumps(d))
+        _try(io, io.load_config, p)
+    p.write_text("[" * 100000)                          # nesting depth
+    _try(io, io.load_config, p)
+    assert base
+
+
+def test_mesh_cache_and_metadata_readers_survive_garbage(io, tmp_path):
+    rng = np.random.default_rng(4)
+    cfg_path = io.write_mesh_mode_sample(tmp_path / "sample", n_files=1, n_particles=5, width=32, height=24)
+    caches = sorted((tmp_path / "sample").rglob("particle*.cache"))
+    assert caches
+    src = caches[0].read_bytes()
+    p = tmp_path / "particle0.cache"
+    good = 0
+    for blob in _mutations(src, rng, n_random=40):
+        p.write_bytes(blob)
+        r = _try(io, io.read_mesh_cache, p)
+        if r is not None:
+            good += 1
+            for part in r:
+                assert part["vertices"].shape == part["normals"].shape and part["vertices"].shape[1:] == (3, 3)
+    # counts far beyond the file: a particle count of 2^61, a vertex count that overflows the byte size
+    for n_particles, n_vertices in ((1 << 61, 3), (1, (1 << 62) + 3), (3, 1 << 40), (0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF)):
+        p.write_bytes(struct.pack("<Q", n_particles) + struct.pack("<Q3fQ", 7, 0.0, 0.0, 0.0, n_vertices) + b"\x00" * 72)
+        assert _try(io, io.read_mesh_cache, p) is None
+    for text in (b"", b"-1", b"12abc", b"99999999999999999999999999", b"\x00\x01", b" 42 \n"):
+        (tmp_path / "metadata.cache").write_bytes(text)
+        _try(io, io.read_metadata_cache, str(tmp_path) + "/")
+
+
+def test_vtk_mesh_reader_survives_garbage(io, tmp_path):
+    rng = np.random.default_rng(5)
+    from test_io_cpu import MESH_VTK
+    good = MESH_VTK.encode()
+    p = tmp_path / "mesh.vtk"
+    p.write_bytes(good)
+    r = _try(io, io.read_vtk_mesh_file, p)
+    for blob in _mutations(good, rng, n_random=60):
+        p.write_bytes(blob)
+        _try(io, io.read_vtk_mesh_file, p)
+    for bad in (good.replace(b"5 0 1 2 3 4", b"5 0 1 2 3 99"), good.replace(b"5 0 1 2 3 4", b"5 0 1 2 3 -1"), good.replace(b"5 0 1 2 3 4", b"900 0 1 2 3 4"),
+                good.replace(b"4 5 6 7 8", b"0 5 6 7 8"), good.replace(b"POINTS 9", b"POINTS 4000000000"), good.replace(b"TRIANGLE_STRIPS 2 11", b"TRIANGLE_STRIPS 2000000000 11"),
+                good.replace(b"TRIANGLE_STRIPS 2 11", b"TRIANGLE_STRIPS 2 18446744073709551615"), good.replace(b"CELL_DATA 2", b"CELL_DATA 200")):
+        p.write_bytes(bad)
+        _try(io, io.read_vtk_mesh_file, p)
+    assert r is not None and r[1] == 2 and len(r[0]) == 2 and r[0][0]["vertices"].shape == (3, 3, 3)
+
+
+def test_host_builder_takes_degenerate_geometry(hrt=None):
+    """NaN / Inf / zero-area / coincident / enormous triangles through hrt_host_build_bvh8 with and without spatial splits."""
+    import os
+    hrt = importlib.import_module("nvidia-optix-ray-tracer_amd")
+    from test_host_cpu import _host_bvh_lib
+    lib = _host_bvh_lib(hrt)
+    rng = np.random.default_rng(6)
+    base = rng.uniform(-1, 1, (400, 3, 3)).astype(np.float32)
+    weird = base.copy()
+    weird[::7, 0, 0] = np.nan
+    weird[3::11, 1] = np.inf
+    weird[5::13] = 0.0
+    weird[6::17] = weird[6]
+    weird[8::19] *= np.float32(1e30)
+    weird[9::23] *= np.float32(1e-38)
+    for env in ("0", "1"):
+        os.environ["HRT_SBVH"] = env
+        try:
+            for tris in (weird, base[:1], base[:2], np.repeat(base[:1], 300, 0), (base * np.float32(3e38)).astype(np.float32)):
+                blob = hrt.BvhBlob()
+                v = np.ascontiguousarray(tris, np.float32)
+                rc = lib.hrt_host_build_bvh8(v.ctypes.data, v.shape[0], C.byref(blob))
+                assert rc in (0, -5), rc              # built, or the builder's own validation refused it (never a crash)
+                if rc == 0:
+                    assert blob.n_nodes >= 1
+                    lib.hrt_host_free(C.byref(blob))
+        finally:
+            del os.environ["HRT_SBVH"]
+
+
+def test_sanitizer_job_is_clean():
+    """`make asan-test`: the readers, the host BVH8 builder and the oracle rebuilt with AddressSanitizer + UBSan (CPU only), and the
+    CPU tests that drive them -- this file included -- run against those builds.  Any report aborts the run."""
+    import os
+    import shutil
+    import subprocess
+    if os.environ.get("HRT_IO_LIB") or os.environ.get("HRT_HOST_BVH_LIB"):
+        pytest.skip("already inside the sanitizer job")
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not shutil.which("make") or not asan or not Path(asan).is_absolute() or not Path(asan).exists():
+        pytest.skip("no libasan for gcc here")
+    root = Path(__file__).resolve().parent.parent
+    p = subprocess.run(["make", "-C", str(root), "asan-test"], capture_output=True, text=True, timeout=900)
+    tail = (p.stdout + p.stderr)[-3000:]
+    assert p.returncode == 0, tail
+    assert " passed" in p.stdout and "runtime error" not in tail and "AddressSanitizer" not in tail, tail

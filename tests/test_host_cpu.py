@@ -53,8 +53,24 @@ def test_sbt_header_packing(hrt):
     assert lib.hrt_sbt_record_pack_header(0, None) == -1
 
 
+def _host_bvh_lib(hrt):
+    """libhrt.so, or -- under `make asan-test` -- the sanitizer build of the host builder alone (HRT_HOST_BVH_LIB)."""
+    import os
+    path = os.environ.get("HRT_HOST_BVH_LIB")
+    if not path:
+        return hrt.load_library()
+    lib = C.CDLL(path)
+    lib.hrt_last_error.restype = C.c_char_p
+    lib.hrt_last_error.argtypes = [C.c_void_p]
+    lib.hrt_host_build_bvh8.restype = C.c_int
+    lib.hrt_host_build_bvh8.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(hrt.BvhBlob)]
+    lib.hrt_host_free.restype = None
+    lib.hrt_host_free.argtypes = [C.POINTER(hrt.BvhBlob)]
+    return lib
+
+
 def _build(hrt, tris):
-    lib = hrt.load_library()
+    lib = _host_bvh_lib(hrt)
     v = np.ascontiguousarray(tris, np.float32).reshape(-1, 3, 3)
     blob = hrt.BvhBlob()
     rc = lib.hrt_host_build_bvh8(v.ctypes.data, v.shape[0], C.byref(blob))
@@ -127,7 +143,7 @@ def test_host_bvh8_spatial_splits_keep_the_canonical_hit(hrt, oracle, monkeypatc
 
 
 def test_empty_bvh(hrt, oracle):
-    lib = hrt.load_library()
+    lib = _host_bvh_lib(hrt)
     blob = hrt.BvhBlob()
     assert lib.hrt_host_build_bvh8(None, 0, C.byref(blob)) == 0
     assert blob.n_nodes == 1 and blob.n_triangles == 0
