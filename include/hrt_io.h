@@ -26,9 +26,12 @@ extern "C" {
 const char *hrt_io_last_error(void);
 
 /* One STL shape.  vertices: 9 floats per triangle in file order (float(double) as the reference converts them).
- * normals: 9 floats per triangle -- the unit geometric normal of the facet's winding replicated for its three
- * vertices, i.e. the layout the shader indexes (3*prim + k, shader/Shader.cu:140-142).  The reference feeds one
- * normal per FACE here (quirk Q5: wrong normals and out-of-bounds reads); this is the per-vertex array Mesh mode uses.
+ * normals: 9 floats per triangle -- the unit geometric normal of the facet replicated for its three vertices, i.e. the
+ * layout the shader indexes (3*prim + k, shader/Shader.cu:140-142), oriented as vtkPolyDataNormals orients it with the
+ * reference's settings (Consistency + AutoOrientNormals, src/Util/VTKReaderImpl.cpp:279-285: coincident points merged,
+ * every connected component made consistent across its manifold edges and turned outwards from its leftmost triangle);
+ * the vertices keep the file's order, as in the reference.  The reference feeds one normal per FACE here (quirk Q5: wrong
+ * normals and out-of-bounds reads); this is the per-vertex array Mesh mode uses.
  * file_normals: 3 floats per triangle, the "facet normal" lines (vtkSTLReader ignores them; kept for checks). */
 typedef struct HrtIoMesh {
     float   *vertices, *normals, *file_normals;
@@ -108,7 +111,8 @@ int  hrt_io_write_metadata_cache(const char *directory, uint64_t max_cell_count)
  * POLYDATA whose cells are TRIANGLE_STRIPS, one strip per particle, with CELL_DATA `id` and `vel`.  Strip k yields
  * (points - 2) triangles, odd ones with their last two vertices swapped (:96-104); every triangle vertex carries its POINT's
  * normal = the normalised sum of the unit normals of the triangles that use the point (vtkPolyDataNormals with point normals,
- * no splitting; its consistency / auto-orientation passes are not applied: consistently wound input is assumed).  The result
+ * no splitting), the triangles first made consistent and oriented outwards per connected component as that filter does with
+ * the reference's settings (:54-60).  FIELD and METADATA blocks are read past, as vtkPolyDataReader does.  The result
  * has the layout of a cache file, so hrt_io_write_mesh_cache(out) writes what the reference's cache run writes.
  * *out_cell_count (may be NULL) receives the file's cell count (the reference's maxCellCountSingleFile candidate). */
 int  hrt_io_read_vtk_mesh_file(const char *path, HrtIoMeshCache *out, uint64_t *out_cell_count);

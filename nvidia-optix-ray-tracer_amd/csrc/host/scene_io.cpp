@@ -5,6 +5,7 @@
 #include "../cr_trig.h"      // cos / sin of constructRotateMatrix: the correctly rounded pin the pose kernel and the oracle share
 
 #include <algorithm>
+#include <array>
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -12,6 +13,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -63,6 +65,38 @@ struct Tokens {
     void skip_line() { while (p < s.size() && s[p] != '\n') ++p; }
 };
 
+
+// Blocks a legacy VTK writer may add and the reference's vtkPolyDataReader reads past: FIELD <name> <n> followed by n arrays
+// "<name> <components> <tuples> <type>" + values, and METADATA ... up to the next empty line.  Returns false on a malformed block.
+bool skip_vtk_block(Tokens &tk, const std::string &keyword) {
+    if (keyword == "METADATA") {
+        while (tk.p < tk.s.size()) {
+            tk.skip_line();
+            if (tk.p < tk.s.size()) ++tk.p;
+            size_t q = tk.p;
+            while (q < tk.s.size() && (tk.s[q] == ' ' || tk.s[q] == '\t' || tk.s[q] == '\r')) ++q;
+            if (q >= tk.s.size() || tk.s[q] == '\n') break;          // the blank line that ends the block
+        }
+        return true;
+    }
+    if (keyword == "FIELD") {
+        std::string name; double n_arrays;
+        if (!tk.next(name) || !tk.number(n_arrays) || n_arrays < 0 || n_arrays > 1e6) return false;
+        for (uint64_t a = 0; a < (uint64_t)n_arrays; ++a) {
+            std::string an, type; double comps, tuples;
+            if (!tk.next(an) || !tk.number(comps) || !tk.number(tuples) || !tk.next(type) || comps < 0 || tuples < 0 || comps * tuples > 1e12) return false;
+            const uint64_t count = (uint64_t)comps * (uint64_t)tuples;
+            std::string v;
+            for (uint64_t i = 0; i < count; ++i) if (!tk.next(v)) return false;
+            // an array may carry its own METADATA block
+            const size_t save = tk.p;
+            if (tk.next(v) && v == "METADATA") skip_vtk_block(tk, v); else tk.p = save;
+        }
+        return true;
+    }
+    return false;
+}
+
 std::string lower(std::string v) { for (auto &c : v) c = (char)std::tolower((unsigned char)c); return v; }
 
 // ---- constructTransformMatrix, include/Global/DeviceFunctions.cuh:43-148 (host side, float libm) ----
@@ -95,6 +129,80 @@ void construct_transform(const float *shift, const float *rot, const float *scal
     const Mat4 r = mul(mul(rotation(rot[0], 0), rotation(rot[1], 1)), rotation(rot[2], 2));
     const Mat4 t = mul(mul(s, r), sc);
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) out[4 * i + j] = t.m[i][j];
+}
+
+
+// ---- vtkPolyDataNormals' orientation pass (Consistency + AutoOrientNormals, as the reference sets them:
+// src/Util/VTKReaderImpl.cpp:54-60 for Mesh files, :279-285 for STL shapes).  VTK's published algorithm, restated: per
+// connected component the seed is found at the leftmost point (smallest x) that still has unvisited triangles -- of those, the
+// one whose normal is most aligned with the x axis -- and is reversed when its normal points right (+x); orientation then
+// spreads through MANIFOLD edges (exactly one neighbour): a neighbour that walks the shared edge in the same direction is
+// reversed.  Returns one flag per triangle: reversed.  The reference takes the VERTICES from the reader's output and only the
+// NORMALS from this filter, so a reversed triangle keeps its file winding and gets the opposite normal.
+// Not reproducible from the published description: the order in which VTK's priority queue pops points of EQUAL x (here: the
+// lowest point id first).  tri_points: 3 point ids per triangle; pts: 3 doubles per point.
+std::vector<uint8_t> orient_triangles(const std::vector<uint64_t> &tri_points, const std::vector<double> &pts) {
+    const size_t nt = tri_points.size() / 3, np = pts.size() / 3;
+    std::vector<uint8_t> flip(nt, 0), visited(nt, 0);
+    if (nt == 0) return flip;
+    std::vector<std::vector<uint32_t>> cells_of(np);
+    for (size_t t = 0; t < nt; ++t)
+        for (int k = 0; k < 3; ++k) {
+            auto &v = cells_of[tri_points[3 * t + k]];
+            if (v.empty() || v.back() != (uint32_t)t) v.push_back((uint32_t)t);
+        }
+    std::vector<uint64_t> cur(tri_points);
+    auto reverse_cell = [&](size_t t) { std::swap(cur[3 * t], cur[3 * t + 2]); flip[t] ^= 1u; };
+    auto unit_normal_x = [&](size_t t) -> double {
+        const double *A = &pts[3 * cur[3 * t]], *B = &pts[3 * cur[3 * t + 1]], *C = &pts[3 * cur[3 * t + 2]];
+        const double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+        const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        return len > 0.0 ? n[0] / len : 0.0;
+    };
+    // the triangles other than t that use both p and q
+    auto edge_neighbours = [&](uint32_t t, uint64_t p, uint64_t q, std::vector<uint32_t> &out) {
+        out.clear();
+        if (p == q) return;
+        for (uint32_t c : cells_of[p]) {
+            if (c == t) continue;
+            if (cur[3 * (size_t)c] == q || cur[3 * (size_t)c + 1] == q || cur[3 * (size_t)c + 2] == q) out.push_back(c);
+        }
+    };
+    std::vector<uint32_t> order(np);
+    for (size_t i = 0; i < np; ++i) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return pts[3 * (size_t)a] < pts[3 * (size_t)b]; });
+    std::vector<uint32_t> wave, wave2, nei;
+    for (uint32_t pid : order) {
+        double best = 0.0; int64_t seed = -1; bool reverse = false;
+        for (uint32_t c : cells_of[pid]) {
+            if (visited[c]) continue;
+            const double nx = unit_normal_x(c);
+            if (std::fabs(nx) > best) { best = std::fabs(nx); seed = c; reverse = nx > 0.0; }
+        }
+        if (seed < 0) continue;
+        if (reverse) reverse_cell((size_t)seed);
+        visited[(size_t)seed] = 1;
+        wave.assign(1, (uint32_t)seed);
+        while (!wave.empty()) {
+            wave2.clear();
+            for (uint32_t c : wave)
+                for (int j = 0; j < 3; ++j) {
+                    const uint64_t p1 = cur[3 * (size_t)c + j], p2 = cur[3 * (size_t)c + (j + 1) % 3];
+                    edge_neighbours(c, p1, p2, nei);
+                    if (nei.size() != 1) continue;                 // boundary or non-manifold edge: orientation does not cross it
+                    const uint32_t nb = nei[0];
+                    if (visited[nb]) continue;
+                    int l = 0;
+                    while (l < 3 && cur[3 * (size_t)nb + l] != p2) ++l;
+                    if (l < 3 && cur[3 * (size_t)nb + (l + 1) % 3] != p1) reverse_cell(nb);     // it walks the edge p1 -> p2 too: inconsistent
+                    visited[nb] = 1;
+                    wave2.push_back(nb);
+                }
+            wave.swap(wave2);
+        }
+    }
+    return flip;
 }
 
 // ---- colour ramps, include/Util/ColorRamp.cuh:31-112 ----
@@ -157,6 +265,21 @@ int hrt_io_read_stl(const char *path, HrtIoMesh *out) {
         if (len > 0.0) { c[0] /= len; c[1] /= len; c[2] /= len; }
         for (int k = 0; k < 3; ++k) for (int a = 0; a < 3; ++a) normals.push_back((float)c[a]);
         for (int a = 0; a < 3; ++a) fnormals.push_back((float)n[a]);
+    }
+    {   // vtkSTLReader merges coincident points (Merging is on by default: exact equality of the float coordinates), which is what
+        // gives vtkPolyDataNormals the connectivity for its consistency / auto-orientation pass; a reversed facet's normal is negated
+        std::map<std::array<uint32_t, 3>, uint64_t> ids;
+        std::vector<uint64_t> tri_points; std::vector<double> pts;
+        for (size_t v = 0; v < verts.size() / 3; ++v) {
+            std::array<uint32_t, 3> key;
+            for (int a = 0; a < 3; ++a) { float f = verts[3 * v + a]; if (f == 0.0f) f = 0.0f; std::memcpy(&key[a], &f, 4); }      // (-0 == +0)
+            auto it = ids.find(key);
+            if (it == ids.end()) { it = ids.emplace(key, (uint64_t)(pts.size() / 3)).first; for (int a = 0; a < 3; ++a) pts.push_back((double)verts[3 * v + a]); }
+            tri_points.push_back(it->second);
+        }
+        const std::vector<uint8_t> flip = orient_triangles(tri_points, pts);
+        for (size_t t2 = 0; t2 < flip.size(); ++t2)
+            if (flip[t2]) for (int k = 0; k < 9; ++k) normals[9 * t2 + k] = -normals[9 * t2 + k];
     }
     out->n_triangles = verts.size() / 9;
     out->vertices = dup_array(verts); out->normals = dup_array(normals); out->file_normals = dup_array(fnormals);
@@ -225,6 +348,8 @@ int hrt_io_read_particle_vtk(const char *path, HrtIoParticles *out) {
             std::string name, type;
             if (!tk.next(name) || !tk.next(type)) return fail(std::string(path) + ": bad " + t + " header");
             if (!read_values(3 * n, (in_point_data && t == "VECTORS" && name == "vel") ? &vel : nullptr)) return fail(std::string(path) + ": short " + t + " " + name);
+        } else if (t == "FIELD" || t == "METADATA") {
+            if (!skip_vtk_block(tk, t)) return fail(std::string(path) + ": malformed " + t + " block");
         } else {
             return fail(std::string(path) + ": unsupported keyword '" + t + "'");
         }
@@ -498,6 +623,8 @@ int hrt_io_read_vtk_mesh_file(const char *path, HrtIoMeshCache *out, uint64_t *o
             std::string name, type;
             if (!tk.next(name) || !tk.next(type)) return fail(std::string(path) + ": bad " + t + " header");
             if (!read_values(3 * n_cells, (in_cell_data && t == "VECTORS" && name == "vel") ? &vel : nullptr)) return fail(std::string(path) + ": short " + t + " " + name);
+        } else if (t == "FIELD" || t == "METADATA") {
+            if (!skip_vtk_block(tk, t)) return fail(std::string(path) + ": malformed " + t + " block");
         } else {
             return fail(std::string(path) + ": unsupported keyword '" + t + "'");
         }
@@ -510,18 +637,30 @@ int hrt_io_read_vtk_mesh_file(const char *path, HrtIoMeshCache *out, uint64_t *o
     std::vector<double> pn(3 * n_points, 0.0);
     struct Tri { uint64_t a, b, c; };
     std::vector<std::vector<Tri>> tris(strips.size());
+    std::vector<uint64_t> tri_points;
     for (size_t s2 = 0; s2 < strips.size(); ++s2) {
         const auto &st = strips[s2];
         for (size_t k = 0; k + 2 < st.size(); ++k) {
             Tri tr{st[k], st[k + 1], st[k + 2]};
             if (k & 1) std::swap(tr.b, tr.c);
             tris[s2].push_back(tr);
-            const double *A = &points[3 * tr.a], *B = &points[3 * tr.b], *C = &points[3 * tr.c];
-            const double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
-            double nrm[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-            const double len = std::sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
-            if (len > 0.0) for (uint64_t v : {tr.a, tr.b, tr.c}) for (int d = 0; d < 3; ++d) pn[3 * v + d] += nrm[d] / len;
+            tri_points.push_back(tr.a); tri_points.push_back(tr.b); tri_points.push_back(tr.c);
         }
+    }
+    // vtkPolyDataNormals works on the strips' triangles, makes their order consistent across shared edges and orients each
+    // connected component outwards (orient_triangles above); the point normals are sums over the triangles SO ORIENTED
+    const std::vector<uint8_t> flip = orient_triangles(tri_points, points);
+    {
+        size_t ti = 0;
+        for (size_t s2 = 0; s2 < strips.size(); ++s2)
+            for (const Tri &tr : tris[s2]) {
+                const double *A = &points[3 * tr.a], *B = &points[3 * tr.b], *C = &points[3 * tr.c];
+                const double e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+                double nrm[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+                const double len = std::sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+                const double sign = flip[ti++] ? -1.0 : 1.0;
+                if (len > 0.0) for (uint64_t v : {tr.a, tr.b, tr.c}) for (int d = 0; d < 3; ++d) pn[3 * v + d] += sign * nrm[d] / len;
+            }
     }
     for (uint64_t v = 0; v < n_points; ++v) {
         const double len = std::sqrt(pn[3 * v] * pn[3 * v] + pn[3 * v + 1] * pn[3 * v + 1] + pn[3 * v + 2] * pn[3 * v + 2]);

@@ -37,8 +37,17 @@ def test_stl_shapes(io):
         # per-vertex layout: the facet's unit geometric normal three times (what Shader.cu:140-142 indexes)
         assert np.array_equal(n[:, 0], n[:, 1]) and np.array_equal(n[:, 0], n[:, 2])
         assert np.abs(np.linalg.norm(n[:, 0].astype(np.float64), axis=1) - 1).max() < 1e-6
-        # the winding normal agrees with the normal the file states (to its 6 printed digits)
-        assert np.abs(n[:, 0] - fn).max() < 1e-4        # vertices are printed with 6 digits, so is the stated normal
+        # the normal is the winding's, oriented by vtkPolyDataNormals' consistency / auto-orientation pass as the reference sets it
+        # (VTKReaderImpl.cpp:279-285).  The two closed particle shapes are wound outwards already: nothing is reversed and the
+        # normal agrees with the one the file states (to its 6 printed digits).  The wall quads are open surfaces, which that pass
+        # orients by its seed rule alone -- the leftmost triangle's normal must not point towards +x -- so a wall facing +x comes
+        # out facing -x (the shader turns normals towards the ray anyway, Shader.cu:152-155); both triangles of a quad agree.
+        if k < 2:
+            assert np.abs(n[:, 0] - fn).max() < 1e-4    # vertices are printed with 6 digits, so is the stated normal
+        else:
+            sign = -1.0 if abs(fn[0, 0]) > 1e-6 and fn[0, 0] > 0 else 1.0
+            assert np.abs(n[:, 0] - sign * fn).max() < 1e-4 and np.array_equal(n[0, 0], n[1, 0])
+            assert n[0, 0, 0] <= 0
     assert counts == [252, 396, 2, 2, 2, 2, 2, 2]
     # the two particle shapes are closed surfaces: every undirected edge belongs to exactly two triangles, and the
     # normals point away from the centroid (star-shaped bodies)
@@ -341,3 +350,77 @@ def test_mesh_mode_cache_run_through_the_cpp_driver(io, tmp_path):
     mm = io.mesh_mode_scene(cfg_path)
     assert len(mm["scenes"]) == 3 and all(len(s["instances"]) == 1 + 7 for s in mm["scenes"])
     assert mm["velocities"][0].shape == (7, 3) and mm["frame_counts"] == [3, 6, 6]
+
+
+def _write_stl(path, tris):
+    with open(path, "w") as f:
+        f.write("solid t\n")
+        for t in tris:
+            f.write("facet normal 0 0 0\nouter loop\n")
+            for v in t:
+                f.write("vertex %r %r %r\n" % tuple(float(x) for x in v))
+            f.write("endloop\nendfacet\n")
+        f.write("endsolid t\n")
+
+
+def _cube_triangles():
+    """12 triangles of the unit cube, wound outwards."""
+    c = np.array([[x, y, z] for x in (0, 1) for y in (0, 1) for z in (0, 1)], np.float32)      # index = 4x + 2y + z
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]   # -x +x -y +y -z +z, outward
+    tris = []
+    for a, b, cc, d in quads:
+        tris += [[c[a], c[b], c[cc]], [c[a], c[cc], c[d]]]
+    return np.array(tris, np.float32)
+
+
+def test_normals_consistency_and_auto_orientation(io, tmp_path):
+    """vtkPolyDataNormals as the reference configures it (Consistency + AutoOrientNormals: VTKReaderImpl.cpp:54-60, :279-285),
+    restated in scene_io.cpp.  The reference keeps the file's vertex order and takes only the normals from the filter, so what
+    changes is the normal's sign: (1) a closed shape with ONE face wound the wrong way gets that face's normal turned outwards,
+    (2) an inside-out closed shape gets all of them turned, (3) a correctly wound one is left alone, (4) two shapes in one file
+    are oriented independently; Mesh-mode strips: (5) a strip stored backwards contributes its point normals with the sign of
+    the component it is connected to."""
+    cube = _cube_triangles()
+    centre = np.float32([0.5, 0.5, 0.5])
+
+    def outward(m):
+        v, n = m["vertices"], m["normals"][:, 0]
+        c = v.reshape(-1, 3).mean(axis=0) if len(v) <= 12 else None
+        return v, n, c
+
+    def all_outward(v, n, c):
+        return bool((((v.mean(axis=1) - c) * n).sum(axis=1) > 0).all())
+    # (3) as wound
+    _write_stl(tmp_path / "cube.stl", cube)
+    m = io.read_stl(tmp_path / "cube.stl")
+    assert np.array_equal(m["vertices"], cube) and all_outward(m["vertices"], m["normals"][:, 0], centre)
+    good_normals = m["normals"].copy()
+    # (1) one face reversed: vertices as in the file, normal as for the correct winding
+    one = cube.copy(); one[5] = one[5][::-1]
+    _write_stl(tmp_path / "one.stl", one)
+    m = io.read_stl(tmp_path / "one.stl")
+    assert np.array_equal(m["vertices"], one)
+    assert all_outward(m["vertices"], m["normals"][:, 0], centre) and np.allclose(m["normals"], good_normals, atol=1e-7)
+    # (2) inside out
+    inside_out = cube[:, ::-1].copy()
+    _write_stl(tmp_path / "inv.stl", inside_out)
+    m = io.read_stl(tmp_path / "inv.stl")
+    assert np.array_equal(m["vertices"], inside_out) and all_outward(m["vertices"], m["normals"][:, 0], centre)
+    # (4) two components, the second inside out and shifted
+    two = np.concatenate([cube, inside_out + np.float32([3, 0.25, -1])])
+    _write_stl(tmp_path / "two.stl", two)
+    m = io.read_stl(tmp_path / "two.stl")
+    assert all_outward(m["vertices"][:12], m["normals"][:12, 0], centre)
+    assert all_outward(m["vertices"][12:], m["normals"][12:, 0], centre + np.float32([3, 0.25, -1]))
+    # (5) Mesh mode: a closed tetrahedron as ONE strip (0 1 2 3 0 1 gives its four faces), once as is and once with the strip reversed;
+    # the point normals must point away from the centroid either way
+    tet = np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    for order in ("0 1 2 3 0 1", "1 0 3 2 1 0"):
+        text = ("# vtk DataFile Version 2.0\ntet\nASCII\nDATASET POLYDATA\nPOINTS 4 double\n" + " ".join("%g %g %g" % tuple(p) for p in tet) +
+                "\nTRIANGLE_STRIPS 1 7\n6 " + order + "\nCELL_DATA 1\nSCALARS id int 1\nLOOKUP_TABLE default\n5\nVECTORS vel double\n0 0 0\n"
+                "FIELD FieldData 1\ntime 1 1 double\n0.25\nMETADATA\nINFORMATION 0\n\n")
+        (tmp_path / "tet.vtk").write_text(text)
+        parts, cells = io.read_vtk_mesh_file(tmp_path / "tet.vtk")          # (FIELD / METADATA blocks are read past, as vtkPolyDataReader does)
+        assert cells == 1 and parts[0]["vertices"].shape == (4, 3, 3)
+        v, n = parts[0]["vertices"].reshape(-1, 3), parts[0]["normals"].reshape(-1, 3)
+        assert (((v - tet.mean(axis=0)) * n).sum(axis=1) > 0).all(), order
