@@ -173,7 +173,9 @@ def main():
     # region).  HRT_BENCH_DEVICE_BUILD=1 times the frame on the device-built PLOC tree instead (8 ms with the upload, 2.5 % more node
     # visits per ray, ~3.5 % fewer Mrays/s: profiles/r02_build_bench.txt).
     device_build = os.environ.get("HRT_BENCH_DEVICE_BUILD") == "1"
-    r = hrt.Renderer(local_rank, hrt.CTX_TIMING | (0 if device_build else hrt.CTX_FAST_TRACE))
+    # HRT_BENCH_NO_TIMING=1: no per-kernel HIP events (wavefront mode then replays its samples from a hipGraph; the roofline block has no kernel time)
+    timing = 0 if os.environ.get("HRT_BENCH_NO_TIMING") == "1" else hrt.CTX_TIMING
+    r = hrt.Renderer(local_rank, timing | (0 if device_build else hrt.CTX_FAST_TRACE))
     t0 = time.perf_counter()
     r.load_scene(scene)
     build_s = time.perf_counter() - t0

@@ -163,6 +163,7 @@ typedef struct HrtStats {
     uint64_t bvh_depth;                    /* levels below the root of the TLAS last launched (trees deeper than 12 take round 1's path kernel) */
     uint64_t fused_fallback_launches;      /* launches since the context was created that took round 1's path kernel because the tree did not
                                               fit k_fused (deeper than 12 levels, or node / record arrays beyond 4 GiB = 32-bit byte offsets) */
+    uint64_t graph_replays;                /* wavefront mode: sample pairs replayed from a captured hipGraph since the context was created */
     uint64_t bvh_alloc_bytes;              /* device memory the TLAS last launched holds for nodes, node boxes and records (bvh_bytes: the packed payload) */
 } HrtStats;
 

@@ -80,7 +80,7 @@ class Stats(C.Structure):
                 ("bvh_nodes", C.c_uint64), ("bvh_triangles", C.c_uint64), ("bvh_spheres", C.c_uint64),
                 ("bvh_bytes", C.c_uint64), ("debug", C.c_uint64 * 4),
                 ("tlas_refits", C.c_uint64), ("tlas_rebuilds", C.c_uint64), ("tlas_refit_ratio", C.c_double),
-                ("bvh_depth", C.c_uint64), ("fused_fallback_launches", C.c_uint64), ("bvh_alloc_bytes", C.c_uint64)]
+                ("bvh_depth", C.c_uint64), ("fused_fallback_launches", C.c_uint64), ("graph_replays", C.c_uint64), ("bvh_alloc_bytes", C.c_uint64)]
 
 
 class BvhBlob(C.Structure):

@@ -164,6 +164,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_SUBSTREAM_MIN_PIXELS")) { const int v = std::atoi(e); if (v >= 1024) ctx->substream_min_pixels = v; }
     if (const char *e = std::getenv("HRT_SUBSTREAMS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) ctx->substreams = v; }
     if (const char *e = std::getenv("HRT_FUSED_MAX_DEPTH")) { const int v = std::atoi(e); if (v >= 0 && v <= kFusedMaxDepth) ctx->fused_max_depth = v; }
+    if (const char *e = std::getenv("HRT_WAVEFRONT_GRAPH")) ctx->wavefront_graph = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_FUSED_MAX_BYTES")) { const unsigned long long v = std::strtoull(e, nullptr, 0); if (v >= 1 && v <= (1ull << 32)) ctx->fused_max_bytes = v; }
     if (const char *e = std::getenv("HRT_TAIL_REGEN")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->fused_tail_regen = v; }
     if (const char *e = std::getenv("HRT_LEAF_QUORUM")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->leaf_quorum = v; }
@@ -548,7 +549,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
 
     for (const Sub &sb : subs) { rc = do_generate(0, sb); if (rc != HRT_OK) return rc; }
     for (const Sub &sb : subs) do_traverse(sb, 0, 1, false, 0, 0);
-    for (uint32_t sample = 0; sample < spp; ++sample) {
+    auto sample_body = [&](uint32_t sample) -> int {
         const bool prev = sample > 0, next = sample + 1 < spp;
         for (const Sub &sb : subs) do_after(sb, sample, 1);
         for (const Sub &sb : subs) do_traverse(sb, sample, 2, prev, sample - 1, kRayTraceDepth);
@@ -556,10 +557,38 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         for (const Sub &sb : subs) do_after(sb, sample, 2);
         for (const Sub &sb : subs) do_traverse(sb, sample, 3, false, 0, 0);
         for (const Sub &sb : subs) do_after(sb, sample, 3);
-        if (next) for (const Sub &sb : subs) { rc = do_generate(sample + 1, sb); if (rc != HRT_OK) return rc; }
+        if (next) for (const Sub &sb : subs) { const int r = do_generate(sample + 1, sb); if (r != HRT_OK) return r; }
         for (const Sub &sb : subs) do_traverse(sb, sample, 4, next, sample + 1, 1);
         for (const Sub &sb : subs) do_after(sb, sample, 4);
+        return HRT_OK;
+    };
+    uint32_t sample = 0;
+    rc = sample_body(sample++);
+    if (rc != HRT_OK) return rc;
+    // Samples 1 .. spp - 2 enqueue the same ~45 operations on the same buffers, alternating between the two workspace sets:
+    // a pair of them is captured once as a hipGraph and replayed (HRT_WAVEFRONT_GRAPH=1; one stream, no per-kernel event
+    // timers inside a graph, so not under HRT_CTX_TIMING).  Every kernel reads its ray count from device memory, so the
+    // replayed launches are the eager ones, and the image is the same bits.
+    if (ctx->wavefront_graph && S == 1 && (ctx->flags & HRT_CTX_TIMING) == 0 && spp >= 4u) {
+        const uint32_t pairs = (spp - 2u) / 2u;
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        HIP_TRY(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int rc1 = sample_body(1u);
+        if (rc1 == HRT_OK) rc1 = sample_body(2u);
+        const hipError_t ce = hipStreamEndCapture(s, &graph);
+        if (rc1 != HRT_OK) { if (graph) (void)hipGraphDestroy(graph); return rc1; }
+        HIP_TRY(ctx, ce);
+        hipError_t ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        for (uint32_t k = 0; k < pairs && ge == hipSuccess; ++k) ge = hipGraphLaunch(exec, s);
+        // (the executable graph must outlive its launches: the stream is drained before it is destroyed)
+        if (ge == hipSuccess) ge = hipStreamSynchronize(s);
+        if (exec) (void)hipGraphExecDestroy(exec);
+        (void)hipGraphDestroy(graph);
+        HIP_TRY(ctx, ge);
+        sample += 2u * pairs;
+        ctx->graph_replays += pairs;
     }
+    for (; sample < spp; ++sample) { rc = sample_body(sample); if (rc != HRT_OK) return rc; }
     for (const Sub &sb : subs) do_traverse(sb, spp - 1, kRayTraceDepth, false, 0, 0);
     for (const Sub &sb : subs) do_after(sb, spp - 1, kRayTraceDepth);
     if (S > 1) {
@@ -638,7 +667,7 @@ int hrt_stats_get(HrtContext *ctx, HrtStats *out) {
         out->bvh_bytes = (uint64_t)tl.n_nodes * sizeof(Bvh8Node) + (uint64_t)tl.n_prims * sizeof(PrimRecord);
         out->bvh_alloc_bytes = tl.alloc_bytes;
     }
-    out->fused_fallback_launches = ctx->fused_fallback_launches;
+    out->fused_fallback_launches = ctx->fused_fallback_launches; out->graph_replays = ctx->graph_replays;
     return HRT_OK;
 }
 

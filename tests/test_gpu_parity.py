@@ -1095,6 +1095,7 @@ def test_errors_are_loud(hrt, renderer):
 MODES = {
     "default": {},
     "wavefront": {"HRT_FUSED": "0"},
+    "wavefront-every-launch-enqueued-no-graph": {"HRT_FUSED": "0", "HRT_WAVEFRONT_GRAPH": "0"},
     "wavefront-by-tile-size": {"HRT_FUSED": "-1", "HRT_FUSED_MAX_PIXELS": "16000"},
     "wavefront-lds-dma-gather": {"HRT_FUSED": "0", "HRT_LDS_GATHER": "1"},
     "wavefront-substreams": {"HRT_FUSED": "0", "HRT_SUBSTREAMS": "3", "HRT_SUBSTREAM_MIN_PIXELS": "1024"},
@@ -1150,6 +1151,31 @@ def test_every_execution_mode_is_bit_exact(hrt, oracle, gpu_available, monkeypat
             r.render(1)
             ref2 = osc.render(w, h, states, 1)
             assert np.array_equal(r.linear.cpu().numpy().view(np.uint32), ref2["linear"].view(np.uint32)), mode
+    finally:
+        r.close()
+
+
+def test_wavefront_mode_replays_a_captured_graph(hrt, oracle, gpu_available, monkeypatch):
+    """Wavefront mode (separate generate / traverse / bin / shade / accumulate kernels): the launches of samples 1 and 2 are
+    captured as a hipGraph and replayed for the following pairs.  9 samples = sample 0 enqueued, 3 replays, samples 7 and 8
+    enqueued: image, RNG states and ray count are the oracle's, and the replays did happen."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    monkeypatch.setenv("HRT_FUSED", "0")
+    r = hrt.Renderer(0, 0)
+    try:
+        w, h, spp, salt = 150, 90, 9, 77
+        scene = hrt.scenes.mixed_test_scene(2500, 50, 13, w, h, spp)
+        r.load_scene(scene)
+        r.set_frame(w, h, salt, aov=False, linear=True)
+        r.reset_stats()
+        r.render(spp)
+        states = oracle.rng_init(w, h, salt)
+        ref = oracle.OracleScene(scene).render(w, h, states, spp)
+        st = r.stats()
+        assert st.graph_replays == 3 and st.rays == ref["rays"]
+        assert np.array_equal(r.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32))
+        assert np.array_equal(r.rng_states_numpy(), states)
     finally:
         r.close()
 
