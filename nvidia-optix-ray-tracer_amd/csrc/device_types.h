@@ -200,7 +200,8 @@ uint32_t paths_blocks_that_fit(int slots);
 void launch_paths_v1(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s);   // round 1's fused kernel k_traverse<.., FUSED> (HRT_FUSED=2)
 constexpr int kFusedBlocksPerCu = 16;  // k_fused is compiled for 4 waves per SIMD (125 VGPRs, nothing spilled): more workgroups per CU would only queue
 constexpr int kFusedMaxDepth = 12;     // deepest tree (levels below the root) k_fused takes: its per-lane node stack in LDS (trav_lean.h: kNodeStackLds)
-void launch_fused(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s);      // k_fused (fused.hip): the default
+void launch_fused(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s);
+void launch_trace_queue(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s);   // k_trace_queue (fused_queue.hip): wavefront mode's traverse kernel, the loop of k_fused over ray queues      // k_fused (fused.hip): the default
 void launch_sum(float4 *accum, const float4 *result, uint32_t n, uint32_t first_sample, hipStream_t s);
 void launch_bin(const BinArgs &a, uint32_t grid_blocks, hipStream_t s);
 void launch_shade(const ShadeArgs &a, int program, uint32_t grid_blocks, hipStream_t s);

@@ -165,6 +165,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_SUBSTREAMS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) ctx->substreams = v; }
     if (const char *e = std::getenv("HRT_FUSED_MAX_DEPTH")) { const int v = std::atoi(e); if (v >= 0 && v <= kFusedMaxDepth) ctx->fused_max_depth = v; }
     if (const char *e = std::getenv("HRT_WAVEFRONT_GRAPH")) ctx->wavefront_graph = std::atoi(e) != 0;
+    if (const char *e = std::getenv("HRT_WAVEFRONT_LEAN")) ctx->wavefront_lean = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_FUSED_MAX_BYTES")) { const unsigned long long v = std::strtoull(e, nullptr, 0); if (v >= 1 && v <= (1ull << 32)) ctx->fused_max_bytes = v; }
     if (const char *e = std::getenv("HRT_TAIL_REGEN")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->fused_tail_regen = v; }
     if (const char *e = std::getenv("HRT_LEAF_QUORUM")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->leaf_quorum = v; }
@@ -200,6 +201,8 @@ int hrt_ctx_destroy(HrtContext *ctx) {
     for (hipEvent_t e : ctx->sub_done) (void)hipEventDestroy(e);
     for (hipStream_t st : ctx->sub_streams) (void)hipStreamDestroy(st);
     if (ctx->ev_begin) (void)hipEventDestroy(ctx->ev_begin);
+    if (ctx->ev_graph_done) (void)hipEventDestroy(ctx->ev_graph_done);
+    if (ctx->graph_stream) (void)hipStreamDestroy(ctx->graph_stream);
     delete ctx;
     return HRT_OK;
 }
@@ -461,10 +464,23 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
     }
     struct Sub { uint32_t j0, n; hipStream_t st; uint32_t index; uint32_t grid_wide, grid_trav; };
     if (S > (uint32_t)kMaxSubTiles) S = kMaxSubTiles;
+    // hipGraph replay of the per-sample launch sequence (below).  A capture cannot run on the legacy null stream -- the one the
+    // reference, and a caller that passes NULL, uses -- so the pipeline then runs on a stream of the context's own, ordered after
+    // the caller's work by an event and joined back before the finalize kernel.
+    const bool want_graph = ctx->wavefront_graph && S == 1 && (ctx->flags & HRT_CTX_TIMING) == 0 && spp >= 4u;
+    hipStream_t ws = s;
+    if (want_graph && s == nullptr) {
+        if (!ctx->graph_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->graph_stream, hipStreamNonBlocking));
+        if (!ctx->ev_begin) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_begin, hipEventDisableTiming));
+        if (!ctx->ev_graph_done) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_graph_done, hipEventDisableTiming));
+        ws = ctx->graph_stream;
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_begin, s));
+        HIP_TRY(ctx, hipStreamWaitEvent(ws, ctx->ev_begin, 0));
+    }
     std::vector<Sub> subs(S);
     for (uint32_t k = 0; k < S; ++k) {
         const uint32_t j0 = (uint32_t)((uint64_t)n * k / S), j1 = (uint32_t)((uint64_t)n * (k + 1) / S);
-        subs[k].j0 = j0; subs[k].n = j1 - j0; subs[k].st = S > 1 ? ctx->sub_streams[k] : s; subs[k].index = k;
+        subs[k].j0 = j0; subs[k].n = j1 - j0; subs[k].st = S > 1 ? ctx->sub_streams[k] : ws; subs[k].index = k;
         subs[k].grid_wide = std::min<uint32_t>((uint32_t)ctx->n_cu * 8u, (subs[k].n + 255u) / 256u);
         subs[k].grid_trav = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)ctx->traverse_blocks_per_cu, (2u * subs[k].n + 63u) / 64u);
     }
@@ -510,7 +526,13 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;      // Shader.cu:232, :266
         ta.refill_threshold = ctx->refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.leaf_quorum = ctx->leaf_quorum; ta.tail_regen = ctx->fused_tail_regen; ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fetch_chunk;
         Timer tm(ctx, sb.st, (da >= kRayTraceDepth && !second) ? HRT_K_TRAVERSE_ANY : HRT_K_TRAVERSE);
-        launch_traverse(ta, count, t->has_spheres, ctx->lds_gather != 0, sb.grid_trav, sb.st);
+        // production traversal: the loop of the path kernel over the ray queues (k_trace_queue); the counting build, the LDS-DMA gather
+        // mode and trees that do not fit k_fused's stacks / offsets keep round 1's k_traverse
+        if (!count && ctx->lds_gather == 0 && ctx->wavefront_lean && fits_fused_kernel(ctx, *t)) {
+            ta.postpone_pct = ctx->fused_postpone_pct; ta.refill_threshold = ctx->fused_refill_threshold;
+            const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * (uint32_t)std::min(ctx->traverse_blocks_per_cu, kFusedBlocksPerCu), (2u * sb.n + 63u) / 64u);
+            launch_trace_queue(ta, t->has_spheres, grid, sb.st);
+        } else launch_traverse(ta, count, t->has_spheres, ctx->lds_gather != 0, sb.grid_trav, sb.st);
     };
     // everything that follows the traversal of class (sample, depth): binning, shading, path ends
     auto do_after = [&](const Sub &sb, uint32_t sample, uint32_t depth) {
@@ -569,19 +591,19 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
     // a pair of them is captured once as a hipGraph and replayed (HRT_WAVEFRONT_GRAPH=1; one stream, no per-kernel event
     // timers inside a graph, so not under HRT_CTX_TIMING).  Every kernel reads its ray count from device memory, so the
     // replayed launches are the eager ones, and the image is the same bits.
-    if (ctx->wavefront_graph && S == 1 && (ctx->flags & HRT_CTX_TIMING) == 0 && spp >= 4u) {
+    if (want_graph) {
         const uint32_t pairs = (spp - 2u) / 2u;
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-        HIP_TRY(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        HIP_TRY(ctx, hipStreamBeginCapture(ws, hipStreamCaptureModeThreadLocal));
         int rc1 = sample_body(1u);
         if (rc1 == HRT_OK) rc1 = sample_body(2u);
-        const hipError_t ce = hipStreamEndCapture(s, &graph);
+        const hipError_t ce = hipStreamEndCapture(ws, &graph);
         if (rc1 != HRT_OK) { if (graph) (void)hipGraphDestroy(graph); return rc1; }
         HIP_TRY(ctx, ce);
         hipError_t ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        for (uint32_t k = 0; k < pairs && ge == hipSuccess; ++k) ge = hipGraphLaunch(exec, s);
+        for (uint32_t k = 0; k < pairs && ge == hipSuccess; ++k) ge = hipGraphLaunch(exec, ws);
         // (the executable graph must outlive its launches: the stream is drained before it is destroyed)
-        if (ge == hipSuccess) ge = hipStreamSynchronize(s);
+        if (ge == hipSuccess) ge = hipStreamSynchronize(ws);
         if (exec) (void)hipGraphExecDestroy(exec);
         (void)hipGraphDestroy(graph);
         HIP_TRY(ctx, ge);
@@ -591,6 +613,10 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
     for (; sample < spp; ++sample) { rc = sample_body(sample); if (rc != HRT_OK) return rc; }
     for (const Sub &sb : subs) do_traverse(sb, spp - 1, kRayTraceDepth, false, 0, 0);
     for (const Sub &sb : subs) do_after(sb, spp - 1, kRayTraceDepth);
+    if (ws != s) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_graph_done, ws));
+        HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->ev_graph_done, 0));
+    }
     if (S > 1) {
         for (uint32_t k = 0; k < S; ++k) {
             HIP_TRY(ctx, hipEventRecord(ctx->sub_done[k], ctx->sub_streams[k]));

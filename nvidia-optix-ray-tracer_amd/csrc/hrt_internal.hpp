@@ -150,6 +150,7 @@ struct HrtContext {
     int fused_max_depth = kFusedMaxDepth;       // deeper trees take round 1's fused kernel (HRT_FUSED_MAX_DEPTH lowers it: tests)
     uint64_t fused_max_bytes = 1ull << 32;      // k_fused addresses nodes and records by 32-bit byte offsets: larger arrays take round 1's kernel (HRT_FUSED_MAX_BYTES lowers it: tests)
     uint64_t fused_fallback_launches = 0;       // launches that took round 1's path kernel because the tree did not fit k_fused
+    int wavefront_lean = 1;                     // wavefront mode traverses with k_trace_queue (the loop of k_fused); 0: round 1's k_traverse (HRT_WAVEFRONT_LEAN)
     int wavefront_graph = 1;                    // wavefront mode: replay a captured pair of samples as a hipGraph (HRT_WAVEFRONT_GRAPH=0: enqueue every launch)
     uint64_t graph_replays = 0;
     int fused_tail_regen = 12;                  // k_fused, tile used up: finished rays that wait before a regeneration (HRT_TAIL_REGEN; 1/8 of C4: 142 ms with 1, 129 with 8..16)
@@ -178,6 +179,7 @@ struct HrtContext {
     std::atomic<uint64_t> tlas_refits{0}, tlas_rebuilds{0}; std::atomic<double> tlas_refit_ratio{1.0};   // (builds run on several loader threads)
     int substreams = 0;                         // sub-tiles rendered on their own HIP streams so that one's tail overlaps another's bulk
     std::vector<hipStream_t> sub_streams; std::vector<hipEvent_t> sub_done; hipEvent_t ev_begin = nullptr;
+    hipStream_t graph_stream = nullptr; hipEvent_t ev_graph_done = nullptr;     // wavefront mode's graph capture when the caller's stream is the null stream
 };
 
 namespace hrt {

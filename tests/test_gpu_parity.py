@@ -1096,6 +1096,7 @@ MODES = {
     "default": {},
     "wavefront": {"HRT_FUSED": "0"},
     "wavefront-every-launch-enqueued-no-graph": {"HRT_FUSED": "0", "HRT_WAVEFRONT_GRAPH": "0"},
+    "wavefront-round-1-traverse-kernel": {"HRT_FUSED": "0", "HRT_WAVEFRONT_LEAN": "0"},
     "wavefront-by-tile-size": {"HRT_FUSED": "-1", "HRT_FUSED_MAX_PIXELS": "16000"},
     "wavefront-lds-dma-gather": {"HRT_FUSED": "0", "HRT_LDS_GATHER": "1"},
     "wavefront-substreams": {"HRT_FUSED": "0", "HRT_SUBSTREAMS": "3", "HRT_SUBSTREAM_MIN_PIXELS": "1024"},
@@ -1151,6 +1152,39 @@ def test_every_execution_mode_is_bit_exact(hrt, oracle, gpu_available, monkeypat
             r.render(1)
             ref2 = osc.render(w, h, states, 1)
             assert np.array_equal(r.linear.cpu().numpy().view(np.uint32), ref2["linear"].view(np.uint32)), mode
+    finally:
+        r.close()
+
+
+def test_fast_trace_tree_with_spatial_splits(hrt, oracle, gpu_available):
+    """HRT_CTX_FAST_TRACE (the reference's PREFER_FAST_TRACE on its static geometry, RendererImpl.cu:94): the host builder with spatial
+    splits (SBVH) -- triangles referenced from several leaves, each with the box of its part.  Duplicates cannot change the
+    canonical hit: image, RNG states, ray counts and hit records are the oracle's; the tree does hold more records than the scene
+    has triangles; and an update (a refit from whole primitives, then whatever the quality guard decides) keeps the frame exact."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    r = hrt.Renderer(0, hrt.CTX_FAST_TRACE)
+    try:
+        w, h, spp = 160, 100, 2
+        scene = hrt.scenes.random_soup(60000, 0.06, 9, w, h, spp)
+        r.load_scene(scene)
+        _moved_scene_matches_oracle(hrt, oracle, r, scene, w, h, 3, spp)
+        st = r.stats()
+        assert st.bvh_triangles == 60000 and st.bvh_bytes > st.bvh_nodes * 80 + 60000 * 48 * 1.05       # duplicated references
+        blob = hrt.BvhBlob()
+        import ctypes as C
+        r._check(r.lib.hrt_tlas_download(r.ctx, r.tlas, C.byref(blob)), "download")
+        assert blob.n_triangles > 63000
+        r.lib.hrt_host_free(C.byref(blob))
+        scene2 = hrt.scenes.mixed_test_scene(4000, 30, 5, w, h, spp)
+        r.load_scene(scene2)
+        _moved_scene_matches_oracle(hrt, oracle, r, scene2, w, h, 4, spp)
+        moved = [it["transform"].copy() for it in scene2["instances"]]
+        moved[0][3] += 0.1
+        r.update_instances(moved)
+        for it, m in zip(scene2["instances"], moved):
+            it["transform"] = m
+        _moved_scene_matches_oracle(hrt, oracle, r, scene2, w, h, 5, spp)
     finally:
         r.close()
 

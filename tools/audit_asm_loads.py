@@ -73,7 +73,7 @@ def audit(source, kernel_prefix, verbose=False):
 if __name__ == "__main__":
     v = "-v" in sys.argv
     total_groups = total_bad = 0
-    for src, prefix in (("nvidia-optix-ray-tracer_amd/csrc/kernels.hip", "_ZN3hrt10k_traverse"), ("nvidia-optix-ray-tracer_amd/csrc/fused.hip", "_ZN3hrt7k_fused"), ("nvidia-optix-ray-tracer_amd/csrc/paths.hip", "_ZN3hrt7k_paths")):
+    for src, prefix in (("nvidia-optix-ray-tracer_amd/csrc/kernels.hip", "_ZN3hrt10k_traverse"), ("nvidia-optix-ray-tracer_amd/csrc/fused.hip", "_ZN3hrt7k_fused"), ("nvidia-optix-ray-tracer_amd/csrc/fused_queue.hip", "_ZN3hrt13k_trace_queue"), ("nvidia-optix-ray-tracer_amd/csrc/paths.hip", "_ZN3hrt7k_paths")):
         g, b = audit(src, prefix, v)
         print(f"{src}: {g} groups of in-flight loads checked, {b} hazardous instructions")
         total_groups += g; total_bad += b
