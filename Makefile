@@ -86,13 +86,14 @@ $(info RCCL not found under $(ROCM_PATH): skipping hrt_render (the multi-GPU dri
 endif
 tools: $(MULTI_GPU_TOOL) $(LIBDIR)/hrt_time_render $(LIBDIR)/hrt_mesh_render
 
-$(LIBDIR)/hrt_render: $(CSRC)/host/hrt_render.cpp $(CSRC)/host/renderer_host.hpp $(CSRC)/host/multi_gpu.hpp $(LIBDIR)/libhrt.so
+TOOL_HDRS := include/hrt.h include/hrt_params.h include/hrt_io.h
+$(LIBDIR)/hrt_render: $(CSRC)/host/hrt_render.cpp $(CSRC)/host/renderer_host.hpp $(CSRC)/host/multi_gpu.hpp $(TOOL_HDRS) $(LIBDIR)/libhrt.so
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Iinclude -I$(CSRC) -I$(ROCM_PATH)/include -o $@ $< -L$(LIBDIR) -lhrt -L$(ROCM_PATH)/lib -lrccl -pthread -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM_PATH)/lib
 
-$(LIBDIR)/hrt_time_render: $(CSRC)/host/hrt_time_render.cpp $(CSRC)/host/renderer_host.hpp $(LIBDIR)/libhrt.so $(LIBDIR)/libhrt_io.so
+$(LIBDIR)/hrt_time_render: $(CSRC)/host/hrt_time_render.cpp $(CSRC)/host/renderer_host.hpp $(TOOL_HDRS) $(LIBDIR)/libhrt.so $(LIBDIR)/libhrt_io.so
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Iinclude -I$(CSRC) -o $@ $< -L$(LIBDIR) -lhrt -lhrt_io -Wl,-rpath,'$$ORIGIN'
 
-$(LIBDIR)/hrt_mesh_render: $(CSRC)/host/hrt_mesh_render.cpp $(CSRC)/host/renderer_host.hpp $(LIBDIR)/libhrt.so $(LIBDIR)/libhrt_io.so
+$(LIBDIR)/hrt_mesh_render: $(CSRC)/host/hrt_mesh_render.cpp $(CSRC)/host/renderer_host.hpp $(TOOL_HDRS) $(LIBDIR)/libhrt.so $(LIBDIR)/libhrt_io.so
 	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 -Iinclude -I$(CSRC) -o $@ $< -L$(LIBDIR) -lhrt -lhrt_io -pthread -Wl,-rpath,'$$ORIGIN'
 
 clean:

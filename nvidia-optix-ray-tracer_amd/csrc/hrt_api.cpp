@@ -164,7 +164,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_SUBSTREAM_MIN_PIXELS")) { const int v = std::atoi(e); if (v >= 1024) ctx->substream_min_pixels = v; }
     if (const char *e = std::getenv("HRT_SUBSTREAMS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) ctx->substreams = v; }
     if (const char *e = std::getenv("HRT_FUSED_MAX_DEPTH")) { const int v = std::atoi(e); if (v >= 0 && v <= kFusedMaxDepth) ctx->fused_max_depth = v; }
-    if (const char *e = std::getenv("HRT_WAVEFRONT_GRAPH")) ctx->wavefront_graph = std::atoi(e) != 0;
+    if (const char *e = std::getenv("HRT_WAVEFRONT_GRAPH")) ctx->wavefront_graph = std::atoi(e);
     if (const char *e = std::getenv("HRT_WAVEFRONT_LEAN")) ctx->wavefront_lean = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_FUSED_MAX_BYTES")) { const unsigned long long v = std::strtoull(e, nullptr, 0); if (v >= 1 && v <= (1ull << 32)) ctx->fused_max_bytes = v; }
     if (const char *e = std::getenv("HRT_TAIL_REGEN")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->fused_tail_regen = v; }
@@ -467,7 +467,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
     // hipGraph replay of the per-sample launch sequence (below).  A capture cannot run on the legacy null stream -- the one the
     // reference, and a caller that passes NULL, uses -- so the pipeline then runs on a stream of the context's own, ordered after
     // the caller's work by an event and joined back before the finalize kernel.
-    const bool want_graph = ctx->wavefront_graph && S == 1 && (ctx->flags & HRT_CTX_TIMING) == 0 && spp >= 4u;
+    const bool want_graph = ctx->wavefront_graph && S == 1 && (ctx->flags & HRT_CTX_TIMING) == 0 && spp >= 5u;
     hipStream_t ws = s;
     if (want_graph && s == nullptr) {
         if (!ctx->graph_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->graph_stream, hipStreamNonBlocking));
@@ -587,16 +587,19 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
     uint32_t sample = 0;
     rc = sample_body(sample++);
     if (rc != HRT_OK) return rc;
-    // Samples 1 .. spp - 2 enqueue the same ~45 operations on the same buffers, alternating between the two workspace sets:
+    // Samples 2 .. spp - 2 enqueue the same ~45 operations on the same buffers, alternating between the two workspace sets:
     // a pair of them is captured once as a hipGraph and replayed (HRT_WAVEFRONT_GRAPH=1; one stream, no per-kernel event
     // timers inside a graph, so not under HRT_CTX_TIMING).  Every kernel reads its ray count from device memory, so the
-    // replayed launches are the eager ones, and the image is the same bits.
+    // replayed launches are the eager ones, and the image is the same bits.  (Sample 1 is not like the others: its launches
+    // add sample 0 to the running sum with the "initialise" flag set.)
     if (want_graph) {
-        const uint32_t pairs = (spp - 2u) / 2u;
+        rc = sample_body(sample++);
+        if (rc != HRT_OK) return rc;
+        const uint32_t pairs = (spp - 3u) / 2u;
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
         HIP_TRY(ctx, hipStreamBeginCapture(ws, hipStreamCaptureModeThreadLocal));
-        int rc1 = sample_body(1u);
-        if (rc1 == HRT_OK) rc1 = sample_body(2u);
+        int rc1 = sample_body(2u);
+        if (rc1 == HRT_OK) rc1 = sample_body(3u);
         const hipError_t ce = hipStreamEndCapture(ws, &graph);
         if (rc1 != HRT_OK) { if (graph) (void)hipGraphDestroy(graph); return rc1; }
         HIP_TRY(ctx, ce);

@@ -151,7 +151,8 @@ struct HrtContext {
     uint64_t fused_max_bytes = 1ull << 32;      // k_fused addresses nodes and records by 32-bit byte offsets: larger arrays take round 1's kernel (HRT_FUSED_MAX_BYTES lowers it: tests)
     uint64_t fused_fallback_launches = 0;       // launches that took round 1's path kernel because the tree did not fit k_fused
     int wavefront_lean = 1;                     // wavefront mode traverses with k_trace_queue (the loop of k_fused); 0: round 1's k_traverse (HRT_WAVEFRONT_LEAN)
-    int wavefront_graph = 1;                    // wavefront mode: replay a captured pair of samples as a hipGraph (HRT_WAVEFRONT_GRAPH=0: enqueue every launch)
+    int wavefront_graph = 0;                    // wavefront mode: 1 = replay a captured pair of samples as a hipGraph; 0 (default) = enqueue every launch: the launches
+                                                // are not what limits the mode (traversal is 85 % of its GPU time), profiles/r03_wavefront.txt
     uint64_t graph_replays = 0;
     int fused_tail_regen = 12;                  // k_fused, tile used up: finished rays that wait before a regeneration (HRT_TAIL_REGEN; 1/8 of C4: 142 ms with 1, 129 with 8..16)
     int leaf_quorum = 1;                        // k_fused: lanes with nothing but leaf work wait until this many of them have gathered (HRT_LEAF_QUORUM)

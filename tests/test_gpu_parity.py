@@ -1095,7 +1095,7 @@ def test_errors_are_loud(hrt, renderer):
 MODES = {
     "default": {},
     "wavefront": {"HRT_FUSED": "0"},
-    "wavefront-every-launch-enqueued-no-graph": {"HRT_FUSED": "0", "HRT_WAVEFRONT_GRAPH": "0"},
+    "wavefront-samples-replayed-from-a-graph": {"HRT_FUSED": "0", "HRT_WAVEFRONT_GRAPH": "1"},
     "wavefront-round-1-traverse-kernel": {"HRT_FUSED": "0", "HRT_WAVEFRONT_LEAN": "0"},
     "wavefront-by-tile-size": {"HRT_FUSED": "-1", "HRT_FUSED_MAX_PIXELS": "16000"},
     "wavefront-lds-dma-gather": {"HRT_FUSED": "0", "HRT_LDS_GATHER": "1"},
@@ -1190,15 +1190,16 @@ def test_fast_trace_tree_with_spatial_splits(hrt, oracle, gpu_available):
 
 
 def test_wavefront_mode_replays_a_captured_graph(hrt, oracle, gpu_available, monkeypatch):
-    """Wavefront mode (separate generate / traverse / bin / shade / accumulate kernels): the launches of samples 1 and 2 are
-    captured as a hipGraph and replayed for the following pairs.  9 samples = sample 0 enqueued, 3 replays, samples 7 and 8
-    enqueued: image, RNG states and ray count are the oracle's, and the replays did happen."""
+    """Wavefront mode (separate generate / traverse / bin / shade / accumulate kernels) with HRT_WAVEFRONT_GRAPH=1: the launches of
+    samples 2 and 3 are captured as a hipGraph and replayed for the following pairs.  10 samples = samples 0 and 1 enqueued, 3 replays,
+    samples 8 and 9 enqueued: image, RNG states and ray count are the oracle's, and the replays did happen."""
     if not gpu_available:
         pytest.skip("no GPU")
     monkeypatch.setenv("HRT_FUSED", "0")
+    monkeypatch.setenv("HRT_WAVEFRONT_GRAPH", "1")
     r = hrt.Renderer(0, 0)
     try:
-        w, h, spp, salt = 150, 90, 9, 77
+        w, h, spp, salt = 150, 90, 10, 77
         scene = hrt.scenes.mixed_test_scene(2500, 50, 13, w, h, spp)
         r.load_scene(scene)
         r.set_frame(w, h, salt, aov=False, linear=True)
