@@ -141,7 +141,7 @@ struct HrtContext {
     double kernel_ms[HRT_K_COUNT] = {0}; uint64_t kernel_launches[HRT_K_COUNT] = {0};
     float4 *d_linear = nullptr;
     int refill_threshold = 16;                  // wavefront mode; fused mode: fused_refill_threshold
-    int fused_refill_threshold = 16, fused_fetch_chunk = 16;   // measured optimum of the fused path mode (profiles/r01_sweep_fused_*.txt, r02_sweep_fused_knobs.txt)
+    int fused_refill_threshold = 20, fused_fetch_chunk = 16;   // measured optimum of the fused path mode (profiles/r01_sweep_fused_*.txt, r02_sweep_fused_knobs.txt, r03_sweep_fused_knobs.txt: 20 is 1 % ahead of 16)
     int traverse_blocks_per_cu = 16;            // one-wave workgroups of the wavefront traverse kernel per CU
     int fused_blocks_per_cu = 20;               // ... of the fused path kernels: round 1's takes 5 waves per SIMD (96 VGPRs), k_fused is capped at kFusedBlocksPerCu
     bool traverse_blocks_auto = true;           // fused mode: fewer of them for small tiles (not when the env knob is set)
