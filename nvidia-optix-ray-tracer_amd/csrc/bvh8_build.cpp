@@ -64,6 +64,8 @@ struct Builder {
     // references are harmless to the canonical closest hit (min t, then min (instance, primitive)).
     bool spatial = false;
     int n_bins = 16;                     // object-split bins per axis
+    uint32_t spatial_min_refs = 48;            // spatial splits are tried in nodes of at least this many references (HRT_SBVH_MIN_REFS): below, they cost build time and references for nothing (profiles/r03_tree_quality_cpu.txt)
+    uint32_t spatial_max_refs = 0xffffffffu;   // experiment knob (HRT_SBVH_MAX_REFS): spatial splits only in nodes with at most this many references
     float spatial_bias = 0.95f;          // < 1 favours spatial splits over object splits of equal SAH cost (C4: 3610 -> 3663 Mrays/s at 0.95, no further gain below)
     float alpha = 1e-5f;                 // spatial splits are tried when area(left ∩ right) / area(root) exceeds this
     float root_area = 0.0f;
@@ -171,7 +173,7 @@ struct Builder {
         // ---- spatial split candidate ----
         int sp_axis = -1; float sp_pos = 0.0f, sp_cost = kInfF;
         Box3 sp_l, sp_r; uint32_t sp_nl = 0, sp_nr = 0;
-        if (spatial && budget.load(std::memory_order_relaxed) > 0) {
+        if (spatial && cnt <= spatial_max_refs && cnt >= spatial_min_refs && budget.load(std::memory_order_relaxed) > 0) {
             bool try_spatial = best_axis < 0;
             if (!try_spatial) {
                 float il[3], ih[3]; bool overlap = true;
@@ -328,6 +330,8 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
     if (const char *e = std::getenv("HRT_SBVH_BUDGET")) budget_frac = std::max(0.0, std::atof(e));
     if (const char *e = std::getenv("HRT_SBVH_ALPHA")) B.alpha = (float)std::atof(e);
     if (const char *e = std::getenv("HRT_SBVH_BIAS")) B.spatial_bias = (float)std::atof(e);
+    if (const char *e = std::getenv("HRT_SBVH_MIN_REFS")) B.spatial_min_refs = (uint32_t)std::strtoul(e, nullptr, 10);
+    if (const char *e = std::getenv("HRT_SBVH_MAX_REFS")) B.spatial_max_refs = (uint32_t)std::strtoul(e, nullptr, 10);
     const int64_t extra = B.spatial ? (int64_t)std::min<double>(budget_frac * (double)n, 3.0e9 - 2.0 * (double)n) : 0;
     B.budget = extra;
     if (const char *e = std::getenv("HRT_BVH_BINS")) B.n_bins = std::min(std::max(std::atoi(e), 2), 64);

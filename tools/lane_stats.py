@@ -6,7 +6,7 @@ import importlib, sys
 sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
 hrt = importlib.import_module("nvidia-optix-ray-tracer_amd")
 scene = hrt.scenes.soup_1m(1920, 1080, 16)
-r = hrt.Renderer(0, hrt.CTX_FAST_TRACE); r.load_scene(scene)      # the tree bench.py times; r.set_frame(1920, 1080, hrt.scenes.SEED_SALT, aov=False)
+r = hrt.Renderer(0, hrt.CTX_FAST_TRACE); r.load_scene(scene); r.set_frame(1920, 1080, hrt.scenes.SEED_SALT, aov=False)      # (the tree bench.py times)
 r.render(2); r.reset_stats(); r.render(16)
 s = r.stats()
 it, alive, node, prim = s.debug[0], s.debug[1], s.debug[2], s.debug[3]

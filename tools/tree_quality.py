@@ -2,7 +2,7 @@
 """Tree quality without a GPU: node visits / primitive tests per ray of a host-built BVH8, counted by the CPU walker of the
 test oracle over a realistic ray set -- the rays of path-traced samples of the scene (primary rays of a pixel subset and their
 rough bounces up to depth 5, generated here with numpy random numbers: only the distribution matters).
-    python tools/tree_quality.py [n_triangles=1000000] [n_pixels=60000]
+    python tools/tree_quality.py [n_triangles=1000000] [n_pixels=60000] [--empty]
 Environment knobs of the host builder (csrc/bvh8_build.cpp) select the variant; prints one line."""
 import ctypes as C, importlib, os, sys, time
 from pathlib import Path
@@ -56,8 +56,9 @@ def build(verts):
 
 
 if __name__ == "__main__":
-    n_tri = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-    n_px = int(sys.argv[2]) if len(sys.argv) > 2 else 60000
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n_tri = int(pos[0]) if len(pos) > 0 else 1_000_000
+    n_px = int(pos[1]) if len(pos) > 1 else 60000
     scene = hrt.scenes.soup_1m(1920, 1080, 1) if n_tri == 1_000_000 else hrt.scenes.random_soup(n_tri, hrt.scenes.soup_law_edge(n_tri), 1, 1920, 1080, 1)
     cache = Path("/tmp") / f"tq_rays_{n_tri}_{n_px}.npz"
     if cache.exists():
@@ -71,4 +72,16 @@ if __name__ == "__main__":
     knobs = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("HRT_"))
     print(f"{knobs or 'default':60s} build {secs:6.2f}s nodes {blob.n_nodes:8d} refs {blob.n_triangles:8d} | rays {len(o)} hits {hits} | "
           f"nodes/ray {nodes / len(o):6.3f} prims/ray {prims / len(o):6.3f} | est instr/ray {213 * nodes / len(o) + 83 * prims / len(o):7.1f}")
+    if "--empty" in sys.argv:
+        # what the visits are made of: visits that find nothing to enter or test, for miss rays, hit rays, and hit rays culled with
+        # their final hit distance from the start (the best any traversal order could do)
+        t, prim = res[0], res[3]
+        hit = prim != 0xFFFFFFFF
+        def run(oo, dd, **kw):
+            r = oracle_py.bvh8_trace(blob.nodes, blob.triangles, oo, dd, **kw)
+            return r[5] / len(oo), oracle_py.bvh8_trace.last_empty_visits / len(oo)
+        na, ea = run(o, d); nm, em = run(o[~hit], d[~hit]); nh, eh = run(o[hit], d[hit])
+        d2 = (d[hit] * (t[hit] * np.float32(1.00001))[:, None]).astype(np.float32)
+        nb, eb = run(o[hit], d2, tmax=1.0)
+        print(f"  empty visits: all rays {ea:.3f} of {na:.3f} | miss rays {em:.3f} of {nm:.3f} | hit rays {eh:.3f} of {nh:.3f} | hit rays culled with t_hit from the start {eb:.3f} of {nb:.3f}")
     lib.hrt_host_free(C.byref(blob))
