@@ -152,3 +152,70 @@ if __name__ == "__main__":
         t0 = time.time(); rlo, rhi = presplit(v, beta, slo, shi)
         tot, root, rounds = ploc(rlo, rhi, 2)
         print("PLOC r=2 presplit beta %.1f: refs %d inner-area sum / root %.2f leaf-area sum / root %.2f (%.1fs)" % (beta, len(rlo), tot / root, half_area(rlo, rhi).sum() / root, time.time() - t0))
+
+
+def grid_cells_split(verts, G, slo, shi):
+    """every triangle cut at the planes of a uniform G^3 grid over the scene box: references (clipped boxes) that lie in one cell each"""
+    v = verts.astype(np.float64)
+    lo, hi = v.min(1), v.max(1)
+    tri = np.arange(len(v))
+    ext = shi - slo
+    for a in range(3):
+        step = ext[a] / G
+        for _ in range(3):                     # (a triangle of this soup spans at most two cells per axis)
+            ca = np.floor((lo[:, a] - slo[a]) / step + 1e-9).clip(0, G - 1); cb = np.floor((hi[:, a] - slo[a]) / step - 1e-9).clip(0, G - 1)
+            cross = cb > ca
+            if not cross.any():
+                break
+            pos = slo[a] + (ca[cross] + 1) * step
+            (l0, l1), (r0, r1) = clip_boxes(v[tri[cross]], lo[cross], hi[cross], a, pos)
+            r0[:, a] = np.maximum(r0[:, a], pos + 1e-12)
+            keep = ~cross
+            tri = np.concatenate([tri[keep], tri[cross], tri[cross]]); lo = np.concatenate([lo[keep], l0, r0]); hi = np.concatenate([hi[keep], l1, r1])
+            ok = (hi >= lo).all(1)
+            tri, lo, hi = tri[ok], lo[ok], hi[ok]
+    cen = 0.5 * (lo + hi)
+    cell = np.floor((cen - slo) / (ext / G)).clip(0, G - 1).astype(np.int64)
+    return lo, hi, cell[:, 0] * G * G + cell[:, 1] * G + cell[:, 2]
+
+
+def ploc_in_cells(lo, hi, cell, radius=2):
+    """PLOC inside every cell (a cluster only merges with clusters of its own cell), then PLOC over the cell roots"""
+    cen = 0.5 * (lo + hi)
+    key = morton(cen, cen.min(0), cen.max(0))
+    order = np.lexsort((key, cell))
+    lo, hi, cell = lo[order].copy(), hi[order].copy(), cell[order].copy()
+    total = 0.0
+    staged = True
+    while len(lo) > 1:
+        m = len(lo); idx = np.arange(m)
+        best = np.full(m, np.inf); nn = np.full(m, -1, np.int64)
+        for d in list(range(-radius, 0)) + list(range(1, radius + 1)):
+            j = idx + d; ok = (j >= 0) & (j < m); jj = np.clip(j, 0, m - 1)
+            if staged:
+                ok &= cell[jj] == cell
+            a = np.where(ok, half_area(np.minimum(lo, lo[jj]), np.maximum(hi, hi[jj])), np.inf)
+            better = a < best; best = np.where(better, a, best); nn = np.where(better, jj, nn)
+        valid = nn >= 0
+        mutual = valid & (nn[np.clip(nn, 0, m - 1)] == idx)
+        starts = mutual & (idx < nn); ends = mutual & (idx > nn)
+        if not starts.any():
+            if staged:
+                staged = False; continue
+            break
+        s = np.nonzero(starts)[0]
+        nlo, nhi = lo.copy(), hi.copy()
+        nlo[s] = np.minimum(lo[s], lo[nn[s]]); nhi[s] = np.maximum(hi[s], hi[nn[s]])
+        total += half_area(nlo[s], nhi[s]).sum()
+        keep = ~ends
+        lo, hi, cell = nlo[keep], nhi[keep], cell[keep]
+    return total, half_area(lo[0], hi[0])
+
+
+if __name__ == "__main__" and "--cells" in sys.argv:
+    for G in (4, 8, 16, 32):
+        t0 = time.time(); rlo, rhi, cell = grid_cells_split(v, G, slo, shi)
+        tot, root = ploc_in_cells(rlo, rhi, cell, 2)
+        print("grid %2d^3 cells + PLOC inside cells: refs %d inner-area sum / root %.2f leaf-area sum / root %.2f (%.1fs)" % (G, len(rlo), tot / root, half_area(rlo, rhi).sum() / root, time.time() - t0))
+        tot2, root2 = ploc_in_cells(lo, hi, np.floor((0.5 * (lo + hi) - slo) / ((shi - slo) / G)).clip(0, G - 1).astype(np.int64) @ np.array([G * G, G, 1]), 2)
+        print("          same cells by centroid, NO splitting: inner-area sum / root %.2f" % (tot2 / root2))
