@@ -308,6 +308,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         // HRT_CTX_FAST_TRACE: the static-scene tree, with spatial splits (a later refit recomputes the boxes from whole primitives:
         // valid, conservative, and without the splits' benefit -- the quality guard of hrt_tlas_update then rebuilds on the device)
         build_bvh8(prims, t.bvh, 0, scene_scale, kMaxLeafPrims, fast_trace);
+        t.has_split_refs = t.bvh.prims.size() > prims.size();
         for (size_t l = t.bvh.level_begin.size() - 1; l-- > 0;) t.phases.emplace_back(t.bvh.level_begin[l], t.bvh.level_begin[l + 1] - t.bvh.level_begin[l]);
     }
     const bool on_device = device_merged && first[n] != 0u;
@@ -636,7 +637,9 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
     std::vector<HrtInstance> inst;
     const int rc = download_instances(ctx, d_instances, n, s, inst);
     if (rc != HRT_OK) return rc;
-    bool same = ctx->refit != 0 && t->n_prims != 0u && !force_rebuild;
+    // (a tree with split references is a static-scene tree: refitted, its leaves would fall back to whole-primitive boxes around
+    // duplicated records -- worse than no splits -- so the first update replaces it by a device-built tree)
+    bool same = ctx->refit != 0 && t->n_prims != 0u && !force_rebuild && !t->has_split_refs;
     for (uint32_t i = 0; i < n && same; ++i)
         same = inst[i].traversableHandle == t->sig_handle[i] && (inst[i].visibilityMask & 1u) == t->sig_visibility[i];
     if (same && t->area_pending) {

@@ -69,6 +69,7 @@ struct Tlas {
     uint32_t *h_update_flags = nullptr;                  // pinned: [0..1] copy of the above after the last update, [2..3] their initial values
     std::vector<std::pair<uint32_t, uint32_t>> phases;   // (first, count) in processing order, children before parents
     bool instanced = false;
+    bool has_split_refs = false;                         // built with spatial splits (HRT_CTX_FAST_TRACE): a refit would recompute the leaf boxes from whole primitives, so the first update rebuilds instead
     const void **d_inst_src = nullptr;
     float *h_area = nullptr;                             // pinned: area sum of the last refit
     hipEvent_t area_ready = nullptr; bool area_pending = false;

@@ -1160,7 +1160,7 @@ def test_fast_trace_tree_with_spatial_splits(hrt, oracle, gpu_available):
     """HRT_CTX_FAST_TRACE (the reference's PREFER_FAST_TRACE on its static geometry, RendererImpl.cu:94): the host builder with spatial
     splits (SBVH) -- triangles referenced from several leaves, each with the box of its part.  Duplicates cannot change the
     canonical hit: image, RNG states, ray counts and hit records are the oracle's; the tree does hold more records than the scene
-    has triangles; and an update (a refit from whole primitives, then whatever the quality guard decides) keeps the frame exact."""
+    has triangles; and the first update replaces the split tree by a device-built one (a refit would fall back to whole-primitive boxes)."""
     if not gpu_available:
         pytest.skip("no GPU")
     r = hrt.Renderer(0, hrt.CTX_FAST_TRACE)
@@ -1181,10 +1181,16 @@ def test_fast_trace_tree_with_spatial_splits(hrt, oracle, gpu_available):
         _moved_scene_matches_oracle(hrt, oracle, r, scene2, w, h, 4, spp)
         moved = [it["transform"].copy() for it in scene2["instances"]]
         moved[0][3] += 0.1
+        before = r.stats()
+        assert before.bvh_bytes - before.bvh_nodes * 80 > (4000 + 30) * 48          # this tree has split references too
         r.update_instances(moved)
+        after = r.stats()
+        assert after.tlas_rebuilds == before.tlas_rebuilds + 1      # a tree with split references is not refitted: the update rebuilds (device build)
         for it, m in zip(scene2["instances"], moved):
             it["transform"] = m
         _moved_scene_matches_oracle(hrt, oracle, r, scene2, w, h, 5, spp)
+        r.update_instances(moved)
+        assert r.stats().tlas_refits == after.tlas_refits + 1        # ... and from then on it is an ordinary refittable tree
     finally:
         r.close()
 
