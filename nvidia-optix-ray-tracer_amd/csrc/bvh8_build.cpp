@@ -69,7 +69,6 @@ struct Builder {
     float spatial_bias = 0.95f;          // < 1 favours spatial splits over object splits of equal SAH cost (C4: 3610 -> 3663 Mrays/s at 0.95, no further gain below)
     float alpha = 1e-5f;                 // spatial splits are tried when area(left ∩ right) / area(root) exceeds this
     float root_area = 0.0f;
-    std::atomic<int64_t> budget{0};      // references the spatial splits may still add
 
     explicit Builder(const std::vector<BuildPrim> &p) : in(p) {}
 
@@ -119,7 +118,9 @@ struct Builder {
         }
     }
 
-    void build(uint32_t node, std::vector<Ref> refs, int depth) {
+    // budget: references the spatial splits of THIS subtree may still add; a split hands what is left to its children in proportion to
+    // their sizes, so the tree does not depend on thread timing and the node array (2 x (n + budget)) cannot overflow
+    void build(uint32_t node, std::vector<Ref> refs, int depth, int64_t budget) {
         const uint32_t cnt = (uint32_t)refs.size();
         Box3 nb, cb;
         for (const Ref &r : refs) {
@@ -173,7 +174,7 @@ struct Builder {
         // ---- spatial split candidate ----
         int sp_axis = -1; float sp_pos = 0.0f, sp_cost = kInfF;
         Box3 sp_l, sp_r; uint32_t sp_nl = 0, sp_nr = 0;
-        if (spatial && cnt <= spatial_max_refs && cnt >= spatial_min_refs && budget.load(std::memory_order_relaxed) > 0) {
+        if (spatial && cnt <= spatial_max_refs && cnt >= spatial_min_refs && budget > 0) {
             bool try_spatial = best_axis < 0;
             if (!try_spatial) {
                 float il[3], ih[3]; bool overlap = true;
@@ -226,7 +227,9 @@ struct Builder {
             // the two children as the binning pass found them (every straddling reference cut): B1, B2, N1, N2 of the paper's
             // unsplitting test; a reference moved whole to one side grows that side's box and leaves the other's count
             Box3 lb = sp_l, rb = sp_r; uint32_t nl = sp_nl, nr = sp_nr;
-            int64_t added = 0;
+            int64_t added = 0, straddlers = 0;
+            for (const Ref &r : refs) if (r.lo[a] < sp_pos && r.hi[a] > sp_pos) ++straddlers;
+            if (straddlers <= budget)
             for (const Ref &r : refs) {
                 if (r.hi[a] <= sp_pos) { left.push_back(r); continue; }
                 if (r.lo[a] >= sp_pos) { right.push_back(r); continue; }
@@ -245,7 +248,7 @@ struct Builder {
             }
             if (!left.empty() && !right.empty() && left.size() < cnt + (size_t)added && right.size() < cnt + (size_t)added &&
                 (left.size() < cnt || right.size() < cnt)) {
-                budget.fetch_sub(added, std::memory_order_relaxed);
+                budget -= added;
                 done = true;
             } else { left.clear(); right.clear(); }
         }
@@ -273,13 +276,14 @@ struct Builder {
 
         const uint32_t l = alloc2();
         nodes[node].left = l; nodes[node].right = l + 1;
+        const int64_t budget_l = budget > 0 ? (int64_t)((double)budget * (double)left.size() / (double)(left.size() + right.size())) : 0, budget_r = budget - budget_l;
         if (depth < max_par_depth && cnt > 65536) {
-            std::thread t([this, l, depth, lv = std::move(left)]() mutable { build(l, std::move(lv), depth + 1); });
-            build(l + 1, std::move(right), depth + 1);
+            std::thread t([this, l, depth, budget_l, lv = std::move(left)]() mutable { build(l, std::move(lv), depth + 1, budget_l); });
+            build(l + 1, std::move(right), depth + 1, budget_r);
             t.join();
         } else {
-            build(l, std::move(left), depth + 1);
-            build(l + 1, std::move(right), depth + 1);
+            build(l, std::move(left), depth + 1, budget_l);
+            build(l + 1, std::move(right), depth + 1, budget_r);
         }
     }
 };
@@ -333,16 +337,15 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
     if (const char *e = std::getenv("HRT_SBVH_MIN_REFS")) B.spatial_min_refs = (uint32_t)std::strtoul(e, nullptr, 10);
     if (const char *e = std::getenv("HRT_SBVH_MAX_REFS")) B.spatial_max_refs = (uint32_t)std::strtoul(e, nullptr, 10);
     const int64_t extra = B.spatial ? (int64_t)std::min<double>(budget_frac * (double)n, 3.0e9 - 2.0 * (double)n) : 0;
-    B.budget = extra;
     if (const char *e = std::getenv("HRT_BVH_BINS")) B.n_bins = std::min(std::max(std::atoi(e), 2), 64);
     B.root_area = scene_box.area();
-    B.nodes.resize(2 * ((size_t)n + (size_t)std::max<int64_t>(extra, 0)) + 64 * 1024);      // (threads may overshoot the budget by a few references each)
+    B.nodes.resize(2 * ((size_t)n + (size_t)std::max<int64_t>(extra, 0)) + 2);
     B.n_nodes = 1;
     int hw = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
     if (hw < 1) hw = 1;
     B.max_par_depth = 0;
     while ((1 << B.max_par_depth) < hw && B.max_par_depth < 6) B.max_par_depth++;
-    B.build(0, std::move(refs), 0);
+    B.build(0, std::move(refs), 0, extra);
 
     for (int a = 0; a < 3; ++a) { out.lo[a] = B.nodes[0].lo[a]; out.hi[a] = B.nodes[0].hi[a]; }
 

@@ -319,6 +319,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
     t.n_instances = n;
     t.blas_refs = std::move(refs);
     t.node_stride = (uint32_t)ctx->node_stride; t.prim_stride = (uint32_t)ctx->prim_stride;
+    if (ctx->node_stride_auto && first[n] > 3500000u) t.node_stride = 128u;      // a tree that will not fit the Infinity Cache: one 128-byte line per node
     // A device build emits its nodes into the build's working memory, sized for the worst case (one node per primitive;
     // typically a seventh is used); the TLAS gets buffers of the size the build turned out to need (below).
     const size_t n_nodes = on_device ? 0 : t.bvh.nodes.size(), n_prims = on_device ? (size_t)first[n] : t.bvh.prims.size();

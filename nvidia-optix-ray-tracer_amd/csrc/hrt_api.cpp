@@ -140,7 +140,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
         return fail(nullptr, HRT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(hipGetLastError()));
     if (const char *e = std::getenv("HRT_TRAVERSE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) { ctx->traverse_blocks_per_cu = v; ctx->fused_blocks_per_cu = v; ctx->traverse_blocks_auto = false; } }
     if (const char *e = std::getenv("HRT_FETCH_CHUNK")) { const int v = std::atoi(e); if (v >= 8 && v <= 4096) { ctx->fetch_chunk = v; ctx->fused_fetch_chunk = v; } }
-    if (const char *e = std::getenv("HRT_NODE_STRIDE")) { const int v = std::atoi(e); if (v >= 80 && v <= 256 && v % 16 == 0) ctx->node_stride = v; }
+    if (const char *e = std::getenv("HRT_NODE_STRIDE")) { const int v = std::atoi(e); if (v >= 80 && v <= 256 && v % 16 == 0) { ctx->node_stride = v; ctx->node_stride_auto = false; } }
     if (const char *e = std::getenv("HRT_PRIM_STRIDE")) { const int v = std::atoi(e); if (v >= 48 && v <= 256 && v % 16 == 0) ctx->prim_stride = v; }
     if (const char *e = std::getenv("HRT_FUSED")) ctx->fused = std::atoi(e);
     if (const char *e = std::getenv("HRT_PATHS_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 20) ctx->paths_blocks_per_cu = v; }

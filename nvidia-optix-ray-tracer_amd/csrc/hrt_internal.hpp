@@ -159,6 +159,9 @@ struct HrtContext {
     int leaf_quorum = 1;                        // k_fused: lanes with nothing but leaf work wait until this many of them have gathered (HRT_LEAF_QUORUM)
     int tail_split = 1;
     int node_stride = 80, prim_stride = 64;     // bytes between records in HBM (80/48 packed; 128/64 = one cache line each)
+    bool node_stride_auto = true;               // no HRT_NODE_STRIDE given: trees beyond the Infinity Cache (> 3.5 M primitives) get 128-byte nodes -- a packed
+                                                // 80-byte node straddles two 128-byte lines two times in five, which only costs once the lines come from HBM
+                                                // (32 M triangles: +3.4 %, 8 M: +1 %, C4: -3 %; profiles/r03_large_scenes_node_stride.txt)
     int fused = 1;                              // 1: fused persistent path kernel k_fused (default), 2: round 1's fused kernel, 3: slot-pipeline path kernel k_paths, 0: wavefront kernels, -1: fused only for small tiles
     int paths_slots = 112;                      // k_paths: pixels in flight per wave (80 / 96 / 112 / 128): 64 in lanes, the rest queued in LDS
     int paths_blocks_per_cu = 20;               // k_paths: one-wave workgroups per CU, at most what the LDS holds (20 / 18 / 16 / 15 for the slot counts above)

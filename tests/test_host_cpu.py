@@ -142,6 +142,31 @@ def test_host_bvh8_spatial_splits_keep_the_canonical_hit(hrt, oracle, monkeypatc
     lib.hrt_host_free(C.byref(blob))
 
 
+def test_host_bvh8_spatial_split_budget_and_determinism(hrt, oracle, monkeypatch):
+    """The references spatial splits may add are a budget handed down the tree (HRT_SBVH_BUDGET x n for the root, shared among
+    children in proportion to their sizes): the tree never holds more than n + budget references, whatever the worker threads'
+    timing, and two builds of the same input are the same bytes."""
+    n = 150000                                                    # large enough for the builder to fork worker threads
+    scene = hrt.scenes.random_soup(n, 0.03, 5)
+    v = scene["instances"][0]["vertices"]
+    monkeypatch.setenv("HRT_SBVH", "1")
+    sizes = {}
+    for budget in ("0", "0.02", "2"):
+        monkeypatch.setenv("HRT_SBVH_BUDGET", budget)
+        lib, blob = _build(hrt, v)
+        sizes[budget] = int(blob.n_triangles)
+        assert n <= blob.n_triangles <= n + int(float(budget) * n)
+        nodes = np.ctypeslib.as_array(C.cast(blob.nodes, C.POINTER(C.c_uint8)), (blob.n_nodes * 80,)).copy()
+        prims = np.ctypeslib.as_array(C.cast(blob.triangles, C.POINTER(C.c_uint8)), (blob.n_triangles * 48,)).copy()
+        lib.hrt_host_free(C.byref(blob))
+        lib, blob = _build(hrt, v)
+        assert blob.n_triangles == sizes[budget]
+        assert np.array_equal(nodes, np.ctypeslib.as_array(C.cast(blob.nodes, C.POINTER(C.c_uint8)), (blob.n_nodes * 80,)))
+        assert np.array_equal(prims, np.ctypeslib.as_array(C.cast(blob.triangles, C.POINTER(C.c_uint8)), (blob.n_triangles * 48,)))
+        lib.hrt_host_free(C.byref(blob))
+    assert sizes["0"] == n and sizes["0"] < sizes["0.02"] < sizes["2"]
+
+
 def test_empty_bvh(hrt, oracle):
     lib = _host_bvh_lib(hrt)
     blob = hrt.BvhBlob()
