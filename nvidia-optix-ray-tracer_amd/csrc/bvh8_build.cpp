@@ -277,7 +277,7 @@ struct Builder {
         const uint32_t l = alloc2();
         nodes[node].left = l; nodes[node].right = l + 1;
         const int64_t budget_l = budget > 0 ? (int64_t)((double)budget * (double)left.size() / (double)(left.size() + right.size())) : 0, budget_r = budget - budget_l;
-        if (depth < max_par_depth && cnt > 65536) {
+        if (depth < max_par_depth && cnt > 8192) {
             std::thread t([this, l, depth, budget_l, lv = std::move(left)]() mutable { build(l, std::move(lv), depth + 1, budget_l); });
             build(l + 1, std::move(right), depth + 1, budget_r);
             t.join();
@@ -344,7 +344,7 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
     int hw = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
     if (hw < 1) hw = 1;
     B.max_par_depth = 0;
-    while ((1 << B.max_par_depth) < hw && B.max_par_depth < 6) B.max_par_depth++;
+    while ((1 << B.max_par_depth) < 2 * hw && B.max_par_depth < 9) B.max_par_depth++;      // (twice as many subtree tasks as threads: the subtrees are not equally expensive)
     B.build(0, std::move(refs), 0, extra);
 
     for (int a = 0; a < 3; ++a) { out.lo[a] = B.nodes[0].lo[a]; out.hi[a] = B.nodes[0].hi[a]; }
