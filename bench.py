@@ -169,9 +169,9 @@ def main():
     W, H, spp = scene["width"], scene["height"], scene["spp"]
 
     # The scene is static, so trace speed is preferred to build speed, as the reference does for its geometry
-    # (OPTIX_BUILD_FLAG_PREFER_FAST_TRACE, RendererImpl.cu:94): HRT_CTX_FAST_TRACE = the host's binned-SAH tree (0.65 s, outside the timed
-    # region).  HRT_BENCH_DEVICE_BUILD=1 times the frame on the device-built PLOC tree instead (8 ms with the upload, 2.5 % more node
-    # visits per ray, ~3.5 % fewer Mrays/s: profiles/r02_build_bench.txt).
+    # (OPTIX_BUILD_FLAG_PREFER_FAST_TRACE, RendererImpl.cu:94): HRT_CTX_FAST_TRACE = the host's binned-SAH tree with spatial splits (~2.5 s,
+    # outside the timed region).  HRT_BENCH_DEVICE_BUILD=1 times the frame on the device-built PLOC tree instead (8 ms with the upload, 13 % more
+    # node visits per ray, ~10 % fewer Mrays/s); either way the line carries the other builder's rate as config.alt_builder.
     device_build = os.environ.get("HRT_BENCH_DEVICE_BUILD") == "1"
     # HRT_BENCH_NO_TIMING=1: no per-kernel HIP events (wavefront mode then replays its samples from a hipGraph; the roofline block has no kernel time)
     timing = 0 if os.environ.get("HRT_BENCH_NO_TIMING") == "1" else hrt.CTX_TIMING
@@ -309,7 +309,7 @@ def main():
                                    f"{W}x{H}, {spp} spp, depth {5}, tile-split x{world} (8-row stripes, BVH replicated)",
                        "rays_per_step": int(total_rays / max(args.steps, 1)), "rays_per_path": round(st.rays / max(st.paths, 1), 4),
                        "bvh_nodes": int(st.bvh_nodes), "bvh_bytes": int(st.bvh_bytes), "bvh_build_s": round(build_s, 3),
-                       "bvh_builder": "device PLOC (build.hip)" if device_build else "host binned SAH (HRT_CTX_FAST_TRACE)"},
+                       "bvh_builder": "device PLOC (build.hip)" if device_build else "host binned SAH with spatial splits (HRT_CTX_FAST_TRACE)"},
             # What bounds the kernel is INSTRUCTION ISSUE (`bound`, `issue_frac`, `useful_lane_frac`: DESIGN.md section 4.1), not memory:
             # the tree of this scene is resident in L2 / Infinity Cache.  `achieved` / `peak` / `frac` stay the contract's figure
             # (ALGORITHMIC bytes -- 80 B per node visit + 48 B per primitive test -- over the launch time over the HBM
@@ -344,7 +344,7 @@ def main():
             torch.cuda.synchronize(dev)
             alt_dt = time.perf_counter() - t0
             sa = alt.stats()
-            out["config"]["alt_builder"] = {"bvh_builder": "host binned SAH (HRT_CTX_FAST_TRACE)" if device_build else "device PLOC (build.hip)",
+            out["config"]["alt_builder"] = {"bvh_builder": "host binned SAH with spatial splits (HRT_CTX_FAST_TRACE)" if device_build else "device PLOC (build.hip)",
                                             "value": round(sa.rays / alt_dt / 1e6, 3), "unit": "Mrays/s", "steps": alt_steps,
                                             "bvh_nodes": int(sa.bvh_nodes), "bvh_build_s": round(alt_build_s, 3)}
             alt.close()
