@@ -295,6 +295,10 @@ struct Builder {
 
 inline uint8_t unary_count(uint32_t n) { return (uint8_t)((1u << n) - 1u); }
 
+// cost table of a BVH2 node for the optimal collapse: c[i] = cheapest representation of the subtree as a forest of at most i roots, i = 1..7;
+// split[j], j = 2..8 = roots given to the left child when j roots are distributed over the two children
+struct Cost { float c[8]; uint8_t leaf1; uint8_t use_dist[8]; uint8_t split[9]; };
+
 }  // namespace
 
 void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, float scene_scale, uint32_t max_leaf_prims, bool spatial_splits) {
@@ -360,39 +364,50 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
     // ---- optimal collapse: cost tables bottom-up (children always have larger indices than parents) ----
     const uint32_t nb2 = B.n_nodes.load();
     // c_prim measured on MI355X (C4): 0.3 -> 1674, 0.45 -> 1691, 0.6 -> 1691, 1.0 -> 1684 Mrays/s
-    float kCNode = 1.0f, kCPrim = 0.45f; const float kInf = std::numeric_limits<float>::infinity();
+    float kCNode = 1.0f, kCPrim = 0.45f;
     if (const char *e = std::getenv("HRT_BVH_CPRIM")) kCPrim = (float)std::atof(e);     // tuning experiments
     if (const char *e = std::getenv("HRT_BVH_CNODE")) kCNode = (float)std::atof(e);
-    struct Cost { float c[8]; uint8_t leaf1; uint8_t use_dist[8]; uint8_t split[9]; };   // c[i], i = 1..7; split[j], j = 2..8
     std::vector<Cost> cost(nb2);
-    for (uint32_t ni = nb2; ni-- > 0;) {
-        const B2 &bn = B.nodes[ni];
-        Cost &cn = cost[ni];
-        std::memset(&cn, 0, sizeof cn);
-        const float area = half_area(bn.lo, bn.hi);
-        const float c_leaf = bn.nprims <= max_leaf_prims ? area * kCPrim * (float)bn.nprims : kInf;
-        if (bn.count > 0) {                      // BVH2 leaf
-            for (int i = 1; i <= 7; ++i) cn.c[i] = c_leaf;
-            cn.leaf1 = 1;
-            continue;
-        }
-        const Cost &cl = cost[bn.left], &cr = cost[bn.right];
-        float dist[9];
-        for (int j = 2; j <= 8; ++j) {
-            float best = kInf; int bk = 1;
-            for (int k = 1; k < j; ++k) {
-                const float v = cl.c[std::min(k, 7)] + cr.c[std::min(j - k, 7)];
-                if (v < best) { best = v; bk = k; }
+    {   // post-order over the BVH2, the big subtrees on worker threads like the build itself (a table depends on its children's only)
+        struct Pass {
+            const Builder &B; std::vector<Cost> &cost; float c_node, c_prim; uint32_t max_leaf; int par_depth;
+            void run(uint32_t ni, int depth) {
+                const B2 &bn = B.nodes[ni];
+                Cost &cn = cost[ni];
+                std::memset(&cn, 0, sizeof cn);
+                const float kInf = std::numeric_limits<float>::infinity();
+                const float area = half_area(bn.lo, bn.hi);
+                const float c_leaf = bn.nprims <= max_leaf ? area * c_prim * (float)bn.nprims : kInf;
+                if (bn.count > 0) {                      // BVH2 leaf
+                    for (int i = 1; i <= 7; ++i) cn.c[i] = c_leaf;
+                    cn.leaf1 = 1;
+                    return;
+                }
+                if (depth < par_depth && bn.nprims > 8192) {
+                    std::thread t([this, &bn, depth] { run(bn.left, depth + 1); });
+                    run(bn.right, depth + 1);
+                    t.join();
+                } else { run(bn.left, depth + 1); run(bn.right, depth + 1); }
+                const Cost &cl = cost[bn.left], &cr = cost[bn.right];
+                float dist[9];
+                for (int j = 2; j <= 8; ++j) {
+                    float best = kInf; int bk = 1;
+                    for (int k = 1; k < j; ++k) {
+                        const float v = cl.c[std::min(k, 7)] + cr.c[std::min(j - k, 7)];
+                        if (v < best) { best = v; bk = k; }
+                    }
+                    dist[j] = best; cn.split[j] = (uint8_t)bk;
+                }
+                const float c_internal = dist[8] + area * c_node;
+                cn.leaf1 = c_leaf <= c_internal ? 1 : 0;
+                cn.c[1] = std::min(c_leaf, c_internal);
+                for (int i = 2; i <= 7; ++i) {
+                    if (dist[i] < cn.c[i - 1]) { cn.c[i] = dist[i]; cn.use_dist[i] = 1; }
+                    else { cn.c[i] = cn.c[i - 1]; cn.use_dist[i] = 0; }
+                }
             }
-            dist[j] = best; cn.split[j] = (uint8_t)bk;
-        }
-        const float c_internal = dist[8] + area * kCNode;
-        cn.leaf1 = c_leaf <= c_internal ? 1 : 0;
-        cn.c[1] = std::min(c_leaf, c_internal);
-        for (int i = 2; i <= 7; ++i) {
-            if (dist[i] < cn.c[i - 1]) { cn.c[i] = dist[i]; cn.use_dist[i] = 1; }
-            else { cn.c[i] = cn.c[i - 1]; cn.use_dist[i] = 0; }
-        }
+        } pass{B, cost, kCNode, kCPrim, max_leaf_prims, B.max_par_depth};
+        pass.run(0, 0);
     }
     // roots of the forest that represents subtree n with a budget of j roots (as chosen by the tables)
     struct Collector {
