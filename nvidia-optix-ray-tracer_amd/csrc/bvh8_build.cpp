@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <chrono>
 #include <cstdio>
@@ -424,87 +425,49 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
         }
     };
 
-    // ---- emit 8-wide nodes breadth first so that inner children are contiguous ----
-    struct Item { uint32_t b2; uint32_t depth; };
-    std::vector<Item> queue;
-    queue.reserve(n);
-    out.nodes.reserve(n / 2 + 8);
-    out.prims.reserve(B.nodes[0].nprims);
-    out.prim_bounds.reserve(6 * (size_t)B.nodes[0].nprims);
-
-    queue.push_back({0u, 0u});
-    out.nodes.emplace_back();
-    size_t head = 0;
-    while (head < queue.size()) {
-        const Item it = queue[head];
-        const uint32_t self = (uint32_t)head;
-        ++head;
-        const B2 &bn = B.nodes[it.b2];
-        out.max_depth = std::max(out.max_depth, it.depth);
-
+    // ---- emit 8-wide nodes breadth first so that inner children are contiguous: level by level, the nodes of a level in parallel
+    //      (children, slots, quantised boxes, leaf records), a serial prefix in between for the child / primitive bases -- the
+    //      numbering is that of a breadth-first queue ----
+    struct Local {
+        Bvh8Node nd; uint32_t inner_b2[8]; uint32_t n_inner = 0, n_leaf = 0;
+        uint32_t leaf_prim[8 * kMaxLeafPrims]; const B2 *leaf_box[8 * kMaxLeafPrims];
+    };
+    auto emit_node = [&](uint32_t b2, Local &L) {
+        const B2 &bn = B.nodes[b2];
         uint32_t ch[8]; int nch = 0;
         bool ch_leaf[8];
-        if (bn.count > 0 || (it.b2 == 0 && bn.nprims <= max_leaf_prims)) {
-            ch[nch] = it.b2; ch_leaf[nch] = true; ++nch;         // the whole scene fits one leaf: wrap it
+        if (bn.count > 0 || (b2 == 0 && bn.nprims <= max_leaf_prims)) {
+            ch[nch] = b2; ch_leaf[nch] = true; ++nch;         // the whole scene fits one leaf: wrap it
         } else {
             Collector col{B, cost};
-            col.distribute(it.b2, 8);
+            col.distribute(b2, 8);
             for (int k = 0; k < col.n; ++k) {
                 ch[nch] = col.out[k];
                 ch_leaf[nch] = B.nodes[col.out[k]].count > 0 || cost[col.out[k]].leaf1;
                 ++nch;
             }
         }
-
         // slot assignment: slot s is visited first by rays of octant s (bit2 = -x, bit1 = -y, bit0 = -z)
         float ncx[3];
         for (int a = 0; a < 3; ++a) ncx[a] = 0.5f * (bn.lo[a] + bn.hi[a]);
-        float cost[8][8];
+        float scost[8][8];
         for (int k = 0; k < nch; ++k) {
             const B2 &c = B.nodes[ch[k]];
             const float d[3] = {0.5f * (c.lo[0] + c.hi[0]) - ncx[0], 0.5f * (c.lo[1] + c.hi[1]) - ncx[1], 0.5f * (c.lo[2] + c.hi[2]) - ncx[2]};
             for (int s = 0; s < 8; ++s) {
                 const float sx = (s & 4) ? -1.0f : 1.0f, sy = (s & 2) ? -1.0f : 1.0f, sz = (s & 1) ? -1.0f : 1.0f;
-                cost[k][s] = d[0] * sx + d[1] * sy + d[2] * sz;
+                scost[k][s] = d[0] * sx + d[1] * sy + d[2] * sz;
             }
         }
         int slot_child[8]; for (int s = 0; s < 8; ++s) slot_child[s] = -1;
-        static const int assign_mode = std::getenv("HRT_BVH_ASSIGN") ? std::atoi(std::getenv("HRT_BVH_ASSIGN")) : 0;
-        bool assigned = false;
-        if (assign_mode == 1) {
-            // exact assignment (minimum total cost) by dynamic programming over the set of used slots: child k = popcount(set)
-            float dp[256]; int8_t from[256];
-            for (int m = 0; m < 256; ++m) { dp[m] = std::numeric_limits<float>::infinity(); from[m] = -1; }
-            dp[0] = 0.0f;
-            bool ok = true;
-            for (int k = 0; k < nch && ok; ++k) for (int s = 0; s < 8; ++s) if (!(cost[k][s] == cost[k][s])) ok = false;
-            if (ok) {
-                for (int m = 0; m < 256; ++m) {
-                    const int k = __builtin_popcount((unsigned)m);
-                    if (k >= nch || !(dp[m] < std::numeric_limits<float>::infinity())) continue;
-                    for (int s = 0; s < 8; ++s) {
-                        if (m & (1 << s)) continue;
-                        const float v = dp[m] + cost[k][s];
-                        if (v < dp[m | (1 << s)]) { dp[m | (1 << s)] = v; from[m | (1 << s)] = (int8_t)s; }
-                    }
-                }
-                int best_m = -1; float best_v = std::numeric_limits<float>::infinity();
-                for (int m = 0; m < 256; ++m) if (__builtin_popcount((unsigned)m) == nch && dp[m] < best_v) { best_v = dp[m]; best_m = m; }
-                if (best_m >= 0) {
-                    int m = best_m;
-                    for (int k = nch - 1; k >= 0; --k) { const int s = from[m]; slot_child[s] = k; m &= ~(1 << s); }
-                    assigned = true;
-                }
-            }
-        }
         bool child_done[8] = {false, false, false, false, false, false, false, false};
-        for (int round = 0; round < nch && !assigned; ++round) {
+        for (int round = 0; round < nch; ++round) {
             int bk = -1, bs = -1; float bc = std::numeric_limits<float>::infinity();
             for (int k = 0; k < nch; ++k) {
                 if (child_done[k]) continue;
                 for (int s = 0; s < 8; ++s) {
                     if (slot_child[s] >= 0) continue;
-                    if (cost[k][s] < bc) { bc = cost[k][s]; bk = k; bs = s; }
+                    if (scost[k][s] < bc) { bc = scost[k][s]; bk = k; bs = s; }
                 }
             }
             if (bk < 0) {   // NaN costs (degenerate boxes): first free pair
@@ -513,18 +476,12 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
             }
             slot_child[bs] = bk; child_done[bk] = true;
         }
-
-        Bvh8Node nd; std::memset(&nd, 0, sizeof nd);
+        Bvh8Node &nd = L.nd; std::memset(&nd, 0, sizeof nd);
         for (int a = 0; a < 3; ++a) {
             nd.p[a] = bn.lo[a];
             nd.e[a] = node_exponent(bn.hi[a] - bn.lo[a]);
         }
-        if (out.level_begin.size() <= it.depth) out.level_begin.push_back(self);
-        for (int a = 0; a < 3; ++a) out.node_box.push_back(bn.lo[a]);
-        for (int a = 0; a < 3; ++a) out.node_box.push_back(bn.hi[a]);
-        nd.child_base = (uint32_t)queue.size();
-        nd.prim_base = (uint32_t)out.prims.size();
-        uint32_t prim_off = 0;
+        L.n_inner = L.n_leaf = 0;
         for (int s = 0; s < 8; ++s) {
             const int k = slot_child[s];
             if (k < 0) {
@@ -538,31 +495,67 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
                 // the <= 3 references of the leaf: walk its little BVH2 subtree, left first; the same primitive twice (both
                 // halves of a spatial split ended up here) is stored once
                 uint32_t st[8]; int sp = 0; st[sp++] = ch[k];
-                uint32_t lp[kMaxLeafPrims]; const B2 *lb[kMaxLeafPrims]; uint32_t nl = 0;
+                const uint32_t first = L.n_leaf; uint32_t nl = 0;
                 while (sp > 0) {
                     const B2 &x = B.nodes[st[--sp]];
                     if (x.count > 0) {
                         bool dup = false;
-                        for (uint32_t q = 0; q < nl; ++q) if (lp[q] == x.first) dup = true;
-                        if (!dup && nl < kMaxLeafPrims) { lp[nl] = x.first; lb[nl] = &x; ++nl; }
+                        for (uint32_t q = 0; q < nl; ++q) if (L.leaf_prim[first + q] == x.first) dup = true;
+                        if (!dup && nl < kMaxLeafPrims) { L.leaf_prim[first + nl] = x.first; L.leaf_box[first + nl] = &x; ++nl; }
                     } else { st[sp++] = x.right; st[sp++] = x.left; }
                 }
-                nd.meta[s] = (uint8_t)((unary_count(nl) << 5) | prim_off);
-                for (uint32_t i = 0; i < nl; ++i) {
-                    out.prims.push_back(prims[lp[i]].rec);
-                    // (host-side checks: the part of the primitive this leaf answers for, unpadded side of the reference's box)
-                    for (int a = 0; a < 3; ++a) out.prim_bounds.push_back(lb[i]->lo[a] + pad);
-                    for (int a = 0; a < 3; ++a) out.prim_bounds.push_back(lb[i]->hi[a] - pad);
-                }
-                prim_off += nl;
+                nd.meta[s] = (uint8_t)((unary_count(nl) << 5) | first);
+                L.n_leaf += nl;
             } else {
                 nd.meta[s] = (uint8_t)(0x20u | (24u + (uint32_t)s));
                 nd.imask |= (uint8_t)(1u << s);
-                queue.push_back({ch[k], it.depth + 1});
-                out.nodes.emplace_back();
+                L.inner_b2[L.n_inner++] = ch[k];
             }
         }
-        out.nodes[self] = nd;
+    };
+    auto parallel_for = [&](size_t count, const std::function<void(size_t, size_t)> &body) {
+        const size_t T = std::min<size_t>((size_t)hw, count / 512 + 1);
+        if (T <= 1) { body(0, count); return; }
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < T; ++t) pool.emplace_back(body, count * t / T, count * (t + 1) / T);
+        for (auto &th : pool) th.join();
+    };
+    std::vector<uint32_t> level{0u}, next_level, child_base, prim_base;
+    std::vector<Local> locals;
+    uint32_t level_first = 0, depth = 0;
+    while (!level.empty()) {
+        const size_t n_level = level.size();
+        locals.resize(n_level); child_base.resize(n_level); prim_base.resize(n_level);
+        parallel_for(n_level, [&](size_t b, size_t e) { for (size_t i = b; i < e; ++i) emit_node(level[i], locals[i]); });
+        uint32_t next_node = level_first + (uint32_t)n_level, next_prim = (uint32_t)out.prims.size();
+        for (size_t i = 0; i < n_level; ++i) {
+            child_base[i] = next_node; next_node += locals[i].n_inner;
+            prim_base[i] = next_prim; next_prim += locals[i].n_leaf;
+        }
+        out.level_begin.push_back(level_first);
+        out.max_depth = depth;
+        out.nodes.resize(level_first + n_level);
+        out.node_box.resize(6 * (size_t)(level_first + n_level));
+        out.prims.resize(next_prim); out.prim_bounds.resize(6 * (size_t)next_prim);
+        next_level.assign(next_node - (level_first + n_level), 0u);
+        parallel_for(n_level, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                Local &L = locals[i];
+                const B2 &bn = B.nodes[level[i]];
+                L.nd.child_base = child_base[i]; L.nd.prim_base = prim_base[i];
+                out.nodes[level_first + i] = L.nd;
+                for (int a = 0; a < 3; ++a) { out.node_box[6 * (level_first + i) + a] = bn.lo[a]; out.node_box[6 * (level_first + i) + 3 + a] = bn.hi[a]; }
+                for (uint32_t q = 0; q < L.n_leaf; ++q) {
+                    out.prims[prim_base[i] + q] = prims[L.leaf_prim[q]].rec;
+                    // (host-side checks: the part of the primitive this leaf answers for, unpadded side of the reference's box)
+                    for (int a = 0; a < 3; ++a) { out.prim_bounds[6 * (size_t)(prim_base[i] + q) + a] = L.leaf_box[q]->lo[a] + pad; out.prim_bounds[6 * (size_t)(prim_base[i] + q) + 3 + a] = L.leaf_box[q]->hi[a] - pad; }
+                }
+                for (uint32_t r = 0; r < L.n_inner; ++r) next_level[child_base[i] - (level_first + n_level) + r] = L.inner_b2[r];
+            }
+        });
+        level_first += (uint32_t)n_level;
+        level.swap(next_level);
+        if (!level.empty()) ++depth;
     }
     out.level_begin.push_back((uint32_t)out.nodes.size());
     if (std::getenv("HRT_BUILD_VERBOSE")) {
