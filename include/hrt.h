@@ -56,7 +56,7 @@ typedef struct HrtContext HrtContext;
                                     with identity transforms and poses it afterwards, so that update is the one that has to rebuild. */
 #define HRT_CTX_FAST_TRACE 0x4u  /* hrt_tlas_build prefers trace speed to build speed: the reference's OPTIX_BUILD_FLAG_PREFER_FAST_TRACE
                                     (its GAS builds, RendererImpl.cu:94,118,144).  The tree is then built by the host's binned-SAH builder
-                                    WITH SPATIAL SPLITS from a host copy of the geometry (1 M triangles: ~2.5 s, 9.5 % fewer node visits per
+                                    WITH SPATIAL SPLITS from a host copy of the geometry (1 M triangles: ~1.4 s, 9.5 % fewer node visits per
                                     ray, 1.4 records per triangle) instead of by the device build (PLOC, ~8 ms, no
                                     geometry leaves the GPU).  Such a tree is for static scenes: the first hrt_tlas_update replaces it by a
                                     device-built one (a refit cannot keep the split references' boxes), and rebuilds inside hrt_tlas_update

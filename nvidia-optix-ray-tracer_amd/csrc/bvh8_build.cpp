@@ -7,7 +7,7 @@
 //      spatial splits (SBVH: references cut by planes where that is cheaper, for static scenes);
 //   2. optimal SAH collapse to 8-wide nodes by dynamic programming (Ylitie, Karras, Laine 2017,
 //      sec. 4.1): C(n, i) = cheapest way to represent subtree n as a forest of at most i roots,
-//      c_node = 1, c_prim = 0.3, leaves <= 3 primitives.  (A first greedy version -- always open
+//      c_node = 1, c_prim = 0.45, leaves <= 3 primitives.  (A first greedy version -- always open
 //      the largest inner child -- left 64 % of the nodes with only two children.)
 //   3. octant-ordered slot assignment so that (slot ^ (7 - ray_octant)) approximates
 //      front-to-back order during traversal;
