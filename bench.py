@@ -76,6 +76,46 @@ def build_id():
         return None
 
 
+def profile_fields(profiles_dir, running):
+    """(traffic, traffic_source, issue) of the roofline block from the newest committed PMC summaries (tools/profile_final.sh).  A
+    figure is quoted only when its file was taken on the build that is running (`running` = lib/BUILD_ID); otherwise the figure
+    is None and the source is marked stale -- the bench never prints the counters of another build as its own."""
+    def newest(pattern):
+        for f in sorted(Path(profiles_dir).glob(pattern), reverse=True)[:1]:
+            try:
+                d = json.loads(f.read_text())
+            except Exception:
+                return None, None, None
+            return d, f"profiles/{f.name}", d.get("provenance", {}).get("build")
+        return None, None, None
+    traffic = traffic_source = issue = None
+    d, name, b = newest("r*_traverse_traffic.json")
+    if d is not None:
+        stale = running is None or b != running
+        traffic = None if stale else d.get("fabric_bytes_per_launch")
+        traffic_source = {"file": name, "build": b, "running_build": running, "stale": stale, "tcc_hit_rate": None if stale else d.get("tcc_hit_rate"),
+                          "what": "bytes the L2s requested from the fabric per launch (read + write); Infinity-Cache hits included: an upper bound on HBM bytes"}
+    d, name, b = newest("r*_pmc_fused_kernel.json")
+    if d is not None and "valu" in d:
+        stale = running is None or b != running
+        issue = {"file": name, "build": b, "running_build": running, "stale": stale}
+        c = d.get("counters_mean_per_launch", {})
+        cyc = d["valu"].get("kernel_cycles")
+        n_inst = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"))
+        if not stale and cyc and n_inst:
+            cpi = cyc * 1024.0 / n_inst
+            issue.update({
+                "instructions_per_launch": n_inst, "simd_cycles_per_instruction": round(cpi, 3),
+                "floor_cycles_per_instruction": ISSUE_FLOOR_CYCLES,
+                "issue_frac": round(ISSUE_FLOOR_CYCLES / cpi, 4),
+                "lanes_active_frac": round(d["valu"]["lanes_active_frac"], 4),
+                "useful_lane_frac": round(ISSUE_FLOOR_CYCLES / cpi * d["valu"]["lanes_active_frac"], 4),
+                "wave_time_split": {k: round(v, 4) for k, v in (d["valu"].get("wave_time_split") or {}).items()},
+                "what": "issue_frac = 2.4 SIMD cycles per instruction (measured floor, any kind) / (kernel cycles x 1024 SIMDs / instructions); "
+                        "lanes_active = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); useful_lane_frac = their product"})
+    return traffic, traffic_source, issue
+
+
 ISSUE_FLOOR_CYCLES = 2.4        # SIMD cycles per instruction with >= 2 waves issuing side by side (profiles/r02_valu_pipes_microbench.txt)
 
 
@@ -259,41 +299,8 @@ def main():
         # separate --pmc runs, which cannot share a process with the timed region).  They are only quoted when the file was taken on
         # the build that is running (lib/BUILD_ID = hash of the kernel sources); otherwise they are null and marked stale.
         traffic = traffic_source = issue = None
-        running = build_id()
         if args.config == "C4" and world == 1 and fused and args.spp == 0:
-            def newest(pattern):
-                for f in sorted((ROOT / "profiles").glob(pattern), reverse=True)[:1]:
-                    try:
-                        d = json.loads(f.read_text())
-                    except Exception:
-                        return None, None, None
-                    b = d.get("provenance", {}).get("build")
-                    return d, f"profiles/{f.name}", b
-                return None, None, None
-            d, name, b = newest("r*_traverse_traffic.json")
-            if d is not None:
-                stale = running is None or b != running
-                traffic = None if stale else d.get("fabric_bytes_per_launch")
-                traffic_source = {"file": name, "build": b, "running_build": running, "stale": stale, "tcc_hit_rate": None if stale else d.get("tcc_hit_rate"),
-                                  "what": "bytes the L2s requested from the fabric per launch (read + write); Infinity-Cache hits included: an upper bound on HBM bytes"}
-            d, name, b = newest("r*_pmc_fused_kernel.json")
-            if d is not None and "valu" in d:
-                stale = running is None or b != running
-                issue = {"file": name, "build": b, "running_build": running, "stale": stale}
-                c = d.get("counters_mean_per_launch", {})
-                cyc = d["valu"].get("kernel_cycles")
-                n_inst = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"))
-                if not stale and cyc and n_inst:
-                    cpi = cyc * 1024.0 / n_inst
-                    issue.update({
-                        "instructions_per_launch": n_inst, "simd_cycles_per_instruction": round(cpi, 3),
-                        "floor_cycles_per_instruction": ISSUE_FLOOR_CYCLES,
-                        "issue_frac": round(ISSUE_FLOOR_CYCLES / cpi, 4),
-                        "lanes_active_frac": round(d["valu"]["lanes_active_frac"], 4),
-                        "useful_lane_frac": round(ISSUE_FLOOR_CYCLES / cpi * d["valu"]["lanes_active_frac"], 4),
-                        "wave_time_split": {k: round(v, 4) for k, v in (d["valu"].get("wave_time_split") or {}).items()},
-                        "what": "issue_frac = 2.4 SIMD cycles per instruction (measured floor, any kind) / (kernel cycles x 1024 SIMDs / instructions); "
-                                "lanes_active = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); useful_lane_frac = their product"})
+            traffic, traffic_source, issue = profile_fields(ROOT / "profiles", build_id())
         out = {
             "metric": "Mrays/s at 1920x1080, 1M-tri scene",
             "value": round(total_rays / elapsed / 1e6, 3),

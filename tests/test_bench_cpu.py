@@ -59,3 +59,26 @@ def test_launcher_process_never_imports_torch_and_propagates_failure(tmp_path):
     out = subprocess.run([sys.executable, "-c", probe], env=env, capture_output=True, text=True, timeout=120)
     assert "EXIT 7 False" in out.stdout, out.stdout + out.stderr
     assert "--nproc-per-node=2" in out.stdout and "--gpus" in out.stdout
+
+
+def test_profile_figures_are_quoted_only_for_the_running_build(bench, tmp_path):
+    """The roofline block's issue_frac / useful_lane_frac / traffic come from committed PMC summaries; they must be nulled and marked
+    stale when the summary was taken on another build than the library that is running."""
+    import json
+    pmc = {"provenance": {"build": "abc123"}, "counters_mean_per_launch": {"SQ_INSTS_VALU": 270e9, "SQ_INSTS_SALU": 74e9, "SQ_INSTS_VMEM_RD": 6e9,
+           "SQ_INSTS_LDS": 7e9}, "valu": {"kernel_cycles": 9.8e8, "lanes_active_frac": 0.65, "wave_time_split": {"issuing": 0.4}}}
+    (tmp_path / "r07_pmc_fused_kernel.json").write_text(json.dumps(pmc))
+    (tmp_path / "r07_traverse_traffic.json").write_text(json.dumps({"provenance": {"build": "abc123"}, "fabric_bytes_per_launch": 1.4e12, "tcc_hit_rate": 0.78}))
+    (tmp_path / "r06_pmc_fused_kernel.json").write_text(json.dumps({"provenance": {"build": "old"}, "valu": {}}))      # an older round: ignored
+    traffic, src, issue = bench.profile_fields(tmp_path, "abc123")
+    assert traffic == 1.4e12 and src["stale"] is False and src["file"] == "profiles/r07_traverse_traffic.json"
+    assert issue["stale"] is False and 0.8 < issue["issue_frac"] < 0.9 and abs(issue["useful_lane_frac"] - issue["issue_frac"] * 0.65) < 1e-3
+    for running in ("def456", None):
+        traffic, src, issue = bench.profile_fields(tmp_path, running)
+        assert traffic is None and src["stale"] is True and src["tcc_hit_rate"] is None
+        assert issue["stale"] is True and "issue_frac" not in issue and issue["build"] == "abc123"
+    assert bench.profile_fields(tmp_path / "missing", "abc123") == (None, None, None)
+    # the committed summaries of this round belong to the committed sources
+    root = ROOT / "profiles"
+    newest = sorted(root.glob("r*_pmc_fused_kernel.json"))[-1]
+    assert json.loads(newest.read_text())["provenance"]["build"]
