@@ -352,10 +352,14 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
     B.root_area = scene_box.area();
     B.nodes.resize(2 * ((size_t)n + (size_t)std::max<int64_t>(extra, 0)) + 2);
     B.n_nodes = 1;
+    // Worker threads: the hardware's, at most 64 per build (HRT_BUILD_THREADS overrides) -- several processes may build at once (one rank
+    // per GPU, each with its own copy of the scene), and a fork per subtree must not turn into thousands of threads on a shared host
     int hw = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    if (threads <= 0) hw = std::min(hw, 64);
+    if (const char *e = std::getenv("HRT_BUILD_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 1024) hw = v; }
     if (hw < 1) hw = 1;
     B.max_par_depth = 0;
-    while ((1 << B.max_par_depth) < 2 * hw && B.max_par_depth < 9) B.max_par_depth++;      // (twice as many subtree tasks as threads: the subtrees are not equally expensive)
+    while ((1 << B.max_par_depth) < hw && B.max_par_depth < 10) B.max_par_depth++;      // (a fork per node down to this depth: at most hw subtree tasks alive)
     const auto t_begin = std::chrono::steady_clock::now();
     B.build(0, std::move(refs), 0, extra);
     const auto t_bvh2 = std::chrono::steady_clock::now();
