@@ -209,10 +209,15 @@ def main():
     W, H, spp = scene["width"], scene["height"], scene["spp"]
 
     # The scene is static, so trace speed is preferred to build speed, as the reference does for its geometry
-    # (OPTIX_BUILD_FLAG_PREFER_FAST_TRACE, RendererImpl.cu:94): HRT_CTX_FAST_TRACE = the host's binned-SAH tree with spatial splits (~2.5 s,
-    # outside the timed region).  HRT_BENCH_DEVICE_BUILD=1 times the frame on the device-built PLOC tree instead (8 ms with the upload, 13 % more
-    # node visits per ray, ~10 % fewer Mrays/s); either way the line carries the other builder's rate as config.alt_builder.
+    # (OPTIX_BUILD_FLAG_PREFER_FAST_TRACE, RendererImpl.cu:94): HRT_CTX_FAST_TRACE = a tree with spatial splits, built on the device (top-down
+    # SAH splits of references, then PLOC within the cells: build_split.hip; HRT_FAST_TRACE_BUILD=host: the host's binned-SAH builder, the same
+    # rules, ~1.3 s).  HRT_BENCH_DEVICE_BUILD=1 times the frame on the default tree instead (PLOC alone, no splits, refittable: 8 ms, ~13 % more
+    # node visits per ray); the line carries the other builders' rates as config.alt_builders.
     device_build = os.environ.get("HRT_BENCH_DEVICE_BUILD") == "1"
+    split_on_device = os.environ.get("HRT_FAST_TRACE_BUILD", "device") == "device"
+    LABEL_PLOC = "device PLOC (build.hip)"
+    LABEL_SPLIT = {True: "device top-down SAH with spatial splits + PLOC in the cells (build_split.hip, HRT_CTX_FAST_TRACE)",
+                   False: "host binned SAH with spatial splits (bvh8_build.cpp, HRT_CTX_FAST_TRACE, HRT_FAST_TRACE_BUILD=host)"}
     # HRT_BENCH_NO_TIMING=1: no per-kernel HIP events (wavefront mode then replays its samples from a hipGraph; the roofline block has no kernel time)
     timing = 0 if os.environ.get("HRT_BENCH_NO_TIMING") == "1" else hrt.CTX_TIMING
     r = hrt.Renderer(local_rank, timing | (0 if device_build else hrt.CTX_FAST_TRACE))
@@ -316,7 +321,7 @@ def main():
                                    f"{W}x{H}, {spp} spp, depth {5}, tile-split x{world} (8-row stripes, BVH replicated)",
                        "rays_per_step": int(total_rays / max(args.steps, 1)), "rays_per_path": round(st.rays / max(st.paths, 1), 4),
                        "bvh_nodes": int(st.bvh_nodes), "bvh_bytes": int(st.bvh_bytes), "bvh_build_s": round(build_s, 3),
-                       "bvh_builder": "device PLOC (build.hip)" if device_build else "host binned SAH with spatial splits (HRT_CTX_FAST_TRACE)"},
+                       "bvh_builder": LABEL_PLOC if device_build else LABEL_SPLIT[split_on_device]},
             # What bounds the kernel is INSTRUCTION ISSUE (`bound`, `issue_frac`, `useful_lane_frac`: DESIGN.md section 4.1), not memory:
             # the tree of this scene is resident in L2 / Infinity Cache.  `achieved` / `peak` / `frac` stay the contract's figure
             # (ALGORITHMIC bytes -- 80 B per node visit + 48 B per primitive test -- over the launch time over the HBM
@@ -336,25 +341,38 @@ def main():
             "kernel_ms": {hrt.KERNEL_NAMES[k]: round(st.kernel_ms[k], 3) for k in range(hrt.K_COUNT)},
         }
         if world == 1 and not args.no_alt_builder:
-            # the same frame on the tree of the OTHER builder (a second context; a few steps are enough for a rate)
-            alt = hrt.Renderer(local_rank, hrt.CTX_TIMING | (hrt.CTX_FAST_TRACE if device_build else 0))
-            t0 = time.perf_counter()
-            alt.load_scene(scene)
-            alt_build_s = time.perf_counter() - t0
-            alt.set_frame(W, H, hrt.scenes.SEED_SALT, aov=False)
-            alt.render(spp, sync=True)
-            alt.reset_stats()
-            alt_steps = max(1, min(args.steps, 3))
-            t0 = time.perf_counter()
-            for _ in range(alt_steps):
-                alt.render(spp, sync=False)
-            torch.cuda.synchronize(dev)
-            alt_dt = time.perf_counter() - t0
-            sa = alt.stats()
-            out["config"]["alt_builder"] = {"bvh_builder": "host binned SAH with spatial splits (HRT_CTX_FAST_TRACE)" if device_build else "device PLOC (build.hip)",
-                                            "value": round(sa.rays / alt_dt / 1e6, 3), "unit": "Mrays/s", "steps": alt_steps,
-                                            "bvh_nodes": int(sa.bvh_nodes), "bvh_build_s": round(alt_build_s, 3)}
-            alt.close()
+            # the same frame on the trees of the OTHER builders (a context each; a few steps are enough for a rate)
+            alts = [(LABEL_PLOC, 0, None)] if not device_build else [(LABEL_SPLIT[split_on_device], hrt.CTX_FAST_TRACE, None)]
+            alts.append((LABEL_SPLIT[not split_on_device], hrt.CTX_FAST_TRACE, "host" if split_on_device else "device"))
+            out["config"]["alt_builders"] = []
+            for label, flag, where in alts:
+                saved = os.environ.get("HRT_FAST_TRACE_BUILD")
+                if where is not None:
+                    os.environ["HRT_FAST_TRACE_BUILD"] = where           # (read when the context is created)
+                try:
+                    alt = hrt.Renderer(local_rank, hrt.CTX_TIMING | flag)
+                finally:
+                    if where is not None:
+                        if saved is None:
+                            os.environ.pop("HRT_FAST_TRACE_BUILD", None)
+                        else:
+                            os.environ["HRT_FAST_TRACE_BUILD"] = saved
+                t0 = time.perf_counter()
+                alt.load_scene(scene)
+                alt_build_s = time.perf_counter() - t0
+                alt.set_frame(W, H, hrt.scenes.SEED_SALT, aov=False)
+                alt.render(spp, sync=True)
+                alt.reset_stats()
+                alt_steps = max(1, min(args.steps, 3))
+                t0 = time.perf_counter()
+                for _ in range(alt_steps):
+                    alt.render(spp, sync=False)
+                torch.cuda.synchronize(dev)
+                alt_dt = time.perf_counter() - t0
+                sa = alt.stats()
+                out["config"]["alt_builders"].append({"bvh_builder": label, "value": round(sa.rays / alt_dt / 1e6, 3), "unit": "Mrays/s", "steps": alt_steps,
+                                                      "bvh_nodes": int(sa.bvh_nodes), "bvh_build_s": round(alt_build_s, 3)})
+                alt.close()
         if not args.no_cpu_baseline and world == 1:             # the CPU leg is timed at N = 1 only
             r.set_flags(0)                                      # production kernels for the parity render
             out["cpu_baseline"], out["parity"] = cpu_baseline(hrt, scene, args.cpu_seconds, r)

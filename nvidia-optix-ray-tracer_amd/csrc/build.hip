@@ -18,9 +18,7 @@
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <vector>
-#include "build.h"
-#include "bvh8.h"
-#include "bvh8_geom.h"
+#include "build_dev.h"
 
 #pragma clang fp contract(off)
 
@@ -28,55 +26,7 @@ namespace hrt {
 
 namespace {
 
-constexpr uint32_t kNone = 0xffffffffu;
 constexpr int kPlocMaxRadius = 128;
-
-// float <-> unsigned with the same order
-__device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
-__host__ __device__ inline float ord2f(uint32_t u) { const uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u; float f; memcpy(&f, &b, 4); return f; }
-
-__device__ __forceinline__ uint32_t find_instance(const uint32_t *__restrict__ first, uint32_t n_inst, uint32_t k) {
-    uint32_t lo = 0, hi = n_inst;               // first[lo] <= k < first[hi]
-    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (first[mid] <= k) lo = mid; else hi = mid; }
-    return lo;
-}
-
-// world-space bounds of global primitive k (unpadded); false when not finite
-__device__ __forceinline__ bool prim_bounds(const GpuBuildArgs &a, uint32_t k, float *lo, float *hi) {
-    const uint32_t inst = find_instance(a.inst_first, a.n_inst, k), p = k - a.inst_first[inst];
-    const float *m = a.inst_xf + 12 * (size_t)inst;
-    const bool ident = a.inst_identity[inst] != 0u;
-    if (a.inst_kind[inst] == kPrimKindTriangle) {
-        const float *src = reinterpret_cast<const float *>(a.inst_src[inst]) + 9 * (size_t)p;
-        float s9[9], v0[3], e1[3], e2[3];
-        for (int q = 0; q < 9; ++q) s9[q] = src[q];
-        triangle_world(s9, m, ident, v0, e1, e2, lo, hi);
-    } else {
-        const float *src = reinterpret_cast<const float *>(a.inst_src[inst]) + 4 * (size_t)p;
-        const float c3[3] = {src[0], src[1], src[2]};
-        sphere_world_bounds(c3, src[3], m, ident, lo, hi);
-    }
-    return finite_box(lo, hi);
-}
-
-// min / max of up to 12 values over a 1024-thread workgroup: waves by shuffles, then one lane per value through LDS.  Returns
-// the block's result in every thread of wave 0 (valid for lane < n_vals there).  (One atomic per value and BLOCK afterwards:
-// a single address takes ~88 atomics per microsecond, so per-wave atomics cost milliseconds at a million primitives.)
-template <int N>
-__device__ __forceinline__ void block_minmax(float (&mn)[N], float (&mx)[N]) {
-    __shared__ float s_mn[16][N], s_mx[16][N];
-    for (int off = 32; off > 0; off >>= 1)
-        for (int q = 0; q < N; ++q) { mn[q] = fminf(mn[q], __shfl_xor(mn[q], off)); mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], off)); }
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = (blockDim.x + 63u) >> 6;
-    if (lane == 0u) for (int q = 0; q < N; ++q) { s_mn[wave][q] = mn[q]; s_mx[wave][q] = mx[q]; }
-    __syncthreads();
-    if (wave == 0u)
-        for (int q = 0; q < N; ++q) {
-            float a = INFINITY, b = -INFINITY;
-            for (uint32_t w = 0; w < n_waves; ++w) { a = fminf(a, s_mn[w][q]); b = fmaxf(b, s_mx[w][q]); }
-            mn[q] = a; mx[q] = b;
-        }
-}
 
 __global__ __launch_bounds__(1024) void k_prim_bounds(GpuBuildArgs a) {
     const uint32_t k = blockIdx.x * 1024u + threadIdx.x;
@@ -136,6 +86,61 @@ __global__ __launch_bounds__(256) void k_morton(GpuBuildArgs a) {
     a.keys[k] = key; a.vals[k] = k;
 }
 
+// builds with spatial splits: the sort key of a reference is its cell, then the Morton code of its centroid within the cell's
+// centroid bounds (10 bits an axis: cells are small) -- the references of a cell stay together and PLOC works cell by cell
+__global__ __launch_bounds__(256) void k_morton_refs(GpuBuildArgs a, uint32_t n_refs, const SplitSeg *__restrict__ segs, const uint32_t *__restrict__ cell_seg) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_refs) return;
+    const float4 lo = a.ref_lo[i], hi = a.ref_hi[i];
+    const uint32_t cell = __float_as_uint(hi.w);
+    const SplitSeg &sg = segs[cell_seg[cell]];
+    const float ce[3] = {0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)};
+    uint64_t q[3];
+    for (int d = 0; d < 3; ++d) {
+        const float cm = ord2f(sg.cb[d]), cx = -ord2f(sg.cb[3 + d]);
+        const float ext = cx - cm;
+        float t = ext > 0.0f ? (ce[d] - cm) / ext : 0.0f;
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        const uint32_t v = (uint32_t)(t * 1023.0f);
+        q[d] = v > 1023u ? 1023u : v;
+    }
+    a.keys[i] = ((uint64_t)cell << 30) | (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    a.vals[i] = i;
+}
+
+__global__ __launch_bounds__(256) void k_leaves_refs(GpuBuildArgs a, uint32_t n_refs) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_refs) return;
+    const uint32_t r = a.vals_sorted[i];
+    const float4 lo = a.ref_lo[r], hi = a.ref_hi[r];
+    a.node_lo[i] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(kNone));
+    a.node_hi[i] = make_float4(hi.x, hi.y, hi.z, lo.w);
+    a.node_cell[i] = __float_as_uint(hi.w);
+    a.node_parent[i] = kNone; a.node_nprims[i] = 1u;
+    a.cl_a[i] = i;
+}
+
+// the segments the top-down phase split are the top of the BVH2: node top_base + t for top node t, children = top nodes or the
+// roots PLOC left of the cells (cell_root, in cell order).  (A top node's reference count is the segment's before its split.)
+__global__ __launch_bounds__(256) void k_top_link(GpuBuildArgs a, const SplitSeg *__restrict__ segs, const uint32_t *__restrict__ top_seg,
+                                                  const uint32_t *__restrict__ cell_root, uint32_t n_top, uint32_t top_base) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_top) return;
+    const SplitSeg &sg = segs[top_seg[t]];
+    const uint32_t id = top_base + t;
+    uint32_t ch[2];
+    for (int c = 0; c < 2; ++c) {
+        const SplitSeg &cs = segs[sg.child + (uint32_t)c];
+        ch[c] = cs.kind >= 2u ? top_base + cs.index : cell_root[cs.index];
+    }
+    a.node_lo[id] = make_float4(ord2f(sg.nb[0]), ord2f(sg.nb[1]), ord2f(sg.nb[2]), __uint_as_float(ch[0]));
+    a.node_hi[id] = make_float4(-ord2f(sg.nb[3]), -ord2f(sg.nb[4]), -ord2f(sg.nb[5]), __uint_as_float(ch[1]));
+    a.node_parent[ch[0]] = id; a.node_parent[ch[1]] = id;
+    if (t == 0u) a.node_parent[id] = kNone;
+    a.node_nprims[id] = sg.count;
+    a.node_visit[id] = 0u;
+}
+
 // BVH2 node i: lo.xyz | left, hi.xyz | right.  Leaf: left = kNone, right = global primitive number.
 __global__ __launch_bounds__(256) void k_leaves(GpuBuildArgs a, uint32_t nv) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -159,23 +164,25 @@ __device__ __forceinline__ float merged_half_area(const float4 alo, const float4
 // it before it reads the counters back)
 __global__ __launch_bounds__(256) void k_ploc_nn(GpuBuildArgs a, const uint32_t *__restrict__ cl) {
     __shared__ float4 s_lo[256 + 2 * kPlocMaxRadius], s_hi[256 + 2 * kPlocMaxRadius];
+    __shared__ uint32_t s_cell[256 + 2 * kPlocMaxRadius];      // (builds with spatial splits: clusters merge within their cell only)
     const uint32_t m = a.counters->m_cur;
     if (blockIdx.x * 256u >= m) return;
     const int kPlocRadius = a.ploc_radius;
     const int base = (int)(blockIdx.x * 256u) - kPlocRadius;
     for (int t = (int)threadIdx.x; t < 256 + 2 * kPlocRadius; t += 256) {
         const int j = base + t;
-        if (j >= 0 && j < (int)m) { const uint32_t nd = cl[j]; s_lo[t] = a.node_lo[nd]; s_hi[t] = a.node_hi[nd]; }
+        if (j >= 0 && j < (int)m) { const uint32_t nd = cl[j]; s_lo[t] = a.node_lo[nd]; s_hi[t] = a.node_hi[nd]; s_cell[t] = a.node_cell ? a.node_cell[nd] : 0u; }
     }
     __syncthreads();
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= m) return;
     const int me = (int)threadIdx.x + kPlocRadius;
     const float4 mlo = s_lo[me], mhi = s_hi[me];
+    const uint32_t my_cell = s_cell[me];
     float best = INFINITY; uint32_t bj = kNone;
     for (int d = -kPlocRadius; d <= kPlocRadius; ++d) {
         const int j = (int)i + d;
-        if (d == 0 || j < 0 || j >= (int)m) continue;
+        if (d == 0 || j < 0 || j >= (int)m || s_cell[me + d] != my_cell) continue;
         const float ar = merged_half_area(mlo, mhi, s_lo[me + d], s_hi[me + d]);
         if (ar < best || bj == kNone) { best = ar; bj = (uint32_t)j; }      // strict <: the first (lowest) position wins ties; NaN areas still pick something
     }
@@ -210,6 +217,7 @@ __global__ __launch_bounds__(256) void k_ploc_apply(GpuBuildArgs a, const uint32
     a.node_parent[l] = id; a.node_parent[r] = id; a.node_parent[id] = kNone;
     a.node_nprims[id] = a.node_nprims[l] + a.node_nprims[r];
     a.node_visit[id] = 0u;
+    if (a.node_cell) a.node_cell[id] = a.node_cell[l];
     cl_out[pos] = id;
 }
 
@@ -313,6 +321,23 @@ __device__ void collect_forest(const GpuBuildArgs &a, uint32_t root, Forest &out
     }
 }
 
+// the <= 3 references of a leaf child: its little BVH2 subtree, in order
+__device__ __forceinline__ int leaf_refs(const GpuBuildArgs &a, uint32_t c, uint32_t *gk, uint32_t *leaf) {
+    uint32_t st[4]; int sp = 0, n = 0; st[sp++] = c;
+    while (sp > 0) {
+        const uint32_t x = st[--sp];
+        const uint32_t l = __float_as_uint(a.node_lo[x].w), r = __float_as_uint(a.node_hi[x].w);
+        if (l == kNone) { if (n < 3) { gk[n] = r; leaf[n] = x; ++n; } }
+        else { st[sp++] = r; st[sp++] = l; }
+    }
+    return n;
+}
+// pieces of ONE primitive that a spatial split made and PLOC put into the same leaf again are one record (box: their union)
+__device__ __forceinline__ bool first_of_its_prim(const uint32_t *gk, int w) {
+    for (int v = 0; v < w; ++v) if (gk[v] == gk[w]) return false;
+    return true;
+}
+
 __global__ __launch_bounds__(128) void k_emit_level(GpuBuildArgs a, const uint2 *__restrict__ items, uint32_t n_items, uint2 *__restrict__ items_next,
                                                     uint32_t next_level_begin, uint32_t is_root_level) {
     const uint32_t t = blockIdx.x * 128u + threadIdx.x;
@@ -363,7 +388,10 @@ __global__ __launch_bounds__(128) void k_emit_level(GpuBuildArgs a, const uint2 
     for (int s = 0; s < 8; ++s) {
         const int k = slot_child[s];
         if (k < 0) continue;
-        if (ch_leaf[k]) n_leaf_prims += a.node_nprims[f.node[k]]; else ++n_inner;
+        if (!ch_leaf[k]) { ++n_inner; continue; }
+        uint32_t gk[3], lf[3];
+        const int nr = leaf_refs(a, f.node[k], gk, lf);
+        for (int w = 0; w < nr; ++w) if (first_of_its_prim(gk, w)) ++n_leaf_prims;
     }
     const uint32_t child_base = n_inner ? atomicAdd(&a.counters->next_node, n_inner) : 0u;
     const uint32_t prim_base = n_leaf_prims ? atomicAdd(&a.counters->next_prim, n_leaf_prims) : 0u;
@@ -376,29 +404,37 @@ __global__ __launch_bounds__(128) void k_emit_level(GpuBuildArgs a, const uint2 
         if (k >= 0) {
             const uint32_t c = f.node[k];
             if (ch_leaf[k]) {
-                const uint32_t np = a.node_nprims[c];
-                meta = (((1u << np) - 1u) << 5) | prim_off;
-                // the <= 3 primitives of the leaf: walk its little BVH2 subtree
-                uint32_t st[4]; int sp = 0; st[sp++] = c; uint32_t w = 0;
-                while (sp > 0) {
-                    const uint32_t x = st[--sp];
-                    const uint32_t l = __float_as_uint(a.node_lo[x].w), r = __float_as_uint(a.node_hi[x].w);
-                    if (l == kNone) {
-                        const uint32_t gk = r;                                      // global primitive number
-                        const uint32_t inst = find_instance(a.inst_first, a.n_inst, gk), p = gk - a.inst_first[inst];
-                        uint32_t *rec = reinterpret_cast<uint32_t *>(a.out_prims + (size_t)(prim_base + prim_off + w) * a.prim_stride);
-                        const uint32_t kind = a.inst_kind[inst];
-                        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, b0 = 0.0f;
-                        if (kind == kPrimKindSphere) {
-                            const float *src = reinterpret_cast<const float *>(a.inst_src[inst]) + 4 * (size_t)p;
-                            a0 = src[0]; a1 = src[1]; a2 = src[2]; b0 = src[3];
-                        }
-                        rec[0] = __float_as_uint(a0); rec[1] = __float_as_uint(a1); rec[2] = __float_as_uint(a2); rec[3] = p;
-                        rec[4] = __float_as_uint(b0); rec[5] = 0u; rec[6] = 0u; rec[7] = inst;
-                        rec[8] = 0u; rec[9] = 0u; rec[10] = 0u; rec[11] = kind;
-                        ++w;
-                    } else { st[sp++] = r; st[sp++] = l; }
+                uint32_t gks[3], lf[3];
+                const int nr = leaf_refs(a, c, gks, lf);
+                uint32_t np = 0u;
+                for (int w = 0; w < nr; ++w) {
+                    if (!first_of_its_prim(gks, w)) continue;
+                    const uint32_t gk = gks[w];                                     // global primitive number
+                    const uint32_t inst = find_instance(a.inst_first, a.n_inst, gk), p = gk - a.inst_first[inst];
+                    uint32_t *rec = reinterpret_cast<uint32_t *>(a.out_prims + (size_t)(prim_base + prim_off + np) * a.prim_stride);
+                    const uint32_t kind = a.inst_kind[inst];
+                    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, b0 = 0.0f;
+                    if (kind == kPrimKindSphere) {
+                        const float *src = reinterpret_cast<const float *>(a.inst_src[inst]) + 4 * (size_t)p;
+                        a0 = src[0]; a1 = src[1]; a2 = src[2]; b0 = src[3];
+                    }
+                    rec[0] = __float_as_uint(a0); rec[1] = __float_as_uint(a1); rec[2] = __float_as_uint(a2); rec[3] = p;
+                    rec[4] = __float_as_uint(b0); rec[5] = 0u; rec[6] = 0u; rec[7] = inst;
+                    rec[8] = 0u; rec[9] = 0u; rec[10] = 0u; rec[11] = kind;
+                    if (a.out_clip) {       // the box the refit takes for this record: the reference's (the union of its pieces in this leaf)
+                        float4 lo = a.node_lo[lf[w]], hi = a.node_hi[lf[w]];
+                        for (int u = w + 1; u < nr; ++u)
+                            if (gks[u] == gk) {
+                                const float4 l2 = a.node_lo[lf[u]], h2 = a.node_hi[lf[u]];
+                                lo.x = fminf(lo.x, l2.x); lo.y = fminf(lo.y, l2.y); lo.z = fminf(lo.z, l2.z);
+                                hi.x = fmaxf(hi.x, h2.x); hi.y = fmaxf(hi.y, h2.y); hi.z = fmaxf(hi.z, h2.z);
+                            }
+                        float *cb = a.out_clip + 6 * (size_t)(prim_base + prim_off + np);
+                        cb[0] = lo.x; cb[1] = lo.y; cb[2] = lo.z; cb[3] = hi.x; cb[4] = hi.y; cb[5] = hi.z;
+                    }
+                    ++np;
                 }
+                meta = (((1u << np) - 1u) << 5) | prim_off;
                 prim_off += np;
             } else {
                 meta = 0x20u | (24u + (uint32_t)s);
@@ -460,8 +496,6 @@ __global__ __launch_bounds__(256) void k_pack_spheres(const float *centers, cons
 
 #define B_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { res.error = _e; res.where = #expr; goto done; } } while (0)
 
-inline uint32_t blocks(uint32_t n, uint32_t per) { return (n + per - 1u) / per; }
-
 }  // namespace
 
 void launch_pack_spheres(const float *centers, const float *radii, uint32_t n, float *out, hipStream_t s) {
@@ -489,11 +523,18 @@ hipError_t gpu_blas_bounds(const float *d_src, uint32_t n_prims, uint32_t kind, 
     return hipSuccess;
 }
 
-// every array of gpu_build_bvh8 below (296 bytes per primitive) + the radix sort's and the scan's temporaries + alignment
-size_t gpu_build_scratch_bytes(uint32_t n_prims) { return (size_t)n_prims * 340u + (1u << 20); }
+// every array of gpu_build_bvh8 below (296 bytes per leaf) + the radix sort's and the scan's temporaries + alignment; with spatial
+// splits the leaves are references (at most gpu_build_max_refs of them), and the top-down phase's own buffers (build_split.hip: 32 bytes
+// per reference that stay, ~120 that are given back before the arrays below are taken) come on top
+size_t gpu_build_scratch_bytes(uint32_t n_prims, const SplitParams *split) {
+    if (!split || !split->enabled) return (size_t)n_prims * 340u + (1u << 20);
+    const size_t cap = gpu_build_max_refs(n_prims, split), tables = gpu_split_table_bytes(n_prims, *split);
+    const size_t phase = cap * 64u + std::max<size_t>(cap, n_prims) * 16u, after = cap * 348u;
+    return (size_t)n_prims * 32u + cap * 32u + tables + std::max(phase, after) + (4u << 20);
+}
 
-// The build.  in: instance tables + output buffers sized for the worst case (n nodes, n primitives).  Synchronises `s`
-// a few dozen times for a counter each (PLOC rounds, levels); no geometry crosses the bus.
+// The build.  in: instance tables + output buffers sized for the worst case (one node and one record per leaf).  Synchronises `s`
+// a few dozen times for a counter each (split levels, PLOC rounds, levels); no geometry crosses the bus.
 GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     GpuBuildResult res{};
     const uint32_t n = in.n_prims;
@@ -501,16 +542,13 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     void *temp = nullptr; size_t temp_bytes = 0, sort_bytes = 0, scan_bytes = 0;
     uint64_t *keys_out = nullptr; uint32_t *cl_b = nullptr; uint2 *items_a = nullptr, *items_b = nullptr;
     BuildCounters h{};
-    uint32_t nv = 0, m = 0, node_base = 0, root = 0;
-    std::vector<void *> owned;
-    size_t scratch_used = 0;
+    uint32_t nv = 0, nl = 0, ns = 0, m = 0, node_base = 0, root = 0, n_cells = 1;
+    bool split = false;
+    SplitPhaseResult sp{};
     // working memory comes out of the caller's arena while it lasts (a small build otherwise spends more time in ~25 hipMalloc /
     // hipFree pairs, each of which synchronises the device, than in its kernels)
-    auto alloc = [&](void **p, size_t bytes) -> hipError_t {
-        bytes = (std::max<size_t>(bytes, 16) + 255u) & ~(size_t)255u;
-        if (in.scratch && scratch_used + bytes <= in.scratch_bytes) { *p = static_cast<char *>(in.scratch) + scratch_used; scratch_used += bytes; return hipSuccess; }
-        hipError_t e = hipMalloc(p, bytes); if (e == hipSuccess) owned.push_back(*p); return e;
-    };
+    BuildArena arena; arena.base = in.scratch; arena.bytes = in.scratch_bytes;
+    auto alloc = [&](void **p, size_t bytes) -> hipError_t { return arena.alloc(p, bytes); };
 
     a.n = n; a.n_inst = in.n_inst; a.inst_first = in.d_inst_first; a.inst_kind = in.d_inst_kind; a.inst_src = in.d_inst_src;
     a.inst_xf = in.d_inst_xf; a.inst_identity = in.d_inst_identity;
@@ -520,48 +558,68 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
 
     B_TRY(alloc((void **)&a.counters, sizeof(BuildCounters)));
     B_TRY(alloc((void **)&a.pb_lo, sizeof(float4) * (size_t)n)); B_TRY(alloc((void **)&a.pb_hi, sizeof(float4) * (size_t)n));
-    B_TRY(alloc((void **)&a.keys, sizeof(uint64_t) * (size_t)n)); B_TRY(alloc((void **)&keys_out, sizeof(uint64_t) * (size_t)n));
-    B_TRY(alloc((void **)&a.vals, sizeof(uint32_t) * (size_t)n)); B_TRY(alloc((void **)&a.vals_sorted, sizeof(uint32_t) * (size_t)n));
-    B_TRY(alloc((void **)&a.node_lo, sizeof(float4) * 2 * (size_t)n)); B_TRY(alloc((void **)&a.node_hi, sizeof(float4) * 2 * (size_t)n));
-    B_TRY(alloc((void **)&a.node_parent, sizeof(uint32_t) * 2 * (size_t)n)); B_TRY(alloc((void **)&a.node_nprims, sizeof(uint32_t) * 2 * (size_t)n));
-    B_TRY(alloc((void **)&a.node_visit, sizeof(uint32_t) * 2 * (size_t)n));
-    B_TRY(alloc((void **)&a.cl_a, sizeof(uint32_t) * (size_t)n)); B_TRY(alloc((void **)&cl_b, sizeof(uint32_t) * (size_t)n));
-    B_TRY(alloc((void **)&a.nn, sizeof(uint32_t) * (size_t)n));
-    B_TRY(alloc((void **)&a.flags, sizeof(uint64_t) * (size_t)n)); B_TRY(alloc((void **)&a.scan, sizeof(uint64_t) * (size_t)n));
-    B_TRY(alloc((void **)&a.cost, sizeof(float) * 8 * 2 * (size_t)n));
-    B_TRY(alloc((void **)&items_a, sizeof(uint2) * (size_t)n)); B_TRY(alloc((void **)&items_b, sizeof(uint2) * (size_t)n));
-    B_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, a.keys, keys_out, a.vals, a.vals_sorted, (int)n, 0, 64, s));
-    B_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, a.flags, a.scan, (int)n, s));
-    temp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
-    B_TRY(alloc(&temp, temp_bytes));
-
     for (int d = 0; d < 3; ++d) { h.bmin[d] = h.cmin[d] = 0xffffffffu; h.bmax[d] = h.cmax[d] = 0u; }
     h.next_node = 1u;                                            // node 0 is the root
     B_TRY(hipMemcpyAsync(a.counters, &h, sizeof h, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_prim_bounds, dim3(blocks(n, 1024)), dim3(1024), 0, s, a);
-    hipLaunchKernelGGL(k_morton, dim3(blocks(n, 256)), dim3(256), 0, s, a);
     B_TRY(hipGetLastError());
-    B_TRY(hipcub::DeviceRadixSort::SortPairs(temp, sort_bytes, a.keys, keys_out, a.vals, a.vals_sorted, (int)n, 0, 64, s));
+    // ---- spatial splits: the top-down phase turns the primitives into references grouped in cells ----
+    split = in.split.enabled && in.max_leaf_prims == kMaxLeafPrims && n >= std::max(in.split.cell_refs, 8u);
+    if (split) {
+        B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
+        B_TRY(hipStreamSynchronize(s));
+        nv = n - h.n_invalid;
+        if (nv < std::max(in.split.cell_refs, 8u)) split = false;
+    }
+    if (split) {
+        sp = gpu_split_phase(a, nv, in.split, arena, s);
+        if (sp.error != hipSuccess) { res.error = sp.error; res.where = sp.where; goto done; }
+        a.ref_lo = sp.ref_lo; a.ref_hi = sp.ref_hi; a.out_clip = in.out_clip;
+        n_cells = sp.n_cells; res.split_levels = sp.levels; res.n_cells = sp.n_cells;
+    }
+    ns = split ? sp.n_refs : n;                                  // what is sorted: references, or all primitives (the invalid ones last)
+    B_TRY(alloc((void **)&a.keys, sizeof(uint64_t) * (size_t)ns)); B_TRY(alloc((void **)&keys_out, sizeof(uint64_t) * (size_t)ns));
+    B_TRY(alloc((void **)&a.vals, sizeof(uint32_t) * (size_t)ns)); B_TRY(alloc((void **)&a.vals_sorted, sizeof(uint32_t) * (size_t)ns));
+    B_TRY(alloc((void **)&a.node_lo, sizeof(float4) * 2 * (size_t)ns)); B_TRY(alloc((void **)&a.node_hi, sizeof(float4) * 2 * (size_t)ns));
+    B_TRY(alloc((void **)&a.node_parent, sizeof(uint32_t) * 2 * (size_t)ns)); B_TRY(alloc((void **)&a.node_nprims, sizeof(uint32_t) * 2 * (size_t)ns));
+    B_TRY(alloc((void **)&a.node_visit, sizeof(uint32_t) * 2 * (size_t)ns));
+    if (split) B_TRY(alloc((void **)&a.node_cell, sizeof(uint32_t) * 2 * (size_t)ns));
+    B_TRY(alloc((void **)&a.cl_a, sizeof(uint32_t) * (size_t)ns)); B_TRY(alloc((void **)&cl_b, sizeof(uint32_t) * (size_t)ns));
+    B_TRY(alloc((void **)&a.nn, sizeof(uint32_t) * (size_t)ns));
+    B_TRY(alloc((void **)&a.flags, sizeof(uint64_t) * (size_t)ns)); B_TRY(alloc((void **)&a.scan, sizeof(uint64_t) * (size_t)ns));
+    B_TRY(alloc((void **)&a.cost, sizeof(float) * 8 * 2 * (size_t)ns));
+    B_TRY(alloc((void **)&items_a, sizeof(uint2) * (size_t)ns)); B_TRY(alloc((void **)&items_b, sizeof(uint2) * (size_t)ns));
+    B_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, a.keys, keys_out, a.vals, a.vals_sorted, (int)ns, 0, 64, s));
+    B_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, a.flags, a.scan, (int)ns, s));
+    temp_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+    B_TRY(alloc(&temp, temp_bytes));
+
+    if (split) hipLaunchKernelGGL(k_morton_refs, dim3(blocks(ns, 256)), dim3(256), 0, s, a, ns, sp.segs, sp.cell_seg);
+    else hipLaunchKernelGGL(k_morton, dim3(blocks(n, 256)), dim3(256), 0, s, a);
+    B_TRY(hipGetLastError());
+    B_TRY(hipcub::DeviceRadixSort::SortPairs(temp, sort_bytes, a.keys, keys_out, a.vals, a.vals_sorted, (int)ns, 0, 64, s));
     B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
     B_TRY(hipStreamSynchronize(s));
     nv = n - h.n_invalid;
     res.n_prims = nv;
     if (nv == 0) goto done;                                      // nothing to hit: the caller emits the empty root
     for (int d = 0; d < 3; ++d) { res.lo[d] = ord2f(h.bmin[d]); res.hi[d] = ord2f(h.bmax[d]); }
+    nl = split ? ns : nv;                                        // leaves of the BVH2
 
     // ---- PLOC ----
-    hipLaunchKernelGGL(k_leaves, dim3(blocks(nv, 256)), dim3(256), 0, s, a, nv);
-    B_TRY(hipMemsetAsync(a.node_visit, 0, sizeof(uint32_t) * 2 * (size_t)n, s));
-    m = nv; node_base = nv;
+    if (split) hipLaunchKernelGGL(k_leaves_refs, dim3(blocks(nl, 256)), dim3(256), 0, s, a, nl);
+    else hipLaunchKernelGGL(k_leaves, dim3(blocks(nl, 256)), dim3(256), 0, s, a, nl);
+    B_TRY(hipMemsetAsync(a.node_visit, 0, sizeof(uint32_t) * 2 * (size_t)ns, s));
+    m = nl; node_base = nl;
     {
         uint32_t *cl_in = a.cl_a, *cl_out = cl_b;
         h.m_cur = m; h.node_base = node_base; h.m_next = m; h.merges = 0u;
         B_TRY(hipMemcpyAsync(a.counters, &h, sizeof h, hipMemcpyHostToDevice, s));
         // A round merges at least one pair, typically 40 % of the clusters.  The host launches kRoundsPerBatch rounds over the
-        // cluster count it last read (a round past the end of the build copies the one cluster left) and only then synchronises:
-        // 6 read-backs for a million primitives instead of 44
+        // cluster count it last read (a round past the end of the build copies the clusters left) and only then synchronises:
+        // 6 read-backs for a million primitives instead of 44.  With cells the rounds end when every cell is down to one cluster.
         constexpr int kRoundsPerBatch = 8;
-        while (m > 1u) {
+        while (m > n_cells) {
             for (int k = 0; k < kRoundsPerBatch; ++k) {
                 hipLaunchKernelGGL(k_ploc_nn, dim3(blocks(m, 256)), dim3(256), 0, s, a, cl_in);
                 hipLaunchKernelGGL(k_ploc_flags, dim3(blocks(m, 256)), dim3(256), 0, s, a, m);
@@ -577,12 +635,21 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
             if (h.m_cur >= m) { res.error = hipErrorUnknown; res.where = "PLOC made no progress"; goto done; }
             m = h.m_cur;
         }
+        if (m != n_cells) { res.error = hipErrorUnknown; res.where = "PLOC left fewer clusters than cells"; goto done; }
         node_base = h.node_base;
-        B_TRY(hipMemcpyAsync(&root, cl_in, sizeof root, hipMemcpyDeviceToHost, s));
-        B_TRY(hipStreamSynchronize(s));
+        if (split && sp.n_top) {
+            // the top of the tree: the split segments, numbered after PLOC's nodes (node_base + t; top node 0 is the root)
+            if ((uint64_t)node_base + sp.n_top > 2ull * ns) { res.error = hipErrorUnknown; res.where = "BVH2 node count"; goto done; }
+            hipLaunchKernelGGL(k_top_link, dim3(blocks(sp.n_top, 256)), dim3(256), 0, s, a, sp.segs, sp.top_seg, cl_in, sp.n_top, node_base);
+            B_TRY(hipGetLastError());
+            root = node_base;
+        } else {
+            B_TRY(hipMemcpyAsync(&root, cl_in, sizeof root, hipMemcpyDeviceToHost, s));
+            B_TRY(hipStreamSynchronize(s));
+        }
     }
     // ---- cost tables ----
-    hipLaunchKernelGGL(k_cost, dim3(blocks(nv, 256)), dim3(256), 0, s, a, nv);
+    hipLaunchKernelGGL(k_cost, dim3(blocks(nl, 256)), dim3(256), 0, s, a, nl);
     B_TRY(hipGetLastError());
     // ---- emission, level by level ----
     {
@@ -602,14 +669,14 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
             std::swap(it_in, it_out);
             if (level_count) ++depth;
         }
-        res.n_nodes = h.next_node; res.max_depth = depth;
-        if (h.next_prim != nv) { res.error = hipErrorUnknown; res.where = "emitted primitive count differs from the valid count"; goto done; }
+        res.n_nodes = h.next_node; res.max_depth = depth; res.n_records = h.next_prim;
+        // (with spatial splits, pieces of a primitive that met again in a leaf were emitted once)
+        if (split ? (h.next_prim < nv || h.next_prim > nl) : h.next_prim != nv) { res.error = hipErrorUnknown; res.where = "emitted primitive count differs from the valid count"; goto done; }
     }
     hipLaunchKernelGGL(k_normalise_weights, dim3(blocks(res.n_nodes, 256)), dim3(256), 0, s, in.out_node_ref, res.n_nodes, a.counters);
     B_TRY(hipGetLastError());
     B_TRY(hipStreamSynchronize(s));
 done:
-    for (void *p : owned) (void)hipFree(p);
     return res;
 }
 

@@ -80,47 +80,14 @@ struct Builder {
     uint32_t alloc2() { return n_nodes.fetch_add(2); }
 
     // bounds of the part of reference r between the planes x[a] = p0 and x[a] = p1: the triangle clipped to the reference's box
-    // and the slab (Sutherland-Hodgman, double arithmetic, rounded outwards by one float ULP); other primitives: box ∩ slab
+    // and the slab (bvh8_geom.h clip_triangle_to_box); other primitives: box ∩ slab
     void clip_ref(const Ref &r, int a, float p0, float p1, float *lo, float *hi) const {
         const BuildPrim &bp = in[r.prim];
         float blo[3], bhi[3];
         for (int c = 0; c < 3; ++c) { blo[c] = r.lo[c]; bhi[c] = r.hi[c]; }
         blo[a] = std::max(blo[a], p0); bhi[a] = std::min(bhi[a], p1);
         if (bp.rec.kind != kPrimKindTriangle) { for (int c = 0; c < 3; ++c) { lo[c] = blo[c]; hi[c] = bhi[c]; } return; }
-        double poly[2][16][3]; int np = 3, cur = 0;
-        for (int c = 0; c < 3; ++c) {
-            poly[0][0][c] = bp.rec.a[c];
-            poly[0][1][c] = (double)bp.rec.a[c] + (double)bp.rec.b[c];
-            poly[0][2][c] = (double)bp.rec.a[c] + (double)bp.rec.c[c];
-        }
-        // (the record keeps v0, e1, e2 in float: v1 = v0 + e1 in double is the vertex to within half an ULP, which the outward
-        // rounding and the padding below cover)
-        for (int c = 0; c < 3 && np > 0; ++c)
-            for (int side = 0; side < 2 && np > 0; ++side) {
-                const double plane = side == 0 ? (double)blo[c] : (double)bhi[c];
-                const double sgn = side == 0 ? 1.0 : -1.0;
-                int nq = 0;
-                for (int i = 0; i < np; ++i) {
-                    const double *u = poly[cur][i], *v = poly[cur][(i + 1) % np];
-                    const double du = sgn * (u[c] - plane), dv = sgn * (v[c] - plane);
-                    if (du >= 0.0) { for (int k = 0; k < 3; ++k) poly[cur ^ 1][nq][k] = u[k]; ++nq; }
-                    if ((du > 0.0 && dv < 0.0) || (du < 0.0 && dv > 0.0)) {
-                        const double t = du / (du - dv);
-                        for (int k = 0; k < 3; ++k) poly[cur ^ 1][nq][k] = k == c ? plane : u[k] + t * (v[k] - u[k]);
-                        ++nq;
-                    }
-                }
-                np = nq; cur ^= 1;
-            }
-        if (np == 0) { for (int c = 0; c < 3; ++c) { lo[c] = blo[c]; hi[c] = bhi[c]; } return; }      // (numerically empty: stay conservative)
-        for (int c = 0; c < 3; ++c) {
-            double l = poly[cur][0][c], h = l;
-            for (int i = 1; i < np; ++i) { l = std::min(l, poly[cur][i][c]); h = std::max(h, poly[cur][i][c]); }
-            float fl = (float)l, fh = (float)h;
-            fl = std::nextafter(fl, -kInfF); fh = std::nextafter(fh, kInfF);
-            lo[c] = std::max(blo[c], fl); hi[c] = std::min(bhi[c], fh);
-            if (lo[c] > hi[c]) { lo[c] = blo[c]; hi[c] = bhi[c]; }
-        }
+        clip_triangle_to_box(bp.rec.a, bp.rec.b, bp.rec.c, blo, bhi, lo, hi);
     }
 
     // budget: references the spatial splits of THIS subtree may still add; a split hands what is left to its children in proportion to

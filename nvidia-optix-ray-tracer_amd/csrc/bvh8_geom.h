@@ -64,6 +64,46 @@ HRT_HD bool finite_box(const float *lo, const float *hi) {
     return ok;
 }
 
+// Bounds of the part of a triangle (record form: v0, e1, e2) inside the box [blo, bhi]: Sutherland-Hodgman against the six planes in
+// double arithmetic, rounded outwards by one float ULP and never beyond the box.  Used where a spatial split cuts a reference
+// (host builder bvh8_build.cpp and device builder build_split.hip: one arithmetic).  (The record keeps the vertices as v0, v0 + e1,
+// v0 + e2 in float: the sums in double are the vertices to within half an ULP, which the outward rounding and the builders' padding cover.)
+// A numerically empty result leaves the box itself: conservative.
+HRT_HD void clip_triangle_to_box(const float *v0, const float *e1, const float *e2, const float *blo, const float *bhi, float *lo, float *hi) {
+    double poly[2][16][3]; int np = 3, cur = 0;
+    for (int c = 0; c < 3; ++c) {
+        poly[0][0][c] = v0[c];
+        poly[0][1][c] = (double)v0[c] + (double)e1[c];
+        poly[0][2][c] = (double)v0[c] + (double)e2[c];
+    }
+    for (int c = 0; c < 3 && np > 0; ++c)
+        for (int side = 0; side < 2 && np > 0; ++side) {
+            const double plane = side == 0 ? (double)blo[c] : (double)bhi[c];
+            const double sgn = side == 0 ? 1.0 : -1.0;
+            int nq = 0;
+            for (int i = 0; i < np; ++i) {
+                const double *u = poly[cur][i], *v = poly[cur][(i + 1) % np];
+                const double du = sgn * (u[c] - plane), dv = sgn * (v[c] - plane);
+                if (du >= 0.0) { for (int k = 0; k < 3; ++k) poly[cur ^ 1][nq][k] = u[k]; ++nq; }
+                if ((du > 0.0 && dv < 0.0) || (du < 0.0 && dv > 0.0)) {
+                    const double t = du / (du - dv);
+                    for (int k = 0; k < 3; ++k) poly[cur ^ 1][nq][k] = k == c ? plane : u[k] + t * (v[k] - u[k]);
+                    ++nq;
+                }
+            }
+            np = nq; cur ^= 1;
+        }
+    if (np == 0) { for (int c = 0; c < 3; ++c) { lo[c] = blo[c]; hi[c] = bhi[c]; } return; }
+    for (int c = 0; c < 3; ++c) {
+        double l = poly[cur][0][c], h = l;
+        for (int i = 1; i < np; ++i) { l = l < poly[cur][i][c] ? l : poly[cur][i][c]; h = h > poly[cur][i][c] ? h : poly[cur][i][c]; }
+        float fl = (float)l, fh = (float)h;
+        fl = nextafterf(fl, -INFINITY); fh = nextafterf(fh, INFINITY);
+        lo[c] = blo[c] > fl ? blo[c] : fl; hi[c] = bhi[c] < fh ? bhi[c] : fh;
+        if (lo[c] > hi[c]) { lo[c] = blo[c]; hi[c] = bhi[c]; }
+    }
+}
+
 // Smallest exponent e (biased by 127, within [1, 254]) with 255 * 2^(e-127) >= ext, from the bits of ext.
 HRT_HD uint8_t node_exponent(float ext) {
     if (!(ext > 0.0f)) return 1;

@@ -162,6 +162,8 @@ struct RefitArgs {
     float *node_ref;               // 2 floats per node: {weight, 1 / half area as built}
     uint32_t write_reference;      // 1: this refit completes a build -- record the areas instead of comparing with them
     float *area_sum;               // weighted mean of area now / area as built (quality after the refit), may be NULL
+    const float *clip;             // when set (the refit that completes a device build with spatial splits): 6 floats per record, the box of the part
+                                   // of the primitive this record stands for, taken instead of the primitive's own
 };
 constexpr uint32_t kRefitTopLevels = 16, kRefitTopLevelNodes = 1024;
 struct RefitLevels { uint32_t n_levels; uint32_t first[kRefitTopLevels], count[kRefitTopLevels]; };   // phases in processing order, each at most kRefitTopLevelNodes wide

@@ -237,7 +237,9 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
     }
     std::vector<uint32_t> order;
     t.phases.clear();
-    const bool device_merged = !instanced && ctx->build_on_device != 0 && !fast_trace;
+    // HRT_CTX_FAST_TRACE: the static-scene tree with spatial splits -- from the host builder, or (HRT_FAST_TRACE_BUILD=device) from the device's
+    const bool device_split = fast_trace && ctx->fast_trace_on_device != 0 && !instanced && ctx->build_on_device != 0;
+    const bool device_merged = !instanced && ctx->build_on_device != 0 && (!fast_trace || device_split);
     // global primitive numbering of the merged builds: instance after instance, invisible instances contribute nothing
     std::vector<uint32_t> first(n + 1, 0u);
     uint32_t n_tri_in = 0, n_sph_in = 0;
@@ -328,7 +330,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
     std::vector<const void *> src(std::max(n, 1u), nullptr);
     for (uint32_t i = 0; i < n; ++i) src[i] = t.blas_refs[i]->d_verts;
     if (!on_device) HIP_TRY(ctx, hipMalloc(&t.d_nodes, nb));
-    HIP_TRY(ctx, hipMalloc(&t.d_prims, pb));
+    if (!(on_device && device_split)) HIP_TRY(ctx, hipMalloc(&t.d_prims, pb));      // (a split build knows its record count afterwards)
     HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_inv, sizeof(float) * t.h_inv.size()));
     HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_xf, sizeof(float) * t.h_xf.size()));
     HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_identity, sizeof(uint32_t) * t.h_ident.size()));
@@ -378,15 +380,22 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         in.n_prims = first[n]; in.n_inst = n; in.d_inst_first = t.d_inst_first; in.d_inst_kind = t.d_inst_kind; in.d_inst_src = t.d_inst_src;
         in.d_inst_xf = t.d_inst_xf; in.d_inst_identity = t.d_inst_identity;
         in.max_leaf_prims = kMaxLeafPrims; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius;
-        // worst-case node output (one node and two reference floats per primitive) at the front of the working memory
-        const size_t stage_nodes = ((size_t)t.node_stride * in.n_prims + 255u) & ~(size_t)255u, stage_ref = (sizeof(float) * 2 * (size_t)in.n_prims + 255u) & ~(size_t)255u;
-        const ScratchArena arena = scratch_acquire(ctx, gpu_build_scratch_bytes(in.n_prims) + stage_nodes + stage_ref);
-        if (!arena.p) return fail(ctx, HRT_ERR_OOM, "device build: no working memory (%zu bytes)", gpu_build_scratch_bytes(in.n_prims) + stage_nodes + stage_ref);
+        in.split.enabled = device_split; in.split.budget_frac = ctx->split_budget; in.split.alpha = ctx->split_alpha; in.split.bias = ctx->split_bias;
+        in.split.cell_refs = (uint32_t)ctx->split_cell_refs; in.split.pad = ra.pad; in.split.verbose = std::getenv("HRT_BUILD_VERBOSE") != nullptr;
+        // worst-case node output (one node and two reference floats per leaf: primitive, or reference of a spatial split) at the front of the
+        // working memory; a split build's records and their clip boxes too (their number is known afterwards)
+        const size_t max_leaves = gpu_build_max_refs(in.n_prims, &in.split);
+        const size_t stage_nodes = ((size_t)t.node_stride * max_leaves + 255u) & ~(size_t)255u, stage_ref = (sizeof(float) * 2 * max_leaves + 255u) & ~(size_t)255u;
+        const size_t stage_prims = device_split ? ((size_t)t.prim_stride * max_leaves + 255u) & ~(size_t)255u : 0u, stage_clip = device_split ? (sizeof(float) * 6 * max_leaves + 255u) & ~(size_t)255u : 0u;
+        const size_t stage_all = stage_nodes + stage_ref + stage_prims + stage_clip, want = gpu_build_scratch_bytes(in.n_prims, &in.split) + stage_all;
+        const ScratchArena arena = scratch_acquire(ctx, want);
+        if (!arena.p) return fail(ctx, HRT_ERR_OOM, "device build: no working memory (%zu bytes)", want);
         struct Release { HrtContext *c; ScratchArena a; ~Release() { scratch_release(c, a); } } release{ctx, arena};
         unsigned char *stage = static_cast<unsigned char *>(arena.p);
         in.out_nodes = stage; in.node_stride = t.node_stride; in.out_node_ref = reinterpret_cast<float *>(stage + stage_nodes);
-        in.out_prims = ra.prims; in.prim_stride = t.prim_stride;
-        in.scratch = stage + stage_nodes + stage_ref; in.scratch_bytes = arena.bytes - stage_nodes - stage_ref;
+        in.out_prims = device_split ? stage + stage_nodes + stage_ref : ra.prims; in.prim_stride = t.prim_stride;
+        in.out_clip = device_split ? reinterpret_cast<float *>(stage + stage_nodes + stage_ref + stage_prims) : nullptr;
+        in.scratch = stage + stage_all; in.scratch_bytes = arena.bytes - stage_all;
         const GpuBuildResult r = gpu_build_bvh8(in, s);      // (synchronises the stream before it returns)
         if (r.error != hipSuccess) return fail(ctx, r.error == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, "device build failed: %s (%s)", hipGetErrorString(r.error), r.where);
         {   // the tree's own buffers, as large as the build turned out to need
@@ -394,13 +403,20 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
             HIP_TRY(ctx, hipMalloc(&t.d_nodes, (size_t)t.node_stride * nn));
             HIP_TRY(ctx, hipMalloc((void **)&t.d_node_box, sizeof(float) * 6 * nn));
             HIP_TRY(ctx, hipMalloc((void **)&t.d_node_ref, sizeof(float) * 2 * nn));
+            size_t rec_bytes = pb;
+            if (device_split) {
+                rec_bytes = (size_t)t.prim_stride * std::max<size_t>(r.n_records, 1);
+                HIP_TRY(ctx, hipMalloc(&t.d_prims, rec_bytes));
+                ra.prims = reinterpret_cast<unsigned char *>(t.d_prims);
+                if (r.n_records) HIP_TRY(ctx, hipMemcpyAsync(t.d_prims, in.out_prims, (size_t)t.prim_stride * r.n_records, hipMemcpyDeviceToDevice, s));
+            }
             if (r.n_prims) {
                 HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, stage, (size_t)t.node_stride * nn, hipMemcpyDeviceToDevice, s));
                 HIP_TRY(ctx, hipMemcpyAsync(t.d_node_ref, in.out_node_ref, sizeof(float) * 2 * nn, hipMemcpyDeviceToDevice, s));
                 HIP_TRY(ctx, hipStreamSynchronize(s));         // the working memory goes back to the context when this scope ends
             }
             ra.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); ra.node_box = t.d_node_box; ra.node_ref = t.d_node_ref;
-            t.alloc_bytes = (uint64_t)t.node_stride * nn + sizeof(float) * 8 * nn + pb;
+            t.alloc_bytes = (uint64_t)t.node_stride * nn + sizeof(float) * 8 * nn + rec_bytes;
         }
         t.bvh = Bvh8();
         if (r.n_prims == 0u) {
@@ -412,12 +428,18 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         } else {
             if (2 * r.max_depth + 2 > (uint32_t)(8 + 56)) return fail(ctx, HRT_ERR_INVALID, "BVH depth %u exceeds the traversal stack", r.max_depth);
             for (size_t l = r.level_begin.size() - 1; l-- > 0;) t.phases.emplace_back(r.level_begin[l], r.level_begin[l + 1] - r.level_begin[l]);
+            // (a split build: every record's box is the one its cell is responsible for, not the primitive's -- this once; a later
+            // update would recompute the boxes from whole primitives, so the first update rebuilds instead: has_split_refs)
+            if (r.split_levels) { ra.clip = in.out_clip; t.has_split_refs = true; }
             launch_refit_phases(ra, t.phases, s);
             HIP_TRY(ctx, hipGetLastError());
+            if (r.split_levels) HIP_TRY(ctx, hipStreamSynchronize(s));      // (the clip boxes live in the working memory)
+            ra.clip = nullptr;
             if (std::getenv("HRT_BUILD_VERBOSE"))
-                std::fprintf(stderr, "[hrt] device build: %u primitives -> %u nodes, depth %u, %u PLOC rounds (radius %d)\n", r.n_prims, r.n_nodes, r.max_depth, r.ploc_rounds, ctx->ploc_radius);
+                std::fprintf(stderr, "[hrt] device build: %u primitives -> %u records, %u nodes, depth %u, %u PLOC rounds (radius %d), %u split levels, %u cells\n",
+                             r.n_prims, r.n_records, r.n_nodes, r.max_depth, r.ploc_rounds, ctx->ploc_radius, r.split_levels, r.n_cells);
             const uint32_t dropped = first[n] - r.n_prims;      // non-finite primitives (counted against the triangles unless there are none)
-            t.n_nodes = r.n_nodes; t.n_prims = r.n_prims; t.max_depth = r.max_depth;
+            t.n_nodes = r.n_nodes; t.n_prims = r.n_records; t.max_depth = r.max_depth;
             t.n_triangles = n_tri_in >= dropped ? n_tri_in - dropped : 0u; t.n_spheres = r.n_prims - t.n_triangles;
             for (int a = 0; a < 3; ++a) { t.lo[a] = r.lo[a]; t.hi[a] = r.hi[a]; }
         }

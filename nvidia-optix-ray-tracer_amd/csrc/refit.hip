@@ -61,6 +61,10 @@ __device__ __forceinline__ void refit_slot(const RefitArgs &a, uint32_t node, ui
                         const float c3[3] = {rf[0], rf[1], rf[2]};
                         sphere_world_bounds(c3, rf[4], m, ident, plo, phi);
                     }
+                    if (a.clip) {                                      // a reference of a spatial split: the box its cell is responsible for
+                        const float *cb = a.clip + 6 * (size_t)(prim_base + off + k);
+                        for (int q = 0; q < 3; ++q) { plo[q] = cb[q]; phi[q] = cb[3 + q]; }
+                    }
                     if (finite_box(plo, phi))
                         for (int q = 0; q < 3; ++q) { lo[q] = fminf(lo[q], plo[q] - pad); hi[q] = fmaxf(hi[q], phi[q] + pad); }
                 }
