@@ -10,7 +10,7 @@ LIBDIR  := $(PKG)/lib
 ARCH    := gfx950
 
 # -ffp-contract=off: arithmetic that feeds control flow must round exactly like the oracle.
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Iinclude -I$(CSRC) -Wall -Wno-unused-function -Wno-pass-failed
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Iinclude -I$(CSRC) -Wall -Wno-unused-function -Wno-pass-failed $(EXTRA_HIPFLAGS)
 CXXFLAGS := -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(CSRC) -Wall -pthread
 
 all: lib oracle tools

@@ -55,12 +55,14 @@ typedef struct HrtContext HrtContext;
                                     after a build is synchronous in either mode (one small read-back per build): the reference builds every file's IAS
                                     with identity transforms and poses it afterwards, so that update is the one that has to rebuild. */
 #define HRT_CTX_FAST_TRACE 0x4u  /* hrt_tlas_build prefers trace speed to build speed: the reference's OPTIX_BUILD_FLAG_PREFER_FAST_TRACE
-                                    (its GAS builds, RendererImpl.cu:94,118,144).  The tree is then built by the host's binned-SAH builder
-                                    WITH SPATIAL SPLITS from a host copy of the geometry (1 M triangles: ~1.4 s, 9.5 % fewer node visits per
-                                    ray, 1.4 records per triangle) instead of by the device build (PLOC, ~8 ms, no
-                                    geometry leaves the GPU).  Such a tree is for static scenes: the first hrt_tlas_update replaces it by a
-                                    device-built one (a refit cannot keep the split references' boxes), and rebuilds inside hrt_tlas_update
-                                    always stay on the device (the reference's IAS flags: ALLOW_UPDATE | PREFER_FAST_BUILD, RendererImpl.cu:180). */
+                                    (its GAS builds, RendererImpl.cu:94,118,144).  The tree is then built WITH SPATIAL SPLITS: on the device
+                                    (csrc/build_split.hip: top-down SAH splits of references level by level, PLOC within the cells that
+                                    remain; 1 M triangles: ~22 ms against ~8 ms for the default build, 11.5 % fewer node visits per ray,
+                                    1.3 records per triangle, ~1.2 KB of working memory per triangle), or -- environment
+                                    HRT_FAST_TRACE_BUILD=host -- by the host's binned-SAH builder from a host copy of the geometry (the same
+                                    rules, ~1.3 s).  Such a tree is for static scenes: the first hrt_tlas_update replaces it by a
+                                    default-built one (a refit cannot keep the split references' boxes), and rebuilds inside hrt_tlas_update
+                                    are always default builds (the reference's IAS flags: ALLOW_UPDATE | PREFER_FAST_BUILD, RendererImpl.cu:180). */
 
 /* replaces createContext / destroyContext, src/Global/RendererImpl.cu:6-27 */
 int  hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx);
@@ -83,7 +85,7 @@ int  hrt_blas_destroy(HrtContext *ctx, HrtTraversable blas);
 /* replaces buildIAS / updateIAS, src/Global/RendererImpl.cu:174-242.  d_instances lives in
  * device memory (reference: cudaMemcpy H2D then build, src/Global/RendererMesh.cu:151-160).
  * hrt_tlas_build flattens the instances into one world-space BVH8, built on the device (Morton sort, PLOC, optimal
- * 8-wide collapse: csrc/build.hip; the host's binned-SAH builder only under HRT_CTX_FAST_TRACE).  hrt_tlas_update takes
+ * 8-wide collapse: csrc/build.hip; under HRT_CTX_FAST_TRACE with spatial splits, csrc/build_split.hip).  hrt_tlas_update takes
  * the same number of instances: when only transforms (and sbtOffsets) changed, the tree is refitted on the
  * device, asynchronously on `stream` after one small read-back of the instance array; a changed BLAS handle
  * or visibility mask, or a refitted tree whose boxes have grown too far, rebuilds it (as a tree over

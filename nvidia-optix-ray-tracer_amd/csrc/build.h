@@ -13,6 +13,7 @@ struct BuildCounters {
     uint32_t n_invalid;               // primitives with non-finite bounds (left out of the tree)
     uint32_t m_next, merges;          // PLOC round: clusters after the round, merges made
     uint32_t m_cur, node_base;        // PLOC: clusters before the round, index of the next BVH2 node (advanced on the device between rounds)
+    uint32_t round_base[8], round_idx; // node_base after each of the last eight rounds (the cost pass walks the rounds in order)
     uint32_t next_node, next_prim;    // emission cursors
     float total_below;                // sum over BVH8 nodes of the primitives below them (refit quality weights)
 };
@@ -28,7 +29,7 @@ struct GpuBuildArgs {
     float4 *pb_lo, *pb_hi;            // per primitive: world bounds (lo.w = valid)
     uint64_t *keys; uint32_t *vals, *vals_sorted;
     float4 *node_lo, *node_hi;        // BVH2: lo.xyz | left, hi.xyz | right (leaf: left = ~0, right = primitive)
-    uint32_t *node_parent, *node_nprims, *node_visit;
+    uint32_t *node_nprims;
     uint32_t *cl_a, *nn; uint64_t *flags, *scan;
     float *cost;                      // 8 floats per BVH2 node
     // builds with spatial splits (build_split.hip): the leaves are REFERENCES -- a primitive and the box of the part of it a cell is responsible for
@@ -63,6 +64,7 @@ struct SplitPhaseResult {
     uint32_t n_refs = 0, n_cells = 0, n_top = 0, levels = 0;
     float4 *ref_lo = nullptr, *ref_hi = nullptr;         // n_refs: lo.xyz | primitive, hi.xyz | cell (references of a cell are contiguous)
     SplitSeg *segs = nullptr; uint32_t *top_seg = nullptr, *cell_seg = nullptr;     // top node t is segment top_seg[t]; cell c is segment cell_seg[c]
+    std::vector<uint32_t> top_level_begin;                // top nodes of level l: [top_level_begin[l], top_level_begin[l + 1])
 };
 
 // working memory of a build: the caller's arena while it lasts, hipMalloc beyond

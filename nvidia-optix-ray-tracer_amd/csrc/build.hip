@@ -8,7 +8,7 @@
 //      merged surface area within +-16 positions) when the choice is mutual -- a BVH2 of near-SAH quality in ~15 rounds,
 //      every round a handful of O(n) launches; node numbers come from prefix sums, so the BVH2 is deterministic;
 //   4. the optimal SAH collapse to 8-wide nodes (Ylitie, Karras, Laine 2017, sec. 4.1: the same cost tables as the host
-//      builder bvh8_build.cpp) computed bottom-up, a node by whichever of its children's threads arrives second;
+//      builder bvh8_build.cpp) computed bottom-up, a launch per PLOC round (a round's nodes have children from earlier rounds only);
 //   5. emission of the packed BVH8 breadth first, one launch per level: forest roots from the tables, octant slot
 //      assignment, child / primitive blocks from atomic cursors -- topology and primitive ids only;
 //   6. the refit kernels (refit.hip) then compute every world-space record, box, origin, exponent and quantised child box
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_leaves_refs(GpuBuildArgs a, uint32_t n_
     a.node_lo[i] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(kNone));
     a.node_hi[i] = make_float4(hi.x, hi.y, hi.z, lo.w);
     a.node_cell[i] = __float_as_uint(hi.w);
-    a.node_parent[i] = kNone; a.node_nprims[i] = 1u;
+    a.node_nprims[i] = 1u;
     a.cl_a[i] = i;
 }
 
@@ -135,10 +135,7 @@ __global__ __launch_bounds__(256) void k_top_link(GpuBuildArgs a, const SplitSeg
     }
     a.node_lo[id] = make_float4(ord2f(sg.nb[0]), ord2f(sg.nb[1]), ord2f(sg.nb[2]), __uint_as_float(ch[0]));
     a.node_hi[id] = make_float4(-ord2f(sg.nb[3]), -ord2f(sg.nb[4]), -ord2f(sg.nb[5]), __uint_as_float(ch[1]));
-    a.node_parent[ch[0]] = id; a.node_parent[ch[1]] = id;
-    if (t == 0u) a.node_parent[id] = kNone;
     a.node_nprims[id] = sg.count;
-    a.node_visit[id] = 0u;
 }
 
 // BVH2 node i: lo.xyz | left, hi.xyz | right.  Leaf: left = kNone, right = global primitive number.
@@ -149,7 +146,7 @@ __global__ __launch_bounds__(256) void k_leaves(GpuBuildArgs a, uint32_t nv) {
     const float4 lo = a.pb_lo[k], hi = a.pb_hi[k];
     a.node_lo[i] = make_float4(lo.x, lo.y, lo.z, __uint_as_float(kNone));
     a.node_hi[i] = make_float4(hi.x, hi.y, hi.z, __uint_as_float(k));
-    a.node_parent[i] = kNone; a.node_nprims[i] = 1u;
+    a.node_nprims[i] = 1u;
     a.cl_a[i] = i;
 }
 
@@ -214,9 +211,7 @@ __global__ __launch_bounds__(256) void k_ploc_apply(GpuBuildArgs a, const uint32
     const float4 llo = a.node_lo[l], lhi = a.node_hi[l], rlo = a.node_lo[r], rhi = a.node_hi[r];
     a.node_lo[id] = make_float4(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z), __uint_as_float(l));
     a.node_hi[id] = make_float4(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), __uint_as_float(r));
-    a.node_parent[l] = id; a.node_parent[r] = id; a.node_parent[id] = kNone;
     a.node_nprims[id] = a.node_nprims[l] + a.node_nprims[r];
-    a.node_visit[id] = 0u;
     if (a.node_cell) a.node_cell[id] = a.node_cell[l];
     cl_out[pos] = id;
 }
@@ -225,6 +220,7 @@ __global__ __launch_bounds__(256) void k_ploc_apply(GpuBuildArgs a, const uint32
 __global__ void k_ploc_advance(GpuBuildArgs a) {
     BuildCounters *c = a.counters;
     c->node_base += c->merges; c->m_cur = c->m_next;
+    c->round_base[c->round_idx & 7u] = c->node_base; ++c->round_idx;      // (the host reads eight rounds' worth at a time)
 }
 
 // ---- optimal collapse: cost tables (bvh8_build.cpp, same recurrences) ----
@@ -250,7 +246,7 @@ __device__ void cost_of_node(const GpuBuildArgs &a, uint32_t nd, bool leaf, Cost
     }
     const uint32_t l = __float_as_uint(a.node_lo[nd].w), r = __float_as_uint(a.node_hi[nd].w);
     CostRow cl, cr;
-    {   // the children's rows were written by other threads: read past this CU's L1 (the caller has fenced)
+    {   // the children's rows: written by an earlier launch
         const float4 *pl = reinterpret_cast<const float4 *>(a.cost + 8 * (size_t)l), *pr = reinterpret_cast<const float4 *>(a.cost + 8 * (size_t)r);
         const float4 l0 = pl[0], l1 = pl[1], r0 = pr[0], r1 = pr[1];
         cl.c[0] = l0.x; cl.c[1] = l0.y; cl.c[2] = l0.z; cl.c[3] = l0.w; cl.c[4] = l1.x; cl.c[5] = l1.y; cl.c[6] = l1.z; cl.c[7] = l1.w;
@@ -279,23 +275,15 @@ __device__ __forceinline__ void store_row(const GpuBuildArgs &a, uint32_t nd, co
     p[0] = make_float4(r.c[0], r.c[1], r.c[2], r.c[3]); p[1] = make_float4(r.c[4], r.c[5], r.c[6], r.c[7]);
 }
 
-// one thread per leaf; a node is computed by the second of its children's threads to arrive
-__global__ __launch_bounds__(256) void k_cost(GpuBuildArgs a, uint32_t nv) {
+// a range of BVH2 nodes whose children's tables are complete: the leaves, then the nodes of one PLOC round after another (a round's
+// nodes have children from earlier rounds only), then the top-down phase's levels from the deepest up.  (Round 2 let the second of a
+// node's children to arrive compute it, behind agent-scope fences: 5 ms for a million leaves on a part whose L2s are per XCD.)
+__global__ __launch_bounds__(256) void k_cost_range(GpuBuildArgs a, uint32_t first, uint32_t count, uint32_t leaf) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= nv) return;
+    if (i >= count) return;
     CostRow row;
-    cost_of_node(a, i, true, row);
-    store_row(a, i, row);
-    uint32_t nd = a.node_parent[i];
-    while (nd != kNone) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // my row is visible before my arrival is
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the write-back has completed: never left to the compiler's scoreboard)
-        if (atomicAdd(&a.node_visit[nd], 1u) == 0u) return;       // the sibling subtree is not done: its thread will do this node
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // the sibling's row, not a stale line of this CU's L1
-        cost_of_node(a, nd, false, row);
-        store_row(a, nd, row);
-        nd = a.node_parent[nd];
-    }
+    cost_of_node(a, first + i, leaf != 0u, row);
+    store_row(a, first + i, row);
 }
 
 // ---- emission of one BVH8 level ----
@@ -545,6 +533,7 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     uint32_t nv = 0, nl = 0, ns = 0, m = 0, node_base = 0, root = 0, n_cells = 1;
     bool split = false;
     SplitPhaseResult sp{};
+    std::vector<uint32_t> round_end;                             // index of the next BVH2 node after each PLOC round
     // working memory comes out of the caller's arena while it lasts (a small build otherwise spends more time in ~25 hipMalloc /
     // hipFree pairs, each of which synchronises the device, than in its kernels)
     BuildArena arena; arena.base = in.scratch; arena.bytes = in.scratch_bytes;
@@ -564,12 +553,12 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     hipLaunchKernelGGL(k_prim_bounds, dim3(blocks(n, 1024)), dim3(1024), 0, s, a);
     B_TRY(hipGetLastError());
     // ---- spatial splits: the top-down phase turns the primitives into references grouped in cells ----
-    split = in.split.enabled && in.max_leaf_prims == kMaxLeafPrims && n >= std::max(in.split.cell_refs, 8u);
+    split = in.split.enabled && in.max_leaf_prims == kMaxLeafPrims && n >= std::max(in.split.cell_refs, 2u);
     if (split) {
         B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
         B_TRY(hipStreamSynchronize(s));
         nv = n - h.n_invalid;
-        if (nv < std::max(in.split.cell_refs, 8u)) split = false;
+        if (nv < std::max(in.split.cell_refs, 2u)) split = false;
     }
     if (split) {
         sp = gpu_split_phase(a, nv, in.split, arena, s);
@@ -581,8 +570,7 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     B_TRY(alloc((void **)&a.keys, sizeof(uint64_t) * (size_t)ns)); B_TRY(alloc((void **)&keys_out, sizeof(uint64_t) * (size_t)ns));
     B_TRY(alloc((void **)&a.vals, sizeof(uint32_t) * (size_t)ns)); B_TRY(alloc((void **)&a.vals_sorted, sizeof(uint32_t) * (size_t)ns));
     B_TRY(alloc((void **)&a.node_lo, sizeof(float4) * 2 * (size_t)ns)); B_TRY(alloc((void **)&a.node_hi, sizeof(float4) * 2 * (size_t)ns));
-    B_TRY(alloc((void **)&a.node_parent, sizeof(uint32_t) * 2 * (size_t)ns)); B_TRY(alloc((void **)&a.node_nprims, sizeof(uint32_t) * 2 * (size_t)ns));
-    B_TRY(alloc((void **)&a.node_visit, sizeof(uint32_t) * 2 * (size_t)ns));
+    B_TRY(alloc((void **)&a.node_nprims, sizeof(uint32_t) * 2 * (size_t)ns));
     if (split) B_TRY(alloc((void **)&a.node_cell, sizeof(uint32_t) * 2 * (size_t)ns));
     B_TRY(alloc((void **)&a.cl_a, sizeof(uint32_t) * (size_t)ns)); B_TRY(alloc((void **)&cl_b, sizeof(uint32_t) * (size_t)ns));
     B_TRY(alloc((void **)&a.nn, sizeof(uint32_t) * (size_t)ns));
@@ -609,11 +597,10 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     // ---- PLOC ----
     if (split) hipLaunchKernelGGL(k_leaves_refs, dim3(blocks(nl, 256)), dim3(256), 0, s, a, nl);
     else hipLaunchKernelGGL(k_leaves, dim3(blocks(nl, 256)), dim3(256), 0, s, a, nl);
-    B_TRY(hipMemsetAsync(a.node_visit, 0, sizeof(uint32_t) * 2 * (size_t)ns, s));
     m = nl; node_base = nl;
     {
         uint32_t *cl_in = a.cl_a, *cl_out = cl_b;
-        h.m_cur = m; h.node_base = node_base; h.m_next = m; h.merges = 0u;
+        h.m_cur = m; h.node_base = node_base; h.m_next = m; h.merges = 0u; h.round_idx = 0u;
         B_TRY(hipMemcpyAsync(a.counters, &h, sizeof h, hipMemcpyHostToDevice, s));
         // A round merges at least one pair, typically 40 % of the clusters.  The host launches kRoundsPerBatch rounds over the
         // cluster count it last read (a round past the end of the build copies the clusters left) and only then synchronises:
@@ -633,6 +620,7 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
             B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
             B_TRY(hipStreamSynchronize(s));
             if (h.m_cur >= m) { res.error = hipErrorUnknown; res.where = "PLOC made no progress"; goto done; }
+            for (int k = 0; k < kRoundsPerBatch; ++k) round_end.push_back(h.round_base[k]);
             m = h.m_cur;
         }
         if (m != n_cells) { res.error = hipErrorUnknown; res.where = "PLOC left fewer clusters than cells"; goto done; }
@@ -648,8 +636,17 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
             B_TRY(hipStreamSynchronize(s));
         }
     }
-    // ---- cost tables ----
-    hipLaunchKernelGGL(k_cost, dim3(blocks(nl, 256)), dim3(256), 0, s, a, nl);
+    // ---- cost tables: leaves, PLOC's rounds in order, the top-down phase's levels from the deepest up ----
+    hipLaunchKernelGGL(k_cost_range, dim3(blocks(nl, 256)), dim3(256), 0, s, a, 0u, nl, 1u);
+    {
+        uint32_t prev = nl;
+        for (uint32_t e : round_end) { if (e > prev) hipLaunchKernelGGL(k_cost_range, dim3(blocks(e - prev, 256)), dim3(256), 0, s, a, prev, e - prev, 0u); prev = e; }
+        if (split && sp.n_top)
+            for (size_t l = sp.top_level_begin.size() - 1; l-- > 0;) {
+                const uint32_t b0 = sp.top_level_begin[l], cnt = sp.top_level_begin[l + 1] - b0;
+                if (cnt) hipLaunchKernelGGL(k_cost_range, dim3(blocks(cnt, 256)), dim3(256), 0, s, a, node_base + b0, cnt, 0u);
+            }
+    }
     B_TRY(hipGetLastError());
     // ---- emission, level by level ----
     {

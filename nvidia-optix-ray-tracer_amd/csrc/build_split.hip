@@ -8,22 +8,25 @@
 // (build.hip), which builds the subtree of every cell bottom-up and never merges across a cell boundary.  The segments that were split
 // become the top of the BVH2.
 //
-// One level = seven launches over the references still in play (retired cells are copied out once):
-//   bins      per 2048-reference chunk of a segment: 16 object bins + 32 spatial bins x 3 axes in LDS (ordered-integer min / max,
-//             so the result does not depend on the order of arrival), then one flush per chunk;
-//   select    8 lanes per segment sweep the bins (a segment of one chunk: the lanes of the workgroup that binned it, the bins never
-//             leave the LDS): object split, spatial split or "leave it to PLOC";
+// One level = a dozen short launches over the references still in play (retired cells are copied out once); a wave per 512-reference
+// chunk of a segment, so the many small segments of the deep levels cost a wave each and no barrier:
+//   bins      16 object bins + 32 spatial bins x 3 axes in LDS (ordered-integer min / max, so the result does not depend on the
+//             order of arrival), then one flush per chunk -- or none: a segment of one chunk is decided by the wave that binned it;
+//   select    the wave's lanes each evaluate one candidate plane (45 object, 93 spatial), argmin by shuffles: object split,
+//             spatial split or "leave it to PLOC";
 //   flags     per reference: left, right or both (a straddler stays whole on one side when that is cheaper: unsplitting);
 //   scan      hipCUB exclusive sum of (left << 32 | right): positions come from prefix sums, so the order of the references -- and
 //             with it the tree -- is the same in every run;
-//   plan      one workgroup: child segments, budgets, the next level's chunk list, cell / top-node numbers, all by block scans;
+//   plan      per segment: the children's sizes; three more exclusive sums give child segments, budgets, the next level's chunk
+//             list, cell / top-node numbers;
 //   scatter   cut the straddlers (the triangle clipped to the child's box: bvh8_geom.h, the host's arithmetic), write the children,
-//             reduce their bounds per workgroup.
+//             reduce their bounds per wave.
 // HBM-bound integer / min-max work; nothing here is GEMM-shaped.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <algorithm>
 #include "build_dev.h"
 
@@ -40,25 +43,33 @@ BuildArena::~BuildArena() { for (void *p : owned) (void)hipFree(p); }
 
 namespace {
 
-constexpr int kObjBins = 16, kSpBins = 32;
+#ifndef HRT_SPLIT_OBJ_BINS
+#define HRT_SPLIT_OBJ_BINS 16
+#endif
+#ifndef HRT_SPLIT_SP_BINS
+#define HRT_SPLIT_SP_BINS 32
+#endif
+constexpr int kObjBins = HRT_SPLIT_OBJ_BINS, kSpBins = HRT_SPLIT_SP_BINS;      // (experiments: make EXTRA_HIPFLAGS=-DHRT_SPLIT_OBJ_BINS=32)
 constexpr int kObjBox = 0, kSpBox = 3 * kObjBins * 6;                                  // boxes: 6 words per bin (lo as f2ord(x), hi as f2ord(-x))
 constexpr int kBinMinMax = kSpBox + 3 * kSpBins * 6;                                   // 864 words that shrink under atomicMin (identity ~0)
 constexpr int kObjCnt = kBinMinMax, kSpEnter = kObjCnt + 3 * kObjBins, kSpLeave = kSpEnter + 3 * kSpBins;
 constexpr int kBinWords = kSpLeave + 3 * kSpBins;                                      // 1104 words per segment
-constexpr uint32_t kChunk = 2048u, kMaxLevels = 64u;
+constexpr uint32_t kChunk = 512u, kMaxLevels = 64u, kWave = 64u;
 
-struct SplitCounters { uint32_t n_act, n_chunks, src_total, n_cells, n_top, n_out, n_segs, gave_up, n_big; };
+struct SplitCounters { uint32_t n_act, n_chunks, src_total, n_cells, n_top, n_out, n_segs, gave_up, n_big, retry; };
 
 struct SplitArgs {
     GpuBuildArgs b;                                  // instance tables (the scatter clips triangles), primitive bounds, scene counters
     SplitSeg *segs; uint32_t seg_cap;
     uint32_t *act, *act_next;                        // segments of this level / the next
-    uint32_t *chunk_act, *chunk_off, *chunk_act_next, *chunk_off_next;       // chunk -> (position in act, offset within the segment)
+    uint32_t *chunk_act, *chunk_off, *chunk_act_next, *chunk_off_next;       // chunk -> (segment, offset within the segment)
     float4 *src_lo, *src_hi, *dst_lo, *dst_hi, *out_lo, *out_hi;
     uint32_t *bins; uint64_t *flags, *scan;
+    uint64_t *plan_in[3], *plan_ex[3];               // per segment of the level: (splits | cells), (references out | to the children), (chunks | big children) and their exclusive sums
     uint32_t *top_seg, *cell_seg;
     SplitCounters *counters;
     uint32_t n_act, n_chunks, cell_refs, level;
+    uint32_t seg_base, cell_base, top_base, out_base;       // the running totals before this level (the host's copy of the counters)
     float pad, alpha_area, bias;
 };
 
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(256) void k_split_first_level(SplitArgs a, uint32_t
     *a.counters = sc;
 }
 
-__device__ __forceinline__ void select_split(const SplitArgs &a, SplitSeg &sg, const uint32_t *g, uint32_t role, bool live);
+__device__ __forceinline__ void select_split(const SplitArgs &a, SplitSeg &sg, const uint32_t *g, uint32_t lane);
 
 // ---- bins ----
 __global__ __launch_bounds__(256) void k_split_init_bins(uint32_t *bins, uint32_t n_words) {
@@ -117,19 +128,19 @@ __global__ __launch_bounds__(256) void k_split_init_bins(uint32_t *bins, uint32_
     if (i < n_words) bins[i] = (i % (uint32_t)kBinWords) < (uint32_t)kBinMinMax ? 0xffffffffu : 0u;
 }
 
-__global__ __launch_bounds__(256) void k_split_bin(SplitArgs a) {
+__global__ __launch_bounds__(64) void k_split_bin(SplitArgs a) {
     __shared__ uint32_t s_bins[kBinWords];
     const uint32_t ai = a.chunk_act[blockIdx.x], off = a.chunk_off[blockIdx.x];
-    const SplitSeg &sg = a.segs[a.act[ai]];
+    const SplitSeg &sg = a.segs[ai];
     const uint32_t cnt = sg.count, first = sg.first;
     if (cnt < a.cell_refs || sg.level >= kMaxLevels) return;       // a cell: nothing to decide (the same for the whole workgroup)
-    for (uint32_t w = threadIdx.x; w < (uint32_t)kBinWords; w += 256u) s_bins[w] = w < (uint32_t)kBinMinMax ? 0xffffffffu : 0u;
+    for (uint32_t w = threadIdx.x; w < (uint32_t)kBinWords; w += kWave) s_bins[w] = w < (uint32_t)kBinMinMax ? 0xffffffffu : 0u;
     float nlo[3], nhi[3], clo[3], chi[3];
     seg_bounds(sg.nb, nlo, nhi); seg_bounds(sg.cb, clo, chi);
     const bool spatial = sg.budget > 0u;
     __syncthreads();
     const uint32_t end = off + kChunk < cnt ? off + kChunk : cnt;
-    for (uint32_t j = off + threadIdx.x; j < end; j += 256u) {
+    for (uint32_t j = off + threadIdx.x; j < end; j += kWave) {
         const float4 l4 = a.src_lo[first + j], h4 = a.src_hi[first + j];
         const float rl[3] = {l4.x, l4.y, l4.z}, rh[3] = {h4.x, h4.y, h4.z};
         for (int ax = 0; ax < 3; ++ax) {
@@ -161,125 +172,110 @@ __global__ __launch_bounds__(256) void k_split_bin(SplitArgs a) {
         }
     }
     __syncthreads();
-    if (cnt <= kChunk) {       // the whole segment was this workgroup's: decide here, the bins never leave the LDS
-        if (threadIdx.x < 8u) select_split(a, a.segs[a.act[ai]], s_bins, threadIdx.x, true);
-        return;
-    }
+    if (cnt <= kChunk) { select_split(a, a.segs[ai], s_bins, threadIdx.x); return; }      // the whole segment was this wave's: decide here, the bins never leave the LDS
     uint32_t *g = a.bins + (size_t)sg.bins_slot * kBinWords;
-    for (uint32_t w = threadIdx.x; w < (uint32_t)kBinWords; w += 256u) {
+    for (uint32_t w = threadIdx.x; w < (uint32_t)kBinWords; w += kWave) {
         const uint32_t v = s_bins[w];
         if (w < (uint32_t)kBinMinMax) { if (v != 0xffffffffu) atomicMin(&g[w], v); } else if (v) atomicAdd(&g[w], v);
     }
 }
 
-// ---- select: eight lanes per segment; lanes 0..2 sweep the object bins of an axis, lanes 3..5 the spatial bins ----
+// ---- select: a wave per segment, a candidate plane per lane ----
 __device__ __forceinline__ bool bin_box(const uint32_t *w, float *b) {
     if (w[0] == 0xffffffffu) return false;
     for (int c = 0; c < 3; ++c) { b[c] = ord2f(w[c]); b[3 + c] = -ord2f(w[3 + c]); }
     return true;
 }
+// the cheapest candidate of the wave; equal costs: the lowest candidate number (the host's loops keep the first of equals)
+__device__ __forceinline__ void wave_argmin(float &cost, uint32_t &idx) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const float oc = __shfl_xor(cost, off); const uint32_t oi = __shfl_xor(idx, off);
+        if (oc < cost || (oc == cost && oi < idx)) { cost = oc; idx = oi; }
+    }
+}
 
-// (eight consecutive lanes of a wave call this together: `role` = lane & 7; g = the segment's bins, in LDS or in memory)
-__device__ __forceinline__ void select_split(const SplitArgs &a, SplitSeg &sg, const uint32_t *g, uint32_t role, bool live) {
+// (all 64 lanes of a wave call this together; g = the segment's bins, in LDS or in memory)
+__device__ __forceinline__ void select_split(const SplitArgs &a, SplitSeg &sg, const uint32_t *g, uint32_t lane) {
     const uint32_t cnt = sg.count;
-    const bool decide = live && cnt >= a.cell_refs && sg.level < kMaxLevels;
+    if (cnt < a.cell_refs || sg.level >= kMaxLevels) { if (lane == 0u) sg.kind = 1u; return; }
     const float pad = a.pad;
     float nlo[3], nhi[3], clo[3], chi[3];
     seg_bounds(sg.nb, nlo, nhi); seg_bounds(sg.cb, clo, chi);
-
-    float cost = INFINITY, bl[6], br[6], pos = 0.0f; int bk = -1; uint32_t n_l = 0u, n_r = 0u;
-    box_reset(bl); box_reset(br);
-    if (decide && role < 3u) {
-        const int ax = (int)role;
-        if (chi[ax] - clo[ax] > 0.0f) {
-            float rb[kObjBins][6]; uint32_t rc[kObjBins];
-            float acc[6]; box_reset(acc); uint32_t n = 0u;
-            for (int k = kObjBins - 1; k > 0; --k) {
-                n += g[kObjCnt + ax * kObjBins + k];
-                float b[6]; if (bin_box(g + kObjBox + (ax * kObjBins + k) * 6, b)) box_grow(acc, b);
-                for (int c = 0; c < 6; ++c) rb[k][c] = acc[c];
-                rc[k] = n;
-            }
-            box_reset(acc); n = 0u;
-            for (int k = 0; k < kObjBins - 1; ++k) {
-                n += g[kObjCnt + ax * kObjBins + k];
-                float b[6]; if (bin_box(g + kObjBox + (ax * kObjBins + k) * 6, b)) box_grow(acc, b);
-                if (n == 0u || rc[k + 1] == 0u) continue;
-                const float v = padded_area(acc, pad) * (float)n + padded_area(rb[k + 1], pad) * (float)rc[k + 1];
-                if (v < cost) { cost = v; bk = k; n_l = n; n_r = rc[k + 1]; for (int c = 0; c < 6; ++c) { bl[c] = acc[c]; br[c] = rb[k + 1][c]; } }
-            }
+    // ---- object split: candidate c = (axis, k): bins 0..k of the axis go left ----
+    float o_cost = INFINITY, o_l[6], o_r[6]; uint32_t o_idx = 0xffffffffu, o_nl = 0u, o_nr = 0u;
+    for (uint32_t c = lane; c < 3u * (uint32_t)(kObjBins - 1); c += kWave) {
+        const int ax = (int)(c / (uint32_t)(kObjBins - 1)), k = (int)(c % (uint32_t)(kObjBins - 1));
+        if (!(chi[ax] - clo[ax] > 0.0f)) continue;
+        float l[6], r[6]; box_reset(l); box_reset(r); uint32_t nl = 0u, nr = 0u;
+        for (int j = 0; j < kObjBins; ++j) {
+            const uint32_t cj = g[kObjCnt + ax * kObjBins + j];
+            float b[6]; const bool has = bin_box(g + kObjBox + (ax * kObjBins + j) * 6, b);
+            if (j <= k) { nl += cj; if (has) box_grow(l, b); } else { nr += cj; if (has) box_grow(r, b); }
         }
-    } else if (decide && role < 6u && sg.budget > 0u) {
-        const int ax = (int)role - 3;
-        const float lo_a = nlo[ax], ext = nhi[ax] - nlo[ax];
-        if (ext > 0.0f) {
-            const float width = ext / (float)kSpBins;
-            float rb[kSpBins][6]; uint32_t rc[kSpBins]; bool rv[kSpBins];
-            float acc[6]; box_reset(acc); uint32_t n = 0u; bool any = false;
-            for (int k = kSpBins - 1; k > 0; --k) {
-                n += g[kSpLeave + ax * kSpBins + k];
-                float b[6]; if (bin_box(g + kSpBox + (ax * kSpBins + k) * 6, b)) { box_grow(acc, b); any = true; }
-                for (int c = 0; c < 6; ++c) rb[k][c] = acc[c];
-                rc[k] = n; rv[k] = any;
-            }
-            box_reset(acc); n = 0u; any = false;
-            for (int k = 0; k < kSpBins - 1; ++k) {
-                n += g[kSpEnter + ax * kSpBins + k];
-                float b[6]; if (bin_box(g + kSpBox + (ax * kSpBins + k) * 6, b)) { box_grow(acc, b); any = true; }
-                if (n == 0u || rc[k + 1] == 0u || !any || !rv[k + 1]) continue;
-                const float v = padded_area(acc, pad) * (float)n + padded_area(rb[k + 1], pad) * (float)rc[k + 1];
-                if (v < cost && (n < cnt || rc[k + 1] < cnt)) {
-                    cost = v; bk = k; pos = lo_a + width * (float)(k + 1); n_l = n; n_r = rc[k + 1];
-                    for (int c = 0; c < 6; ++c) { bl[c] = acc[c]; br[c] = rb[k + 1][c]; }
-                }
-            }
-        }
+        if (nl == 0u || nr == 0u) continue;
+        const float v = padded_area(l, pad) * (float)nl + padded_area(r, pad) * (float)nr;
+        if (v < o_cost) { o_cost = v; o_idx = c; o_nl = nl; o_nr = nr; for (int q = 0; q < 6; ++q) { o_l[q] = l[q]; o_r[q] = r[q]; } }
     }
-    // the group's best object split and best spatial split (the lowest axis wins ties, as the host's loops do)
-    const int lane = (int)(threadIdx.x & 63u), g0 = lane & ~7;
-    int ow = -1, sw = -1; float oc = INFINITY, sc = INFINITY;
-    for (int r = 0; r < 3; ++r) {
-        const float c1 = __shfl(cost, g0 + r), c2 = __shfl(cost, g0 + 3 + r);
-        if (c1 < oc) { oc = c1; ow = r; }
-        if (c2 < sc) { sc = c2; sw = 3 + r; }
-    }
+    float oc = o_cost; uint32_t ow = o_idx;
+    wave_argmin(oc, ow);
+    const bool obj_ok = ow != 0xffffffffu, i_am_obj = obj_ok && o_idx == ow;
     // spatial splits are worth trying when there is no object split or its children overlap by more than alpha of the scene's area
     // (the object split's boxes as the host takes them: padded)
-    int my_try = 0;
-    if ((int)role == ow) {
+    bool my_try = false;
+    if (i_am_obj) {
         float il[3], ih[3]; bool overlap = true;
         for (int c = 0; c < 3; ++c) {
-            il[c] = fmaxf(bl[c] - pad, br[c] - pad); ih[c] = fminf(bl[3 + c] + pad, br[3 + c] + pad);
+            il[c] = fmaxf(o_l[c] - pad, o_r[c] - pad); ih[c] = fminf(o_l[3 + c] + pad, o_r[3 + c] + pad);
             if (!(il[c] < ih[c])) overlap = false;
         }
-        my_try = overlap && half_area3(il, ih) > a.alpha_area ? 1 : 0;
+        my_try = overlap && half_area3(il, ih) > a.alpha_area;
     }
-    const int try_sp = ow < 0 ? 1 : __shfl(my_try, g0 + (ow < 0 ? 0 : ow));
-    const uint32_t s_nl = __shfl(n_l, g0 + (sw < 0 ? 0 : sw)), s_nr = __shfl(n_r, g0 + (sw < 0 ? 0 : sw));
+    const bool try_sp = sg.budget > 0u && (!obj_ok || __ballot(my_try) != 0ull);
+    // ---- spatial split: candidate c = (axis, k): the plane between bins k and k + 1 ----
+    float s_cost = INFINITY, s_l[6], s_r[6], s_pos = 0.0f; uint32_t s_idx = 0xffffffffu, s_nl = 0u, s_nr = 0u;
+    if (try_sp)
+        for (uint32_t c = lane; c < 3u * (uint32_t)(kSpBins - 1); c += kWave) {
+            const int ax = (int)(c / (uint32_t)(kSpBins - 1)), k = (int)(c % (uint32_t)(kSpBins - 1));
+            const float lo_a = nlo[ax], ext = nhi[ax] - nlo[ax];
+            if (!(ext > 0.0f)) continue;
+            float l[6], r[6]; box_reset(l); box_reset(r); uint32_t nl = 0u, nr = 0u; bool hl = false, hr = false;
+            for (int j = 0; j < kSpBins; ++j) {
+                float b[6]; const bool has = bin_box(g + kSpBox + (ax * kSpBins + j) * 6, b);
+                if (j <= k) { nl += g[kSpEnter + ax * kSpBins + j]; if (has) { box_grow(l, b); hl = true; } }
+                else { nr += g[kSpLeave + ax * kSpBins + j]; if (has) { box_grow(r, b); hr = true; } }
+            }
+            if (nl == 0u || nr == 0u || !hl || !hr || !(nl < cnt || nr < cnt)) continue;
+            const float v = padded_area(l, pad) * (float)nl + padded_area(r, pad) * (float)nr;
+            if (v < s_cost) {
+                s_cost = v; s_idx = c; s_nl = nl; s_nr = nr; s_pos = lo_a + (ext / (float)kSpBins) * (float)(k + 1);
+                for (int q = 0; q < 6; ++q) { s_l[q] = l[q]; s_r[q] = r[q]; }
+            }
+        }
+    float sc = s_cost; uint32_t sw = s_idx;
+    wave_argmin(sc, sw);
+    const bool sp_found = sw != 0xffffffffu, i_am_sp = sp_found && s_idx == sw;
+    const unsigned long long sp_mask = __ballot(i_am_sp);
+    const int sp_lane = sp_mask ? __ffsll((long long)sp_mask) - 1 : 0;
+    const uint32_t w_nl = __shfl(s_nl, sp_lane), w_nr = __shfl(s_nr, sp_lane);
     uint32_t kind = 1u;                                            // a cell unless a split is found
-    if (decide) {
-        const bool sp_ok = sw >= 0 && try_sp && sc * a.bias < oc && (uint64_t)s_nl + s_nr - cnt <= (uint64_t)sg.budget;
-        if (sp_ok) kind = 3u; else if (ow >= 0) kind = 2u;
+    if (sp_found && sc * a.bias < oc && (uint64_t)w_nl + w_nr - cnt <= (uint64_t)sg.budget) kind = 3u;      // (oc is infinite without an object split)
+    else if (obj_ok) kind = 2u;
+    if (kind == 3u && i_am_sp) {
+        sg.axis = s_idx / (uint32_t)(kSpBins - 1); sg.bin = s_idx % (uint32_t)(kSpBins - 1); sg.c0 = s_pos; sg.scale = 0.0f; sg.nl = s_nl; sg.nr = s_nr;
+        for (int c = 0; c < 6; ++c) { sg.sl[c] = s_l[c]; sg.sr[c] = s_r[c]; }
     }
-    if (!live) return;
-    if (kind == 3u && (int)role == sw) {
-        sg.axis = role - 3u; sg.bin = (uint32_t)bk; sg.c0 = pos; sg.scale = 0.0f; sg.nl = n_l; sg.nr = n_r;
-        for (int c = 0; c < 6; ++c) { sg.sl[c] = bl[c]; sg.sr[c] = br[c]; }
+    if (kind == 2u && i_am_obj) {
+        const int ax = (int)(o_idx / (uint32_t)(kObjBins - 1));
+        sg.axis = (uint32_t)ax; sg.bin = o_idx % (uint32_t)(kObjBins - 1); sg.c0 = clo[ax]; sg.scale = (float)kObjBins / (chi[ax] - clo[ax]); sg.nl = o_nl; sg.nr = o_nr;
     }
-    if (kind == 2u && (int)role == ow) {
-        const int ax = (int)role;
-        sg.axis = role; sg.bin = (uint32_t)bk; sg.c0 = clo[ax]; sg.scale = (float)kObjBins / (chi[ax] - clo[ax]); sg.nl = n_l; sg.nr = n_r;
-    }
-    if (role == 7u) sg.kind = kind;
+    if (lane == 0u) sg.kind = kind;
 }
 
-// the segments of more than one chunk: their bins were flushed to memory (slot sg.bins_slot)
-__global__ __launch_bounds__(256) void k_split_select(SplitArgs a) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x, ai = t >> 3, role = t & 7u;
-    const bool in_range = ai < a.n_act;
-    SplitSeg &sg = a.segs[a.act[in_range ? ai : 0u]];
-    const bool live = in_range && sg.count > kChunk;
-    select_split(a, sg, a.bins + (size_t)(live ? sg.bins_slot : 0u) * kBinWords, role, live);
+// the segments of more than one chunk: their bins were flushed to memory (slot sg.bins_slot); a wave each
+__global__ __launch_bounds__(64) void k_split_select(SplitArgs a) {
+    SplitSeg &sg = a.segs[a.act[blockIdx.x]];
+    if (sg.count <= kChunk) return;
+    select_split(a, sg, a.bins + (size_t)sg.bins_slot * kBinWords, threadIdx.x);
 }
 
 // ---- flags: which side(s) a reference goes to ----
@@ -308,12 +304,12 @@ __device__ __forceinline__ uint64_t side_of(const SplitSeg &sg, const float *rl,
     return c_left <= c_right ? kLeft : kRight;
 }
 
-__global__ __launch_bounds__(256) void k_split_flags(SplitArgs a) {
+__global__ __launch_bounds__(64) void k_split_flags(SplitArgs a) {
     const uint32_t ai = a.chunk_act[blockIdx.x], off = a.chunk_off[blockIdx.x];
-    const SplitSeg &sg = a.segs[a.act[ai]];
+    const SplitSeg &sg = a.segs[ai];
     const uint32_t cnt = sg.count, first = sg.first, kind = sg.kind;
     const uint32_t end = off + kChunk < cnt ? off + kChunk : cnt;
-    for (uint32_t j = off + threadIdx.x; j < end; j += 256u) {
+    for (uint32_t j = off + threadIdx.x; j < end; j += kWave) {
         uint64_t f = 0ull;
         if (kind >= 2u) {
             const float4 l4 = a.src_lo[first + j], h4 = a.src_hi[first + j];
@@ -324,91 +320,82 @@ __global__ __launch_bounds__(256) void k_split_flags(SplitArgs a) {
     }
 }
 
-// ---- plan: one workgroup turns the level's decisions into child segments, budgets, output ranges and the next level's work list ----
-__global__ __launch_bounds__(1024) void k_split_plan(SplitArgs a) {
-    typedef hipcub::BlockScan<uint32_t, 1024> Scan;
-    __shared__ typename Scan::TempStorage tmp;
-    __shared__ uint32_t s_split, s_give_up;
+// ---- plan: the level's decisions become child segments, budgets, output ranges and the next level's work list ----
+// count: per segment, what it contributes to the six running totals (three packed pairs, scanned by hipCUB)
+__global__ __launch_bounds__(256) void k_split_plan_count(SplitArgs a) {
+    const uint32_t ai = blockIdx.x * 256u + threadIdx.x;
+    if (ai >= a.n_act) return;
+    SplitSeg &sg = a.segs[a.act[ai]];
+    if (sg.kind >= 2u) {       // the children's sizes from the scan; a split that does not separate anything is left to PLOC
+        const uint32_t last = sg.first + sg.count - 1u;
+        const uint64_t tot = a.scan[last] + a.flags[last] - a.scan[sg.first];
+        const uint32_t nl = (uint32_t)(tot >> 32), nr = (uint32_t)(tot & 0xffffffffull);
+        if (nl == 0u || nr == 0u || (nl >= sg.count && nr >= sg.count)) sg.kind = 1u; else { sg.nl = nl; sg.nr = nr; }
+    }
+    if (sg.kind < 2u) sg.kind = 1u;
+    const bool split = sg.kind >= 2u;
+    const uint64_t nl = split ? sg.nl : 0u, nr = split ? sg.nr : 0u;
+    a.plan_in[0][ai] = split ? 1ull << 32 : 1ull;                                        // splits | cells
+    a.plan_in[1][ai] = split ? nl + nr : (uint64_t)sg.count << 32;                       // references retired | references to the children
+    a.plan_in[2][ai] = split ? (((nl + kChunk - 1u) / kChunk + (nr + kChunk - 1u) / kChunk) << 32) | ((nl > kChunk ? 1u : 0u) + (nr > kChunk ? 1u : 0u)) : 0ull;   // chunks | big children
+}
+// (the segment tables are full: what is left of this level goes to PLOC as it is -- the host runs count / scan / apply again)
+__global__ __launch_bounds__(256) void k_split_force_cells(SplitArgs a) {
+    const uint32_t ai = blockIdx.x * 256u + threadIdx.x;
+    if (ai < a.n_act) a.segs[a.act[ai]].kind = 1u;
+    if (ai == 0u) { a.counters->retry = 0u; a.counters->gave_up = 1u; }
+}
+__global__ __launch_bounds__(256) void k_split_plan_apply(SplitArgs a) {
+    const uint32_t ai = blockIdx.x * 256u + threadIdx.x;
+    if (ai >= a.n_act) return;
     SplitCounters *cn = a.counters;
-    if (threadIdx.x == 0u) { s_split = 0u; s_give_up = 0u; }
-    __syncthreads();
-    // pass 1: the children's sizes from the scan; a split that does not separate anything is left to PLOC
-    for (uint32_t ai = threadIdx.x; ai < a.n_act; ai += 1024u) {
-        SplitSeg &sg = a.segs[a.act[ai]];
-        if (sg.kind >= 2u) {
-            const uint32_t last = sg.first + sg.count - 1u;
-            const uint64_t tot = a.scan[last] + a.flags[last] - a.scan[sg.first];
-            const uint32_t nl = (uint32_t)(tot >> 32), nr = (uint32_t)(tot & 0xffffffffull);
-            if (nl == 0u || nr == 0u || (nl >= sg.count && nr >= sg.count)) sg.kind = 1u;
-            else { sg.nl = nl; sg.nr = nr; atomicAdd(&s_split, 1u); }
-        }
-        if (sg.kind < 2u) sg.kind = 1u;
+    const uint32_t last = a.n_act - 1u;
+    const uint64_t t0 = a.plan_ex[0][last] + a.plan_in[0][last], t1 = a.plan_ex[1][last] + a.plan_in[1][last], t2 = a.plan_ex[2][last] + a.plan_in[2][last];
+    const uint32_t tot_split = (uint32_t)(t0 >> 32), tot_cells = (uint32_t)t0, tot_out = (uint32_t)(t1 >> 32), tot_dst = (uint32_t)t1;
+    const uint32_t seg_base = a.seg_base, cell_base = a.cell_base, top_base = a.top_base, out_base = a.out_base;
+    if ((uint64_t)seg_base + 2ull * tot_split > (uint64_t)a.seg_cap) { if (ai == 0u) cn->retry = 1u; return; }
+    const uint32_t id = a.act[ai];
+    SplitSeg *sg = &a.segs[id];
+    const uint64_t e0 = a.plan_ex[0][ai], e1 = a.plan_ex[1][ai], e2 = a.plan_ex[2][ai];
+    if (sg->kind < 2u) {
+        sg->out_first = out_base + (uint32_t)(e1 >> 32);
+        sg->index = cell_base + (uint32_t)e0;
+        a.cell_seg[sg->index] = id;
+    } else {
+        const uint32_t k = (uint32_t)(e0 >> 32), nl = sg->nl, nr = sg->nr;       // this level's k-th split
+        sg->index = top_base + k; a.top_seg[sg->index] = id;
+        sg->child = seg_base + 2u * k;
+        sg->out_first = (uint32_t)e1;
+        const uint32_t added = nl + nr - sg->count, rem = sg->budget > added ? sg->budget - added : 0u;
+        const uint32_t b_l = (uint32_t)((double)rem * (double)nl / (double)(nl + nr)), b_r = rem - b_l;
+        const uint32_t big0 = (uint32_t)e2;
+        SplitSeg c{};
+        c.kind = 0u; c.level = sg->level + 1u;
+        for (int q = 0; q < 6; ++q) { c.nb[q] = 0xffffffffu; c.cb[q] = 0xffffffffu; }
+        c.first = sg->out_first; c.count = nl; c.budget = b_l; c.bins_slot = big0; a.segs[sg->child] = c;
+        c.first = sg->out_first + nl; c.count = nr; c.budget = b_r; c.bins_slot = big0 + (nl > kChunk ? 1u : 0u); a.segs[sg->child + 1u] = c;
+        a.act_next[2u * k] = sg->child; a.act_next[2u * k + 1u] = sg->child + 1u;
+        uint32_t q = (uint32_t)(e2 >> 32);
+        for (uint32_t o = 0; o < nl; o += kChunk, ++q) { a.chunk_act_next[q] = sg->child; a.chunk_off_next[q] = o; }
+        for (uint32_t o = 0; o < nr; o += kChunk, ++q) { a.chunk_act_next[q] = sg->child + 1u; a.chunk_off_next[q] = o; }
     }
-    __syncthreads();
-    const uint32_t seg_base = cn->n_segs, cell_base = cn->n_cells, top_base = cn->n_top, out_base = cn->n_out;
-    if (threadIdx.x == 0u && (uint64_t)seg_base + 2ull * s_split > (uint64_t)a.seg_cap) s_give_up = 1u;      // the tables are full: everything left is a cell
-    __syncthreads();
-    const bool give_up = s_give_up != 0u;
-    uint32_t run_split = 0u, run_cells = 0u, run_out = 0u, run_dst = 0u, run_chunks = 0u, run_big = 0u;
-    for (uint32_t base = 0; base < a.n_act; base += 1024u) {
-        const uint32_t ai = base + threadIdx.x;
-        const bool live = ai < a.n_act;
-        const uint32_t id = live ? a.act[ai] : 0u;
-        SplitSeg *sg = live ? &a.segs[id] : nullptr;
-        if (live && give_up) sg->kind = 1u;
-        const bool split = live && sg->kind >= 2u, cell = live && !split;
-        const uint32_t nl = split ? sg->nl : 0u, nr = split ? sg->nr : 0u;
-        const uint32_t v_split = split ? 1u : 0u, v_cell = cell ? 1u : 0u, v_out = cell ? sg->count : 0u, v_dst = nl + nr;
-        const uint32_t v_chunks = split ? (nl + kChunk - 1u) / kChunk + (nr + kChunk - 1u) / kChunk : 0u;
-        const uint32_t v_big = (nl > kChunk ? 1u : 0u) + (nr > kChunk ? 1u : 0u);      // children whose bins go through memory
-        uint32_t e_split, e_cell, e_out, e_dst, e_chunks, e_big, t_split, t_cell, t_out, t_dst, t_chunks, t_big;
-        Scan(tmp).ExclusiveSum(v_split, e_split, t_split); __syncthreads();
-        Scan(tmp).ExclusiveSum(v_cell, e_cell, t_cell); __syncthreads();
-        Scan(tmp).ExclusiveSum(v_out, e_out, t_out); __syncthreads();
-        Scan(tmp).ExclusiveSum(v_dst, e_dst, t_dst); __syncthreads();
-        Scan(tmp).ExclusiveSum(v_chunks, e_chunks, t_chunks); __syncthreads();
-        Scan(tmp).ExclusiveSum(v_big, e_big, t_big); __syncthreads();
-        if (cell) {
-            sg->out_first = out_base + run_out + e_out;
-            sg->index = cell_base + run_cells + e_cell;
-            a.cell_seg[sg->index] = id;
-        }
-        if (split) {
-            const uint32_t k = run_split + e_split;                  // this level's k-th split
-            sg->index = top_base + k; a.top_seg[sg->index] = id;
-            sg->child = seg_base + 2u * k;
-            sg->out_first = run_dst + e_dst;
-            const uint32_t added = nl + nr - sg->count, rem = sg->budget > added ? sg->budget - added : 0u;
-            const uint32_t b_l = (uint32_t)((double)rem * (double)nl / (double)(nl + nr)), b_r = rem - b_l;
-            SplitSeg c{};
-            c.kind = 0u; c.level = sg->level + 1u;
-            for (int q = 0; q < 6; ++q) { c.nb[q] = 0xffffffffu; c.cb[q] = 0xffffffffu; }
-            c.first = sg->out_first; c.count = nl; c.budget = b_l; c.bins_slot = run_big + e_big; a.segs[sg->child] = c;
-            c.first = sg->out_first + nl; c.count = nr; c.budget = b_r; c.bins_slot = run_big + e_big + (nl > kChunk ? 1u : 0u); a.segs[sg->child + 1u] = c;
-            a.act_next[2u * k] = sg->child; a.act_next[2u * k + 1u] = sg->child + 1u;
-            uint32_t q = run_chunks + e_chunks;
-            for (uint32_t o = 0; o < nl; o += kChunk, ++q) { a.chunk_act_next[q] = 2u * k; a.chunk_off_next[q] = o; }
-            for (uint32_t o = 0; o < nr; o += kChunk, ++q) { a.chunk_act_next[q] = 2u * k + 1u; a.chunk_off_next[q] = o; }
-        }
-        run_split += t_split; run_cells += t_cell; run_out += t_out; run_dst += t_dst; run_chunks += t_chunks; run_big += t_big;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0u) {
-        cn->n_act = 2u * run_split; cn->n_chunks = run_chunks; cn->src_total = run_dst;
-        cn->n_cells = cell_base + run_cells; cn->n_top = top_base + run_split; cn->n_out = out_base + run_out;
-        cn->n_segs = seg_base + 2u * run_split; cn->gave_up |= give_up ? 1u : 0u; cn->n_big = run_big;
+    if (ai == 0u) {
+        cn->n_act = 2u * tot_split; cn->n_chunks = (uint32_t)(t2 >> 32); cn->src_total = tot_dst; cn->n_big = (uint32_t)t2;
+        cn->n_cells = cell_base + tot_cells; cn->n_top = top_base + tot_split; cn->n_out = out_base + tot_out;
+        cn->n_segs = seg_base + 2u * tot_split; cn->retry = 0u;
     }
 }
 
 // ---- scatter: retire the cells, write the children of the splits ----
-__global__ __launch_bounds__(256) void k_split_scatter(SplitArgs a) {
+__global__ __launch_bounds__(64) void k_split_scatter(SplitArgs a) {
+    if (a.counters->retry) return;                   // (the plan did not fit the tables: the host redoes it with cells only)
     const uint32_t ai = a.chunk_act[blockIdx.x], off = a.chunk_off[blockIdx.x];
-    const SplitSeg &sg = a.segs[a.act[ai]];
+    const SplitSeg &sg = a.segs[ai];
     const uint32_t cnt = sg.count, first = sg.first, kind = sg.kind;
     const uint32_t end = off + kChunk < cnt ? off + kChunk : cnt;
     if (kind < 2u) {
         const uint32_t cell = sg.index, out = sg.out_first;
-        for (uint32_t j = off + threadIdx.x; j < end; j += 256u) {
+        for (uint32_t j = off + threadIdx.x; j < end; j += kWave) {
             const float4 l4 = a.src_lo[first + j], h4 = a.src_hi[first + j];
             a.out_lo[out + j] = l4;
             a.out_hi[out + j] = make_float4(h4.x, h4.y, h4.z, __uint_as_float(cell));
@@ -416,12 +403,12 @@ __global__ __launch_bounds__(256) void k_split_scatter(SplitArgs a) {
         return;
     }
     const uint32_t c_l = sg.child, c_r = sg.child + 1u;
-    const uint32_t dst_l = a.segs[c_l].first, dst_r = a.segs[c_r].first;
+    const uint32_t dst_l = sg.out_first, dst_r = sg.out_first + sg.nl;      // (= the children's `first`)
     const uint64_t sc0 = a.scan[first];
     const int ax = (int)sg.axis; const float pos = sg.c0;
     float mn_l[6], mx_l[6], mn_r[6], mx_r[6];        // [0..2] box, [3..5] centroid
     for (int q = 0; q < 6; ++q) { mn_l[q] = mn_r[q] = INFINITY; mx_l[q] = mx_r[q] = -INFINITY; }
-    for (uint32_t j = off + threadIdx.x; j < end; j += 256u) {
+    for (uint32_t j = off + threadIdx.x; j < end; j += kWave) {
         const float4 l4 = a.src_lo[first + j], h4 = a.src_hi[first + j];
         const uint64_t f = a.flags[first + j], sc = a.scan[first + j] - sc0;
         const bool to_l = (f >> 32) != 0ull, to_r = (f & 1ull) != 0ull;
@@ -496,7 +483,7 @@ struct SplitSizes { uint32_t cap, cell_refs, act_cap, seg_cap, chunk_cap, big_ca
 SplitSizes split_sizes(uint32_t n, const SplitParams &sp) {
     SplitSizes z{};
     z.cap = gpu_build_max_refs(n, &sp);
-    z.cell_refs = std::max(sp.cell_refs, 8u);
+    z.cell_refs = std::max(sp.cell_refs, 2u);
     z.act_cap = 2u * (z.cap / z.cell_refs) + 2u;      // at most cap / cell_refs segments are split on a level, so a level has at most twice as many segments
     z.seg_cap = (uint32_t)std::min<uint64_t>(4ull * z.act_cap + 64u, 1u << 31);       // (twice what balanced splits make; when it runs out, what is left goes to PLOC as it is)
     z.big_cap = z.cap / kChunk + 2u;                  // segments of more than one chunk on a level: their bins go through memory
@@ -507,7 +494,7 @@ SplitSizes split_sizes(uint32_t n, const SplitParams &sp) {
 
 size_t gpu_split_table_bytes(uint32_t n_prims, const SplitParams &sp) {
     const SplitSizes z = split_sizes(n_prims, sp);
-    return (size_t)z.seg_cap * (sizeof(SplitSeg) + 8u) + (size_t)z.big_cap * sizeof(uint32_t) * kBinWords + (size_t)z.act_cap * 8u + (size_t)z.chunk_cap * 16u + (1u << 20);
+    return (size_t)z.seg_cap * (sizeof(SplitSeg) + 8u) + (size_t)z.big_cap * sizeof(uint32_t) * kBinWords + (size_t)z.act_cap * (8u + 48u) + (size_t)z.chunk_cap * 16u + (1u << 20);
 }
 
 SplitPhaseResult gpu_split_phase(const GpuBuildArgs &b, uint32_t n_valid, const SplitParams &sp, BuildArena &arena, hipStream_t s) {
@@ -531,8 +518,9 @@ SplitPhaseResult gpu_split_phase(const GpuBuildArgs &b, uint32_t n_valid, const 
         S_TRY(arena.alloc((void **)&act[q], sizeof(uint32_t) * (size_t)act_cap));
         S_TRY(arena.alloc((void **)&ch_act[q], sizeof(uint32_t) * (size_t)chunk_cap)); S_TRY(arena.alloc((void **)&ch_off[q], sizeof(uint32_t) * (size_t)chunk_cap));
     }
+    for (int q = 0; q < 3; ++q) { S_TRY(arena.alloc((void **)&a.plan_in[q], sizeof(uint64_t) * (size_t)act_cap)); S_TRY(arena.alloc((void **)&a.plan_ex[q], sizeof(uint64_t) * (size_t)act_cap)); }
     S_TRY(arena.alloc((void **)&a.counters, sizeof(SplitCounters)));
-    S_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, a.flags, a.scan, (int)std::max(cap, b.n), s));
+    S_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, a.flags, a.scan, (int)(std::max(cap, b.n) + 4096u), s));      // (also the plan's scans over a level's segments: at most cap + 2)
     S_TRY(arena.alloc(&temp, scan_bytes));
 
     {   // the scene's area for the alpha test: the host takes the unpadded box of all primitives
@@ -556,21 +544,35 @@ SplitPhaseResult gpu_split_phase(const GpuBuildArgs &b, uint32_t n_valid, const 
     S_TRY(hipGetLastError());
     uint32_t src_total = n_valid, n_big = n_valid > kChunk ? 1u : 0u;
     SplitCounters h{};
+    h.n_segs = 1u;
+    uint32_t seg_cap_now = seg_cap;
+    if (const char *e = std::getenv("HRT_SBVH_SEG_CAP")) { const unsigned long v = std::strtoul(e, nullptr, 10); if (v >= 1 && v < seg_cap) seg_cap_now = (uint32_t)v; }      // (tests: the tables-are-full path)
+    a.seg_cap = seg_cap_now;
+    res.top_level_begin.push_back(0u);
     for (;;) {
+        a.seg_base = h.n_segs; a.cell_base = h.n_cells; a.top_base = h.n_top; a.out_base = h.n_out;
         if (n_big) hipLaunchKernelGGL(k_split_init_bins, dim3(blocks(n_big * (uint32_t)kBinWords, 256)), dim3(256), 0, s, a.bins, n_big * (uint32_t)kBinWords);
-        hipLaunchKernelGGL(k_split_bin, dim3(a.n_chunks), dim3(256), 0, s, a);
-        if (n_big) hipLaunchKernelGGL(k_split_select, dim3(blocks(a.n_act * 8u, 256)), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_split_flags, dim3(a.n_chunks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_split_bin, dim3(a.n_chunks), dim3(kWave), 0, s, a);
+        if (n_big) hipLaunchKernelGGL(k_split_select, dim3(a.n_act), dim3(kWave), 0, s, a);
+        hipLaunchKernelGGL(k_split_flags, dim3(a.n_chunks), dim3(kWave), 0, s, a);
         S_TRY(hipcub::DeviceScan::ExclusiveSum(temp, scan_bytes, a.flags, a.scan, (int)src_total, s));
-        hipLaunchKernelGGL(k_split_plan, dim3(1), dim3(1024), 0, s, a);
-        hipLaunchKernelGGL(k_split_scatter, dim3(a.n_chunks), dim3(256), 0, s, a);
-        S_TRY(hipGetLastError());
-        S_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
-        S_TRY(hipStreamSynchronize(s));
+        for (int pass = 0; pass < 2; ++pass) {
+            hipLaunchKernelGGL(k_split_plan_count, dim3(blocks(a.n_act, 256)), dim3(256), 0, s, a);
+            for (int q = 0; q < 3; ++q) S_TRY(hipcub::DeviceScan::ExclusiveSum(temp, scan_bytes, a.plan_in[q], a.plan_ex[q], (int)a.n_act, s));
+            hipLaunchKernelGGL(k_split_plan_apply, dim3(blocks(a.n_act, 256)), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(k_split_scatter, dim3(a.n_chunks), dim3(kWave), 0, s, a);
+            S_TRY(hipGetLastError());
+            S_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
+            S_TRY(hipStreamSynchronize(s));
+            if (!h.retry) break;
+            if (pass == 1) { res.error = hipErrorUnknown; res.where = "split phase: the plan did not fit twice"; return res; }
+            hipLaunchKernelGGL(k_split_force_cells, dim3(blocks(a.n_act, 256)), dim3(256), 0, s, a);      // the segment tables are full: the rest is PLOC's
+        }
         if (sp.verbose)
-            std::fprintf(stderr, "[hrt] split level %u: %u segments (%u references) -> %u children (%u references), %u cells so far (%u references)\n",
-                         a.level, a.n_act, src_total, h.n_act, h.src_total, h.n_cells, h.n_out);
+            std::fprintf(stderr, "[hrt] split level %u: %u segments (%u references) -> %u children (%u references), %u cells so far (%u references)%s\n",
+                         a.level, a.n_act, src_total, h.n_act, h.src_total, h.n_cells, h.n_out, h.gave_up ? " [segment table full]" : "");
         ++res.levels;
+        res.top_level_begin.push_back(h.n_top);
         if (h.n_act == 0u) break;
         if (h.n_act > act_cap || h.n_chunks > chunk_cap || h.src_total > cap || h.n_big > z.big_cap || a.level > 2u * kMaxLevels) { res.error = hipErrorUnknown; res.where = "split phase: a level outgrew its tables"; return res; }
         src ^= 1;

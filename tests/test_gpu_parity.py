@@ -1206,6 +1206,25 @@ def test_fast_trace_tree_with_spatial_splits(hrt, oracle, gpu_available, monkeyp
         r.close()
 
 
+def test_device_split_build_with_full_segment_tables(hrt, oracle, gpu_available, monkeypatch):
+    """The top-down phase keeps its segments in tables sized for twice what balanced splits make.  When they fill up (here: forced,
+    HRT_SBVH_SEG_CAP) the level is planned again with every segment left as a cell, and PLOC builds the rest -- cells of thousands of
+    references instead of a handful.  Same hits, same image."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    monkeypatch.setenv("HRT_SBVH_SEG_CAP", "40")
+    r = hrt.Renderer(0, hrt.CTX_FAST_TRACE)
+    try:
+        w, h, spp = 128, 80, 2
+        scene = hrt.scenes.random_soup(30000, 0.08, 12, w, h, spp)
+        r.load_scene(scene)
+        _moved_scene_matches_oracle(hrt, oracle, r, scene, w, h, 6, spp)
+        nodes, prims = _download_tree(hrt, r)
+        assert prims.size > 30000 * 48          # the first levels did split references
+    finally:
+        r.close()
+
+
 def test_device_split_build_is_deterministic_and_fast(hrt, gpu_available):
     """The device build with spatial splits takes its positions from prefix sums and its bounds from ordered-integer min / max: two
     builds of the same scene give the same tree (the same nodes and records, up to the order of the blocks they are stored in).  1 M triangles build in well under a second (measured: ~45 ms
