@@ -517,7 +517,7 @@ hipError_t gpu_blas_bounds(const float *d_src, uint32_t n_prims, uint32_t kind, 
 size_t gpu_build_scratch_bytes(uint32_t n_prims, const SplitParams *split) {
     if (!split || !split->enabled) return (size_t)n_prims * 340u + (1u << 20);
     const size_t cap = gpu_build_max_refs(n_prims, split), tables = gpu_split_table_bytes(n_prims, *split);
-    const size_t phase = cap * 64u + std::max<size_t>(cap, n_prims) * 16u, after = cap * 348u;
+    const size_t phase = cap * 64u + std::max<size_t>(cap, n_prims) * 16u + (cap - n_prims + 4096u) * 56u, after = cap * 348u;
     return (size_t)n_prims * 32u + cap * 32u + tables + std::max(phase, after) + (4u << 20);
 }
 

@@ -19,8 +19,9 @@
 //             with it the tree -- is the same in every run;
 //   plan      per segment: the children's sizes; three more exclusive sums give child segments, budgets, the next level's chunk
 //             list, cell / top-node numbers;
-//   scatter   cut the straddlers (the triangle clipped to the child's box: bvh8_geom.h, the host's arithmetic), write the children,
-//             reduce their bounds per wave.
+//   clip      the references that are cut, compacted: the triangle clipped to each child's box (bvh8_geom.h, the host's arithmetic:
+//             Sutherland-Hodgman in double -- slow code, so every lane of the waves that run it has work);
+//   scatter   write the children, reduce their bounds per wave.
 // HBM-bound integer / min-max work; nothing here is GEMM-shaped.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -56,7 +57,7 @@ constexpr int kObjCnt = kBinMinMax, kSpEnter = kObjCnt + 3 * kObjBins, kSpLeave 
 constexpr int kBinWords = kSpLeave + 3 * kSpBins;                                      // 1104 words per segment
 constexpr uint32_t kChunk = 512u, kMaxLevels = 64u, kWave = 64u;
 
-struct SplitCounters { uint32_t n_act, n_chunks, src_total, n_cells, n_top, n_out, n_segs, gave_up, n_big, retry; };
+struct SplitCounters { uint32_t n_act, n_chunks, src_total, n_cells, n_top, n_out, n_segs, gave_up, n_big, retry, n_cut; };
 
 struct SplitArgs {
     GpuBuildArgs b;                                  // instance tables (the scatter clips triangles), primitive bounds, scene counters
@@ -67,6 +68,7 @@ struct SplitArgs {
     uint32_t *bins; uint64_t *flags, *scan;
     uint64_t *plan_in[3], *plan_ex[3];               // per segment of the level: (splits | cells), (references out | to the children), (chunks | big children) and their exclusive sums
     uint32_t *top_seg, *cell_seg;
+    uint2 *cut_list; float *cut_box; uint32_t cut_cap;      // the level's straddlers that are cut: (reference, segment) and the two clipped boxes, 12 floats
     SplitCounters *counters;
     uint32_t n_act, n_chunks, cell_refs, level;
     uint32_t seg_base, cell_base, top_base, out_base;       // the running totals before this level (the host's copy of the counters)
@@ -316,7 +318,51 @@ __global__ __launch_bounds__(64) void k_split_flags(SplitArgs a) {
             const float rl[3] = {l4.x, l4.y, l4.z}, rh[3] = {h4.x, h4.y, h4.z};
             f = side_of(sg, rl, rh);
         }
+        // cut: the clipping is a kernel of its own over these (every lane busy); slots from one atomic per wave, the slot rides in the reference
+        const bool cut = f == ((1ull << 32) | 1ull);
+        const unsigned long long cut_mask = __ballot(cut);
+        if (cut_mask) {
+            const int leader = __ffsll((long long)cut_mask) - 1;
+            uint32_t base = 0u;
+            if ((int)threadIdx.x == leader) base = atomicAdd(&a.counters->n_cut, (uint32_t)__popcll(cut_mask));
+            base = __shfl(base, leader);
+            if (cut) {
+                const uint32_t slot = base + (uint32_t)__popcll(cut_mask & ((1ull << threadIdx.x) - 1ull));
+                if (slot < a.cut_cap) { a.cut_list[slot] = make_uint2(first + j, ai); a.src_hi[first + j].w = __uint_as_float(slot); }
+                else f = 1ull << 32;                   // (no room: the reference stays whole)
+            }
+        }
         a.flags[first + j] = f;
+    }
+}
+
+// ---- clip: the two boxes of every reference that is cut (Sutherland-Hodgman in double: slow code, so it runs with all lanes busy) ----
+__global__ __launch_bounds__(64) void k_split_clip(SplitArgs a) {
+    const uint32_t n = a.counters->n_cut < a.cut_cap ? a.counters->n_cut : a.cut_cap;
+    for (uint32_t slot = blockIdx.x * kWave + threadIdx.x; slot < n; slot += gridDim.x * kWave) {
+        const uint2 e = a.cut_list[slot];
+        const SplitSeg &sg = a.segs[e.y];
+        const float4 l4 = a.src_lo[e.x], h4 = a.src_hi[e.x];
+        const int ax = (int)sg.axis; const float pos = sg.c0;
+        float blo[3] = {l4.x, l4.y, l4.z}, bhi[3] = {h4.x, h4.y, h4.z}, ll[3], lh[3], rl[3], rh[3];
+        const uint32_t k = __float_as_uint(l4.w);
+        const uint32_t inst = find_instance(a.b.inst_first, a.b.n_inst, k), p = k - a.b.inst_first[inst];
+        const bool tri = a.b.inst_kind[inst] == kPrimKindTriangle;
+        float v0[3] = {0, 0, 0}, e1[3] = {0, 0, 0}, e2[3] = {0, 0, 0};
+        if (tri) {
+            const float *src = reinterpret_cast<const float *>(a.b.inst_src[inst]) + 9 * (size_t)p;
+            float s9[9], tlo[3], thi[3];
+            for (int q = 0; q < 9; ++q) s9[q] = src[q];
+            triangle_world(s9, a.b.inst_xf + 12 * (size_t)inst, a.b.inst_identity[inst] != 0u, v0, e1, e2, tlo, thi);
+        }
+        const float whole_hi = bhi[ax];
+        bhi[ax] = fminf(bhi[ax], pos);
+        if (tri) clip_triangle_to_box(v0, e1, e2, blo, bhi, ll, lh); else for (int c = 0; c < 3; ++c) { ll[c] = blo[c]; lh[c] = bhi[c]; }
+        bhi[ax] = whole_hi;
+        blo[ax] = fmaxf(blo[ax], pos);
+        if (tri) clip_triangle_to_box(v0, e1, e2, blo, bhi, rl, rh); else for (int c = 0; c < 3; ++c) { rl[c] = blo[c]; rh[c] = bhi[c]; }
+        float *o = a.cut_box + 12 * (size_t)slot;
+        for (int c = 0; c < 3; ++c) { o[c] = ll[c]; o[3 + c] = lh[c]; o[6 + c] = rl[c]; o[9 + c] = rh[c]; }
     }
 }
 
@@ -382,7 +428,7 @@ __global__ __launch_bounds__(256) void k_split_plan_apply(SplitArgs a) {
     if (ai == 0u) {
         cn->n_act = 2u * tot_split; cn->n_chunks = (uint32_t)(t2 >> 32); cn->src_total = tot_dst; cn->n_big = (uint32_t)t2;
         cn->n_cells = cell_base + tot_cells; cn->n_top = top_base + tot_split; cn->n_out = out_base + tot_out;
-        cn->n_segs = seg_base + 2u * tot_split; cn->retry = 0u;
+        cn->n_segs = seg_base + 2u * tot_split; cn->retry = 0u; cn->n_cut = 0u;
     }
 }
 
@@ -405,7 +451,6 @@ __global__ __launch_bounds__(64) void k_split_scatter(SplitArgs a) {
     const uint32_t c_l = sg.child, c_r = sg.child + 1u;
     const uint32_t dst_l = sg.out_first, dst_r = sg.out_first + sg.nl;      // (= the children's `first`)
     const uint64_t sc0 = a.scan[first];
-    const int ax = (int)sg.axis; const float pos = sg.c0;
     float mn_l[6], mx_l[6], mn_r[6], mx_r[6];        // [0..2] box, [3..5] centroid
     for (int q = 0; q < 6; ++q) { mn_l[q] = mn_r[q] = INFINITY; mx_l[q] = mx_r[q] = -INFINITY; }
     for (uint32_t j = off + threadIdx.x; j < end; j += kWave) {
@@ -414,22 +459,8 @@ __global__ __launch_bounds__(64) void k_split_scatter(SplitArgs a) {
         const bool to_l = (f >> 32) != 0ull, to_r = (f & 1ull) != 0ull;
         float ll[3] = {l4.x, l4.y, l4.z}, lh[3] = {h4.x, h4.y, h4.z}, rl[3] = {l4.x, l4.y, l4.z}, rh[3] = {h4.x, h4.y, h4.z};
         if (to_l && to_r) {
-            float blo[3] = {l4.x, l4.y, l4.z}, bhi[3] = {h4.x, h4.y, h4.z};
-            const uint32_t k = __float_as_uint(l4.w);
-            const uint32_t inst = find_instance(a.b.inst_first, a.b.n_inst, k), p = k - a.b.inst_first[inst];
-            const bool tri = a.b.inst_kind[inst] == kPrimKindTriangle;
-            float v0[3] = {0, 0, 0}, e1[3] = {0, 0, 0}, e2[3] = {0, 0, 0};
-            if (tri) {
-                const float *src = reinterpret_cast<const float *>(a.b.inst_src[inst]) + 9 * (size_t)p;
-                float s9[9], tlo[3], thi[3];
-                for (int q = 0; q < 9; ++q) s9[q] = src[q];
-                triangle_world(s9, a.b.inst_xf + 12 * (size_t)inst, a.b.inst_identity[inst] != 0u, v0, e1, e2, tlo, thi);
-            }
-            bhi[ax] = fminf(bhi[ax], pos);
-            if (tri) clip_triangle_to_box(v0, e1, e2, blo, bhi, ll, lh); else for (int c = 0; c < 3; ++c) { ll[c] = blo[c]; lh[c] = bhi[c]; }
-            bhi[ax] = ax == 0 ? h4.x : (ax == 1 ? h4.y : h4.z);
-            blo[ax] = fmaxf(blo[ax], pos);
-            if (tri) clip_triangle_to_box(v0, e1, e2, blo, bhi, rl, rh); else for (int c = 0; c < 3; ++c) { rl[c] = blo[c]; rh[c] = bhi[c]; }
+            const float *cb = a.cut_box + 12 * (size_t)__float_as_uint(h4.w);      // (k_split_clip)
+            for (int c = 0; c < 3; ++c) { ll[c] = cb[c]; lh[c] = cb[3 + c]; rl[c] = cb[6 + c]; rh[c] = cb[9 + c]; }
         }
         if (to_l) {
             const uint32_t o = dst_l + (uint32_t)(sc >> 32);
@@ -519,6 +550,8 @@ SplitPhaseResult gpu_split_phase(const GpuBuildArgs &b, uint32_t n_valid, const 
         S_TRY(arena.alloc((void **)&ch_act[q], sizeof(uint32_t) * (size_t)chunk_cap)); S_TRY(arena.alloc((void **)&ch_off[q], sizeof(uint32_t) * (size_t)chunk_cap));
     }
     for (int q = 0; q < 3; ++q) { S_TRY(arena.alloc((void **)&a.plan_in[q], sizeof(uint64_t) * (size_t)act_cap)); S_TRY(arena.alloc((void **)&a.plan_ex[q], sizeof(uint64_t) * (size_t)act_cap)); }
+    a.cut_cap = budget + 4096u;
+    S_TRY(arena.alloc((void **)&a.cut_list, sizeof(uint2) * (size_t)a.cut_cap)); S_TRY(arena.alloc((void **)&a.cut_box, sizeof(float) * 12 * (size_t)a.cut_cap));
     S_TRY(arena.alloc((void **)&a.counters, sizeof(SplitCounters)));
     S_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, a.flags, a.scan, (int)(std::max(cap, b.n) + 4096u), s));      // (also the plan's scans over a level's segments: at most cap + 2)
     S_TRY(arena.alloc(&temp, scan_bytes));
@@ -556,6 +589,7 @@ SplitPhaseResult gpu_split_phase(const GpuBuildArgs &b, uint32_t n_valid, const 
         if (n_big) hipLaunchKernelGGL(k_split_select, dim3(a.n_act), dim3(kWave), 0, s, a);
         hipLaunchKernelGGL(k_split_flags, dim3(a.n_chunks), dim3(kWave), 0, s, a);
         S_TRY(hipcub::DeviceScan::ExclusiveSum(temp, scan_bytes, a.flags, a.scan, (int)src_total, s));
+        hipLaunchKernelGGL(k_split_clip, dim3(std::min<uint32_t>(blocks(std::min(src_total, a.cut_cap), kWave), 2048u)), dim3(kWave), 0, s, a);
         for (int pass = 0; pass < 2; ++pass) {
             hipLaunchKernelGGL(k_split_plan_count, dim3(blocks(a.n_act, 256)), dim3(256), 0, s, a);
             for (int q = 0; q < 3; ++q) S_TRY(hipcub::DeviceScan::ExclusiveSum(temp, scan_bytes, a.plan_in[q], a.plan_ex[q], (int)a.n_act, s));

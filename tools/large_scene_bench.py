@@ -3,7 +3,7 @@
 from 8 M on).  One JSON line per run: device build time, Mrays/s at 1920x1080 x spp, nodes / primitives per ray (counting
 pass), the algorithmic-bytes fraction of the HBM peak.  tools/profile_large.sh wraps it in rocprofv3 --pmc passes for the
 memory-side counters (fabric bytes per launch, TCC hit rate)."""
-import argparse, ctypes as C, importlib, json, os, sys, time
+import os, argparse, ctypes as C, importlib, json, os, sys, time
 from pathlib import Path
 import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
@@ -14,7 +14,7 @@ ap.add_argument("--tris", type=int, default=8_000_000)
 ap.add_argument("--spp", type=int, default=16)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--no-count", action="store_true", help="skip the counting pass and the build timing (PMC runs)")
-ap.add_argument("--fast-trace", action="store_true", help="host SAH builder (HRT_CTX_FAST_TRACE) instead of the device build")
+ap.add_argument("--fast-trace", action="store_true", help="HRT_CTX_FAST_TRACE: the build with spatial splits (on the device; HRT_FAST_TRACE_BUILD=host: the host builder) instead of the default device build")
 ap.add_argument("--cache-dir", default="/tmp/hrt_scenes")
 args = ap.parse_args()
 
@@ -39,8 +39,9 @@ else:
 r = hrt.Renderer(0, hrt.CTX_TIMING | (hrt.CTX_FAST_TRACE if args.fast_trace else 0))
 t0 = time.perf_counter(); r.load_scene(scene); load_s = time.perf_counter() - t0
 out = {"scene": scene["name"], "triangles": args.tris, "edge": hrt.scenes.soup_law_edge(args.tris) if args.tris != 1_000_000 else 0.014,
-       "builder": "host binned SAH" if args.fast_trace else "device PLOC", "load_scene_s": round(load_s, 3)}
-if not args.no_count and not args.fast_trace:
+       "builder": ("device top-down SAH with spatial splits + PLOC" if os.environ.get("HRT_FAST_TRACE_BUILD", "device") == "device" else "host binned SAH with spatial splits") if args.fast_trace else "device PLOC",
+       "load_scene_s": round(load_s, 3)}
+if not args.no_count and (not args.fast_trace or os.environ.get("HRT_FAST_TRACE_BUILD", "device") == "device"):
     # the TLAS build alone: the same instance array once more, timed from call to stream idle
     best = 1e9
     for _ in range(2):
