@@ -44,6 +44,7 @@ struct SplitParams {
     bool enabled = false;
     float budget_frac = 1.0f;         // at most this many extra references per primitive
     float alpha = 1e-5f, bias = 0.95f;       // as the host builder's (bvh8_build.cpp)
+    float cut_bias = 1.0f;            // a straddler is cut when cut_bias x the SAH cost of cutting it is not above that of keeping it whole on either side
     uint32_t cell_refs = 256;         // segments with fewer references are left to PLOC
     float pad = 0.0f;                 // the padding the SAH areas are computed with (4e-6 of the scene scale)
     bool verbose = false;

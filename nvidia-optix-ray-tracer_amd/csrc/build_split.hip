@@ -72,7 +72,7 @@ struct SplitArgs {
     SplitCounters *counters;
     uint32_t n_act, n_chunks, cell_refs, level;
     uint32_t seg_base, cell_base, top_base, out_base;       // the running totals before this level (the host's copy of the counters)
-    float pad, alpha_area, bias;
+    float pad, alpha_area, bias, cut_bias;
 };
 
 __device__ __forceinline__ float half_area3(const float *lo, const float *hi) {
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64) void k_split_select(SplitArgs a) {
 }
 
 // ---- flags: which side(s) a reference goes to ----
-__device__ __forceinline__ uint64_t side_of(const SplitSeg &sg, const float *rl, const float *rh) {
+__device__ __forceinline__ uint64_t side_of(const SplitSeg &sg, const float *rl, const float *rh, float cut_bias) {
     const uint64_t kLeft = 1ull << 32, kRight = 1ull;
     const int ax = (int)sg.axis;
     if (sg.kind == 2u) {
@@ -302,7 +302,7 @@ __device__ __forceinline__ uint64_t side_of(const SplitSeg &sg, const float *rl,
     const float c_split = al * (float)sg.nl + ar * (float)sg.nr;
     const float c_left = half_area3(lw, lw + 3) * (float)sg.nl + ar * (float)(sg.nr - 1u);
     const float c_right = al * (float)(sg.nl - 1u) + half_area3(rw, rw + 3) * (float)sg.nr;
-    if (c_split <= c_left && c_split <= c_right) return kLeft | kRight;
+    if (c_split * cut_bias <= c_left && c_split * cut_bias <= c_right) return kLeft | kRight;
     return c_left <= c_right ? kLeft : kRight;
 }
 
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(64) void k_split_flags(SplitArgs a) {
         if (kind >= 2u) {
             const float4 l4 = a.src_lo[first + j], h4 = a.src_hi[first + j];
             const float rl[3] = {l4.x, l4.y, l4.z}, rh[3] = {h4.x, h4.y, h4.z};
-            f = side_of(sg, rl, rh);
+            f = side_of(sg, rl, rh, a.cut_bias);
         }
         // cut: the clipping is a kernel of its own over these (every lane busy); slots from one atomic per wave, the slot rides in the reference
         const bool cut = f == ((1ull << 32) | 1ull);
@@ -533,7 +533,7 @@ SplitPhaseResult gpu_split_phase(const GpuBuildArgs &b, uint32_t n_valid, const 
     const SplitSizes z = split_sizes(n_valid, sp);
     const uint32_t cap = z.cap, budget = cap - n_valid, cell_refs = z.cell_refs, act_cap = z.act_cap, seg_cap = z.seg_cap, chunk_cap = z.chunk_cap;
     SplitArgs a{};
-    a.b = b; a.seg_cap = seg_cap; a.cell_refs = cell_refs; a.pad = sp.pad; a.bias = sp.bias;
+    a.b = b; a.seg_cap = seg_cap; a.cell_refs = cell_refs; a.pad = sp.pad; a.bias = sp.bias; a.cut_bias = sp.cut_bias;
     float4 *buf[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t *act[2] = {nullptr, nullptr}, *ch_act[2] = {nullptr, nullptr}, *ch_off[2] = {nullptr, nullptr};
     void *temp = nullptr; size_t scan_bytes = 0;

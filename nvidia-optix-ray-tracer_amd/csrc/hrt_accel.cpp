@@ -238,7 +238,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
     std::vector<uint32_t> order;
     t.phases.clear();
     // HRT_CTX_FAST_TRACE: the static-scene tree with spatial splits -- from the host builder, or (HRT_FAST_TRACE_BUILD=device) from the device's
-    const bool device_split = fast_trace && ctx->fast_trace_on_device != 0 && !instanced && ctx->build_on_device != 0;
+    bool device_split = fast_trace && ctx->fast_trace_on_device != 0 && !instanced && ctx->build_on_device != 0;
     const bool device_merged = !instanced && ctx->build_on_device != 0 && (!fast_trace || device_split);
     // global primitive numbering of the merged builds: instance after instance, invisible instances contribute nothing
     std::vector<uint32_t> first(n + 1, 0u);
@@ -250,6 +250,14 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         first[i + 1] = first[i] + cnt;
         if (refs[i]->kind == kPrimKindTriangle) n_tri_in += cnt; else n_sph_in += cnt;
         (void)n_sph_in;
+    }
+    if (device_split) {
+        // the split build's working memory (~1.2 KB per primitive with the staged output) has to be there: otherwise the default build
+        SplitParams probe; probe.enabled = true; probe.budget_frac = ctx->split_budget; probe.cell_refs = (uint32_t)ctx->split_cell_refs;
+        const size_t leaves = gpu_build_max_refs(first[n], &probe);
+        const size_t want = gpu_build_scratch_bytes(first[n], &probe) + leaves * (size_t)(128 + 8 + ctx->prim_stride + 24);
+        size_t free_b = 0, total_b = 0;
+        if (leaves > (1u << 30) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || want > free_b / 10 * 9) device_split = false;
     }
     if (instanced) {
         std::vector<const Bvh8 *> tmpl(n, nullptr);
@@ -380,7 +388,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         in.n_prims = first[n]; in.n_inst = n; in.d_inst_first = t.d_inst_first; in.d_inst_kind = t.d_inst_kind; in.d_inst_src = t.d_inst_src;
         in.d_inst_xf = t.d_inst_xf; in.d_inst_identity = t.d_inst_identity;
         in.max_leaf_prims = kMaxLeafPrims; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius;
-        in.split.enabled = device_split; in.split.budget_frac = ctx->split_budget; in.split.alpha = ctx->split_alpha; in.split.bias = ctx->split_bias;
+        in.split.enabled = device_split; in.split.budget_frac = ctx->split_budget; in.split.alpha = ctx->split_alpha; in.split.bias = ctx->split_bias; in.split.cut_bias = ctx->split_cut_bias;
         in.split.cell_refs = (uint32_t)ctx->split_cell_refs; in.split.pad = ra.pad; in.split.verbose = std::getenv("HRT_BUILD_VERBOSE") != nullptr;
         // worst-case node output (one node and two reference floats per leaf: primitive, or reference of a spatial split) at the front of the
         // working memory; a split build's records and their clip boxes too (their number is known afterwards)

@@ -155,6 +155,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_SBVH_BUDGET")) { const double v = std::atof(e); if (v >= 0.0 && v <= 8.0) ctx->split_budget = (float)v; }
     if (const char *e = std::getenv("HRT_SBVH_ALPHA")) ctx->split_alpha = (float)std::atof(e);
     if (const char *e = std::getenv("HRT_SBVH_BIAS")) ctx->split_bias = (float)std::atof(e);
+    if (const char *e = std::getenv("HRT_SBVH_CUT_BIAS")) { const double w = std::atof(e); if (w > 0.0) ctx->split_cut_bias = (float)w; }
     if (const char *e = std::getenv("HRT_SBVH_CELL_REFS")) { const int v = std::atoi(e); if (v >= 2 && v <= (1 << 20)) ctx->split_cell_refs = v; }
     if (const char *e = std::getenv("HRT_PLOC_RADIUS")) { const int v = std::atoi(e); if (v >= 1 && v <= 128) ctx->ploc_radius = v; }
     if (const char *e = std::getenv("HRT_BVH_CPRIM")) ctx->build_c_prim = (float)std::atof(e);

@@ -177,7 +177,7 @@ struct HrtContext {
     int tlas_instanced = 0;                     // 1: hrt_tlas_build makes trees over instances too, 0: only rebuilds during updates do, -1: never
     int build_on_device = 1;                    // 1: PLOC build on the GPU (build.hip), 0: binned-SAH build on the host (HRT_BUILD=host; needs a host copy of the geometry)
     int fast_trace_on_device = 1;               // HRT_CTX_FAST_TRACE builds: 1 = on the device with spatial splits (build_split.hip), 0 = the host builder (HRT_FAST_TRACE_BUILD=device|host)
-    float split_budget = 1.0f, split_alpha = 1e-5f, split_bias = 0.95f; int split_cell_refs = 16;      // the device's spatial splits (HRT_SBVH_BUDGET / _ALPHA / _BIAS / _CELL_REFS)
+    float split_budget = 1.0f, split_alpha = 1e-5f, split_bias = 0.95f, split_cut_bias = 1.0f; int split_cell_refs = 16;      // the device's spatial splits (HRT_SBVH_BUDGET / _ALPHA / _BIAS / _CELL_REFS)
     int ploc_radius = 2;                        // device build: nearest-neighbour search radius of the PLOC rounds (positions in Morton order); 2 traces fastest
                                                 // on the soup scenes (C4: 24.1 node visits per ray, 16: 28.3, 64: 36.6 -- profiles/r02_build_bench.txt)
     float build_c_node = 1.0f, build_c_prim = 0.45f;   // collapse costs (bvh8_build.cpp has the same defaults)

@@ -1388,6 +1388,22 @@ def test_eight_million_triangles_out_of_the_infinity_cache(hrt, oracle, gpu_avai
         assert (prim != 0xFFFFFFFF).sum() > 2500
         assert np.array_equal(prim, rprim) and np.array_equal(inst, rinst)
         assert np.array_equal(t.view(np.uint32), rt.view(np.uint32)) and np.array_equal(u.view(np.uint32), ru.view(np.uint32)) and np.array_equal(v.view(np.uint32), rv.view(np.uint32))
+        # the same scene under HRT_CTX_FAST_TRACE: the device build with spatial splits (8 M primitives through ~25 split levels,
+        # ~11 M records) -- the same rows and the same hits, bit for bit
+        linear0, states0 = r.linear.cpu().numpy()[rows].copy(), got_states[rows].copy()
+        r2 = hrt.Renderer(0, hrt.CTX_FAST_TRACE)
+        try:
+            r2.load_scene(scene)
+            r2.set_frame(W, H, hrt.scenes.SEED_SALT, aov=False, linear=True)
+            r2.render(1, tile=tile)
+            st2 = r2.stats()
+            assert st2.rays == st.rays and st2.bvh_bytes > st.bvh_bytes * 1.2 and st2.fused_fallback_launches == 0
+            assert np.array_equal(r2.linear.cpu().numpy()[rows].view(np.uint32), linear0.view(np.uint32))
+            assert np.array_equal(r2.rng_states_numpy().reshape(H, W, 12)[rows], states0)
+            t2, u2, v2, prim2, inst2 = r2.trace_rays(o, d)
+            assert np.array_equal(prim2, prim) and np.array_equal(t2.view(np.uint32), t.view(np.uint32)) and np.array_equal(u2.view(np.uint32), u.view(np.uint32))
+        finally:
+            r2.close()
     finally:
         r.close()
 
