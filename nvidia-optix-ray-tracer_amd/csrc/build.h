@@ -13,7 +13,8 @@ struct BuildCounters {
     uint32_t n_invalid;               // primitives with non-finite bounds (left out of the tree)
     uint32_t m_next, merges;          // PLOC round: clusters after the round, merges made
     uint32_t m_cur, node_base;        // PLOC: clusters before the round, index of the next BVH2 node (advanced on the device between rounds)
-    uint32_t round_base[8], round_idx; // node_base after each of the last eight rounds (the cost pass walks the rounds in order)
+    uint32_t root, small_rounds, cl_in_b;   // k_ploc_small: the root cluster, the rounds it ran, which cluster array holds the result
+    uint32_t n_levels, max_depth, level_begin[40];      // k_emit_small: the levels of a small tree (nodes of level l: [level_begin[l], level_begin[l + 1]))
     uint32_t next_node, next_prim;    // emission cursors
     float total_below;                // sum over BVH8 nodes of the primitives below them (refit quality weights)
 };
@@ -106,7 +107,7 @@ size_t gpu_split_table_bytes(uint32_t n_prims, const SplitParams &split);       
 uint32_t gpu_build_max_refs(uint32_t n_prims, const SplitParams *split);                    // most records / nodes a build can emit
 // build_split.hip: references of the valid primitives (pb_lo / pb_hi of `a`, scene bounds in a.counters) cut top-down into cells
 SplitPhaseResult gpu_split_phase(const GpuBuildArgs &a, uint32_t n_valid, const SplitParams &sp, BuildArena &arena, hipStream_t s);
-constexpr size_t kBoundsScratchBytes = 256;           // ... of gpu_blas_bounds
+constexpr size_t kBoundsScratchBytes = 512;           // ... of gpu_blas_bounds
 hipError_t gpu_blas_bounds(const float *d_src, uint32_t n_prims, uint32_t kind, float *lo, float *hi, void *d_scratch, hipStream_t s);
 void launch_pack_spheres(const float *centers, const float *radii, uint32_t n, float *out, hipStream_t s);
 

@@ -27,6 +27,7 @@ namespace hrt {
 namespace {
 
 constexpr int kPlocMaxRadius = 128;
+constexpr uint32_t kMaxSmallLevels = 40u;
 
 __global__ __launch_bounds__(1024) void k_prim_bounds(GpuBuildArgs a) {
     const uint32_t k = blockIdx.x * 1024u + threadIdx.x;
@@ -86,6 +87,58 @@ __global__ __launch_bounds__(256) void k_morton(GpuBuildArgs a) {
     a.keys[k] = key; a.vals[k] = k;
 }
 
+// ---- optimal collapse: cost tables (bvh8_build.cpp, same recurrences) ----
+// table of a node: c[1..7] as floats in t[1..7]; t[0] bits: leaf1 | use_dist[i] << i (i = 2..7) | split[j] << (8 + 3 (j - 2)) (j = 2..8)
+struct CostRow { float c[8]; };
+__device__ __forceinline__ uint32_t row_bits(const CostRow &r) { return __float_as_uint(r.c[0]); }
+__device__ __forceinline__ uint32_t row_split(uint32_t bits, int j) { return (bits >> (8 + 3 * (j - 2))) & 7u; }
+
+__device__ __forceinline__ float node_half_area(const float4 lo, const float4 hi) {
+    const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__device__ void cost_of_node(const GpuBuildArgs &a, uint32_t nd, bool leaf, CostRow &out) {
+    const float kInf = INFINITY;
+    const float area = node_half_area(a.node_lo[nd], a.node_hi[nd]);
+    const uint32_t np = a.node_nprims[nd];
+    const float c_leaf = np <= a.max_leaf_prims ? area * a.c_prim * (float)np : kInf;
+    if (leaf) {
+        for (int i = 1; i <= 7; ++i) out.c[i] = c_leaf;
+        out.c[0] = __uint_as_float(1u);
+        return;
+    }
+    const uint32_t l = __float_as_uint(a.node_lo[nd].w), r = __float_as_uint(a.node_hi[nd].w);
+    CostRow cl, cr;
+    {   // the children's rows: written by an earlier launch
+        const float4 *pl = reinterpret_cast<const float4 *>(a.cost + 8 * (size_t)l), *pr = reinterpret_cast<const float4 *>(a.cost + 8 * (size_t)r);
+        const float4 l0 = pl[0], l1 = pl[1], r0 = pr[0], r1 = pr[1];
+        cl.c[0] = l0.x; cl.c[1] = l0.y; cl.c[2] = l0.z; cl.c[3] = l0.w; cl.c[4] = l1.x; cl.c[5] = l1.y; cl.c[6] = l1.z; cl.c[7] = l1.w;
+        cr.c[0] = r0.x; cr.c[1] = r0.y; cr.c[2] = r0.z; cr.c[3] = r0.w; cr.c[4] = r1.x; cr.c[5] = r1.y; cr.c[6] = r1.z; cr.c[7] = r1.w;
+    }
+    float dist[9]; uint32_t bits = 0u;
+    for (int j = 2; j <= 8; ++j) {
+        float best = kInf; int bk = 1;
+        for (int k = 1; k < j; ++k) {
+            const float v = cl.c[k < 7 ? k : 7] + cr.c[(j - k) < 7 ? (j - k) : 7];
+            if (v < best) { best = v; bk = k; }
+        }
+        dist[j] = best; bits |= (uint32_t)bk << (8 + 3 * (j - 2));
+    }
+    const float c_internal = dist[8] + area * a.c_node;
+    if (c_leaf <= c_internal) bits |= 1u;
+    out.c[1] = fminf(c_leaf, c_internal);
+    for (int i = 2; i <= 7; ++i) {
+        if (dist[i] < out.c[i - 1]) { out.c[i] = dist[i]; bits |= 1u << i; } else out.c[i] = out.c[i - 1];
+    }
+    out.c[0] = __uint_as_float(bits);
+}
+
+__device__ __forceinline__ void store_row(const GpuBuildArgs &a, uint32_t nd, const CostRow &r) {
+    float4 *p = reinterpret_cast<float4 *>(a.cost + 8 * (size_t)nd);
+    p[0] = make_float4(r.c[0], r.c[1], r.c[2], r.c[3]); p[1] = make_float4(r.c[4], r.c[5], r.c[6], r.c[7]);
+}
+
 // builds with spatial splits: the sort key of a reference is its cell, then the Morton code of its centroid within the cell's
 // centroid bounds (10 bits an axis: cells are small) -- the references of a cell stay together and PLOC works cell by cell
 __global__ __launch_bounds__(256) void k_morton_refs(GpuBuildArgs a, uint32_t n_refs, const SplitSeg *__restrict__ segs, const uint32_t *__restrict__ cell_seg) {
@@ -118,6 +171,7 @@ __global__ __launch_bounds__(256) void k_leaves_refs(GpuBuildArgs a, uint32_t n_
     a.node_cell[i] = __float_as_uint(hi.w);
     a.node_nprims[i] = 1u;
     a.cl_a[i] = i;
+    CostRow row; cost_of_node(a, i, true, row); store_row(a, i, row);
 }
 
 // the segments the top-down phase split are the top of the BVH2: node top_base + t for top node t, children = top nodes or the
@@ -139,8 +193,12 @@ __global__ __launch_bounds__(256) void k_top_link(GpuBuildArgs a, const SplitSeg
 }
 
 // BVH2 node i: lo.xyz | left, hi.xyz | right.  Leaf: left = kNone, right = global primitive number.
-__global__ __launch_bounds__(256) void k_leaves(GpuBuildArgs a, uint32_t nv) {
+// (nv = kNone: a small build, which does not stop for the host to learn the number of valid primitives -- taken from the counters, and
+// the PLOC counters are set here)
+__global__ __launch_bounds__(256) void k_leaves(GpuBuildArgs a, uint32_t nv_host) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t nv = nv_host != kNone ? nv_host : a.n - a.counters->n_invalid;
+    if (i == 0u && nv_host == kNone) { BuildCounters *c = a.counters; c->m_cur = nv; c->m_next = nv; c->node_base = nv; c->merges = 0u; }
     if (i >= nv) return;
     const uint32_t k = a.vals_sorted[i];
     const float4 lo = a.pb_lo[k], hi = a.pb_hi[k];
@@ -148,6 +206,7 @@ __global__ __launch_bounds__(256) void k_leaves(GpuBuildArgs a, uint32_t nv) {
     a.node_hi[i] = make_float4(hi.x, hi.y, hi.z, __uint_as_float(k));
     a.node_nprims[i] = 1u;
     a.cl_a[i] = i;
+    CostRow row; cost_of_node(a, i, true, row); store_row(a, i, row);
 }
 
 __device__ __forceinline__ float merged_half_area(const float4 alo, const float4 ahi, const float4 blo, const float4 bhi) {
@@ -214,69 +273,89 @@ __global__ __launch_bounds__(256) void k_ploc_apply(GpuBuildArgs a, const uint32
     a.node_nprims[id] = a.node_nprims[l] + a.node_nprims[r];
     if (a.node_cell) a.node_cell[id] = a.node_cell[l];
     cl_out[pos] = id;
+    CostRow row; cost_of_node(a, id, false, row); store_row(a, id, row);       // (the children's tables: earlier rounds')
+}
+
+// Few clusters (the whole of a small build, the last dozen rounds of a large one): ONE workgroup runs every remaining round, a barrier
+// where the large build has a launch -- a round of six launches costs 30 us of host time whatever its size.  Same arithmetic and the
+// same tie rules as k_ploc_nn / _flags / _apply, so a build is the same tree whichever kernels ran its rounds.
+constexpr uint32_t kSmallItems = 16u;                            // clusters per thread
+constexpr uint32_t kSmallClusters = 1024u * kSmallItems;
+__global__ __launch_bounds__(1024) void k_ploc_small(GpuBuildArgs a, uint32_t *cl_a, uint32_t *cl_b, uint32_t n_cells) {
+    typedef hipcub::BlockScan<uint64_t, 1024> Scan;
+    __shared__ typename Scan::TempStorage tmp;
+    BuildCounters *c = a.counters;
+    uint32_t m = c->m_cur, node_base = c->node_base;
+    uint32_t *cin = cl_a, *cout = cl_b;
+    const int radius = a.ploc_radius;
+    uint32_t rounds = 0u;
+    while (m > n_cells) {
+        // nearest neighbours
+        for (uint32_t q = 0; q < kSmallItems; ++q) {
+            const uint32_t i = threadIdx.x * kSmallItems + q;
+            if (i >= m) break;
+            const uint32_t me = cin[i];
+            const float4 mlo = a.node_lo[me], mhi = a.node_hi[me];
+            const uint32_t my_cell = a.node_cell ? a.node_cell[me] : 0u;
+            float best = INFINITY; uint32_t bj = kNone;
+            for (int d = -radius; d <= radius; ++d) {
+                const int j = (int)i + d;
+                if (d == 0 || j < 0 || j >= (int)m) continue;
+                const uint32_t o = cin[j];
+                if (a.node_cell && a.node_cell[o] != my_cell) continue;
+                const float ar = merged_half_area(mlo, mhi, a.node_lo[o], a.node_hi[o]);
+                if (ar < best || bj == kNone) { best = ar; bj = (uint32_t)j; }
+            }
+            a.nn[i] = bj;
+        }
+        __syncthreads();
+        // flags, scan, apply
+        uint64_t f[kSmallItems], e[kSmallItems], total;
+        for (uint32_t q = 0; q < kSmallItems; ++q) {
+            const uint32_t i = threadIdx.x * kSmallItems + q;
+            uint64_t v = 0ull;
+            if (i < m) {
+                const uint32_t j = a.nn[i];
+                const bool mutual = j != kNone && a.nn[j] == i;
+                v = 1ull << 32;
+                if (mutual) v = i < j ? ((1ull << 32) | 1ull) : 0ull;
+            }
+            f[q] = v;
+        }
+        Scan(tmp).ExclusiveSum(f, e, total);
+        for (uint32_t q = 0; q < kSmallItems; ++q) {
+            const uint32_t i = threadIdx.x * kSmallItems + q;
+            if (i >= m || (f[q] >> 32) == 0ull) continue;
+            const uint32_t pos = (uint32_t)(e[q] >> 32);
+            if ((f[q] & 1ull) == 0ull) { cout[pos] = cin[i]; continue; }
+            const uint32_t l = cin[i], r = cin[a.nn[i]], id = node_base + (uint32_t)(e[q] & 0xffffffffu);
+            const float4 llo = a.node_lo[l], lhi = a.node_hi[l], rlo = a.node_lo[r], rhi = a.node_hi[r];
+            a.node_lo[id] = make_float4(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z), __uint_as_float(l));
+            a.node_hi[id] = make_float4(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), __uint_as_float(r));
+            a.node_nprims[id] = a.node_nprims[l] + a.node_nprims[r];
+            if (a.node_cell) a.node_cell[id] = a.node_cell[l];
+            cout[pos] = id;
+            CostRow row; cost_of_node(a, id, false, row); store_row(a, id, row);
+        }
+        __threadfence_block();
+        __syncthreads();
+        const uint32_t merges = (uint32_t)(total & 0xffffffffull);
+        ++rounds;
+        uint32_t *t2 = cin; cin = cout; cout = t2;
+        m = (uint32_t)(total >> 32); node_base += merges;
+        if (merges == 0u) break;                                 // (cannot happen while a cell holds two clusters; never loop forever)
+    }
+    if (threadIdx.x == 0u) { c->m_cur = m; c->m_next = m; c->node_base = node_base; c->merges = 0u; c->root = m ? cin[0] : kNone; c->small_rounds = rounds; c->cl_in_b = cin == cl_b ? 1u : 0u; }
 }
 
 // between two rounds: what k_ploc_apply counted becomes the next round's input
 __global__ void k_ploc_advance(GpuBuildArgs a) {
     BuildCounters *c = a.counters;
     c->node_base += c->merges; c->m_cur = c->m_next;
-    c->round_base[c->round_idx & 7u] = c->node_base; ++c->round_idx;      // (the host reads eight rounds' worth at a time)
 }
 
-// ---- optimal collapse: cost tables (bvh8_build.cpp, same recurrences) ----
-// table of a node: c[1..7] as floats in t[1..7]; t[0] bits: leaf1 | use_dist[i] << i (i = 2..7) | split[j] << (8 + 3 (j - 2)) (j = 2..8)
-struct CostRow { float c[8]; };
-__device__ __forceinline__ uint32_t row_bits(const CostRow &r) { return __float_as_uint(r.c[0]); }
-__device__ __forceinline__ uint32_t row_split(uint32_t bits, int j) { return (bits >> (8 + 3 * (j - 2))) & 7u; }
-
-__device__ __forceinline__ float node_half_area(const float4 lo, const float4 hi) {
-    const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
-    return dx * dy + dy * dz + dz * dx;
-}
-
-__device__ void cost_of_node(const GpuBuildArgs &a, uint32_t nd, bool leaf, CostRow &out) {
-    const float kInf = INFINITY;
-    const float area = node_half_area(a.node_lo[nd], a.node_hi[nd]);
-    const uint32_t np = a.node_nprims[nd];
-    const float c_leaf = np <= a.max_leaf_prims ? area * a.c_prim * (float)np : kInf;
-    if (leaf) {
-        for (int i = 1; i <= 7; ++i) out.c[i] = c_leaf;
-        out.c[0] = __uint_as_float(1u);
-        return;
-    }
-    const uint32_t l = __float_as_uint(a.node_lo[nd].w), r = __float_as_uint(a.node_hi[nd].w);
-    CostRow cl, cr;
-    {   // the children's rows: written by an earlier launch
-        const float4 *pl = reinterpret_cast<const float4 *>(a.cost + 8 * (size_t)l), *pr = reinterpret_cast<const float4 *>(a.cost + 8 * (size_t)r);
-        const float4 l0 = pl[0], l1 = pl[1], r0 = pr[0], r1 = pr[1];
-        cl.c[0] = l0.x; cl.c[1] = l0.y; cl.c[2] = l0.z; cl.c[3] = l0.w; cl.c[4] = l1.x; cl.c[5] = l1.y; cl.c[6] = l1.z; cl.c[7] = l1.w;
-        cr.c[0] = r0.x; cr.c[1] = r0.y; cr.c[2] = r0.z; cr.c[3] = r0.w; cr.c[4] = r1.x; cr.c[5] = r1.y; cr.c[6] = r1.z; cr.c[7] = r1.w;
-    }
-    float dist[9]; uint32_t bits = 0u;
-    for (int j = 2; j <= 8; ++j) {
-        float best = kInf; int bk = 1;
-        for (int k = 1; k < j; ++k) {
-            const float v = cl.c[k < 7 ? k : 7] + cr.c[(j - k) < 7 ? (j - k) : 7];
-            if (v < best) { best = v; bk = k; }
-        }
-        dist[j] = best; bits |= (uint32_t)bk << (8 + 3 * (j - 2));
-    }
-    const float c_internal = dist[8] + area * a.c_node;
-    if (c_leaf <= c_internal) bits |= 1u;
-    out.c[1] = fminf(c_leaf, c_internal);
-    for (int i = 2; i <= 7; ++i) {
-        if (dist[i] < out.c[i - 1]) { out.c[i] = dist[i]; bits |= 1u << i; } else out.c[i] = out.c[i - 1];
-    }
-    out.c[0] = __uint_as_float(bits);
-}
-
-__device__ __forceinline__ void store_row(const GpuBuildArgs &a, uint32_t nd, const CostRow &r) {
-    float4 *p = reinterpret_cast<float4 *>(a.cost + 8 * (size_t)nd);
-    p[0] = make_float4(r.c[0], r.c[1], r.c[2], r.c[3]); p[1] = make_float4(r.c[4], r.c[5], r.c[6], r.c[7]);
-}
-
-// a range of BVH2 nodes whose children's tables are complete: the leaves, then the nodes of one PLOC round after another (a round's
-// nodes have children from earlier rounds only), then the top-down phase's levels from the deepest up.  (Round 2 let the second of a
+// a range of BVH2 nodes whose children's tables are complete: a level of the top-down phase (from the deepest up).  The leaves' tables
+// are computed by k_leaves, those of PLOC's nodes at the merge (the children are from earlier rounds).  (Round 2 let the second of a
 // node's children to arrive compute it, behind agent-scope fences: 5 ms for a million leaves on a part whose L2s are per XCD.)
 __global__ __launch_bounds__(256) void k_cost_range(GpuBuildArgs a, uint32_t first, uint32_t count, uint32_t leaf) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -326,11 +405,7 @@ __device__ __forceinline__ bool first_of_its_prim(const uint32_t *gk, int w) {
     return true;
 }
 
-__global__ __launch_bounds__(128) void k_emit_level(GpuBuildArgs a, const uint2 *__restrict__ items, uint32_t n_items, uint2 *__restrict__ items_next,
-                                                    uint32_t next_level_begin, uint32_t is_root_level) {
-    const uint32_t t = blockIdx.x * 128u + threadIdx.x;
-    if (t >= n_items) return;
-    const uint32_t b2 = items[t].x, self = items[t].y;
+__device__ void emit_item(const GpuBuildArgs &a, uint32_t b2, uint32_t self, uint2 *__restrict__ items_next, uint32_t next_level_begin, uint32_t is_root_level) {
     const float4 nlo = a.node_lo[b2], nhi = a.node_hi[b2];
     Forest f;
     bool ch_leaf[8];
@@ -445,8 +520,43 @@ __global__ __launch_bounds__(128) void k_emit_level(GpuBuildArgs a, const uint2 
     atomicAdd(&a.counters->total_below, below);
 }
 
-__global__ __launch_bounds__(256) void k_normalise_weights(float *node_ref, uint32_t n_nodes, const BuildCounters *c) {
+__global__ __launch_bounds__(128) void k_emit_level(GpuBuildArgs a, const uint2 *__restrict__ items, uint32_t n_items, uint2 *__restrict__ items_next,
+                                                    uint32_t next_level_begin, uint32_t is_root_level) {
+    const uint32_t t = blockIdx.x * 128u + threadIdx.x;
+    if (t >= n_items) return;
+    emit_item(a, items[t].x, items[t].y, items_next, next_level_begin, is_root_level);
+}
+
+// a small tree: every level by one workgroup, no trip to the host in between (level_begin goes back with the counters)
+__global__ __launch_bounds__(1024) void k_emit_small(GpuBuildArgs a, uint2 *items_a, uint2 *items_b) {
+    __shared__ uint32_t s_count;
+    BuildCounters *c = a.counters;
+    if (c->m_cur == 0u) { if (threadIdx.x == 0u) c->n_levels = 0u; return; }      // nothing valid: the caller emits the empty root
+    if (threadIdx.x == 0u) { items_a[0] = make_uint2(c->root, 0u); c->level_begin[0] = 0u; }
+    __syncthreads();
+    uint2 *in = items_a, *out = items_b;
+    uint32_t level_begin = 0u, count = 1u, depth = 0u;
+    while (count > 0u) {
+        const uint32_t next_begin = level_begin + count;
+        for (uint32_t t = threadIdx.x; t < count; t += 1024u) emit_item(a, in[t].x, in[t].y, out, next_begin, depth == 0u ? 1u : 0u);
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0u) {
+            s_count = atomicAdd(&c->next_node, 0u) - next_begin;
+            if (depth + 1u < kMaxSmallLevels) c->level_begin[depth + 1u] = next_begin;
+        }
+        __syncthreads();
+        level_begin = next_begin; count = s_count;
+        uint2 *tmp = in; in = out; out = tmp;
+        if (count) ++depth;
+        if (depth + 1u >= kMaxSmallLevels) break;                  // (deeper than the traversal stack allows anyway: the host reports it)
+    }
+    if (threadIdx.x == 0u) { c->n_levels = depth + 1u; c->max_depth = depth; }
+}
+
+__global__ __launch_bounds__(256) void k_normalise_weights(float *node_ref, uint32_t n_nodes_host, const BuildCounters *c) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t n_nodes = n_nodes_host != kNone ? n_nodes_host : (c->n_levels ? c->next_node : 0u);
     if (i >= n_nodes) return;
     const float total = c->total_below;
     node_ref[2 * (size_t)i] = total > 0.0f ? node_ref[2 * (size_t)i] / total : 0.0f;
@@ -531,9 +641,8 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     uint64_t *keys_out = nullptr; uint32_t *cl_b = nullptr; uint2 *items_a = nullptr, *items_b = nullptr;
     BuildCounters h{};
     uint32_t nv = 0, nl = 0, ns = 0, m = 0, node_base = 0, root = 0, n_cells = 1;
-    bool split = false;
+    bool split = false, small_tail = false;
     SplitPhaseResult sp{};
-    std::vector<uint32_t> round_end;                             // index of the next BVH2 node after each PLOC round
     // working memory comes out of the caller's arena while it lasts (a small build otherwise spends more time in ~25 hipMalloc /
     // hipFree pairs, each of which synchronises the device, than in its kernels)
     BuildArena arena; arena.base = in.scratch; arena.bytes = in.scratch_bytes;
@@ -553,7 +662,8 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     hipLaunchKernelGGL(k_prim_bounds, dim3(blocks(n, 1024)), dim3(1024), 0, s, a);
     B_TRY(hipGetLastError());
     // ---- spatial splits: the top-down phase turns the primitives into references grouped in cells ----
-    split = in.split.enabled && in.max_leaf_prims == kMaxLeafPrims && n >= std::max(in.split.cell_refs, 2u);
+    // (a few thousand primitives: the splits buy nothing a ray could notice, and the small build below is the quicker one)
+    split = in.split.enabled && in.max_leaf_prims == kMaxLeafPrims && n >= std::max(in.split.cell_refs, 2u) && n > kSmallClusters / 4u;
     if (split) {
         B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
         B_TRY(hipStreamSynchronize(s));
@@ -586,6 +696,28 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     else hipLaunchKernelGGL(k_morton, dim3(blocks(n, 256)), dim3(256), 0, s, a);
     B_TRY(hipGetLastError());
     B_TRY(hipcub::DeviceRadixSort::SortPairs(temp, sort_bytes, a.keys, keys_out, a.vals, a.vals_sorted, (int)ns, 0, 64, s));
+    if (!split && n <= kSmallClusters) {
+        // ---- a small build (the reference's own scenes: a few thousand triangles): every PLOC round and every level of the emission in
+        //      one workgroup each, and the host looks at the counters once, at the end ----
+        hipLaunchKernelGGL(k_leaves, dim3(blocks(n, 256)), dim3(256), 0, s, a, kNone);
+        hipLaunchKernelGGL(k_ploc_small, dim3(1), dim3(1024), 0, s, a, a.cl_a, cl_b, 1u);
+        hipLaunchKernelGGL(k_emit_small, dim3(1), dim3(1024), 0, s, a, items_a, items_b);
+        hipLaunchKernelGGL(k_normalise_weights, dim3(blocks(n, 256)), dim3(256), 0, s, in.out_node_ref, kNone, a.counters);
+        B_TRY(hipGetLastError());
+        B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
+        B_TRY(hipStreamSynchronize(s));
+        nv = n - h.n_invalid;
+        res.n_prims = nv;
+        if (nv == 0) goto done;
+        for (int d = 0; d < 3; ++d) { res.lo[d] = ord2f(h.bmin[d]); res.hi[d] = ord2f(h.bmax[d]); }
+        if (h.m_cur != 1u) { res.error = hipErrorUnknown; res.where = "PLOC made no progress"; goto done; }
+        if (h.n_levels == 0u || h.n_levels >= kMaxSmallLevels) { res.error = hipErrorUnknown; res.where = "small build: tree too deep"; goto done; }
+        res.ploc_rounds = h.small_rounds; res.n_nodes = h.next_node; res.max_depth = h.max_depth; res.n_records = h.next_prim;
+        for (uint32_t l = 0; l < h.n_levels; ++l) res.level_begin.push_back(h.level_begin[l]);
+        res.level_begin.push_back(h.next_node);
+        if (h.next_prim != nv) { res.error = hipErrorUnknown; res.where = "emitted primitive count differs from the valid count"; goto done; }
+        goto done;
+    }
     B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
     B_TRY(hipStreamSynchronize(s));
     nv = n - h.n_invalid;
@@ -600,13 +732,22 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     m = nl; node_base = nl;
     {
         uint32_t *cl_in = a.cl_a, *cl_out = cl_b;
-        h.m_cur = m; h.node_base = node_base; h.m_next = m; h.merges = 0u; h.round_idx = 0u;
+        h.m_cur = m; h.node_base = node_base; h.m_next = m; h.merges = 0u;
         B_TRY(hipMemcpyAsync(a.counters, &h, sizeof h, hipMemcpyHostToDevice, s));
         // A round merges at least one pair, typically 40 % of the clusters.  The host launches kRoundsPerBatch rounds over the
         // cluster count it last read (a round past the end of the build copies the clusters left) and only then synchronises:
         // 6 read-backs for a million primitives instead of 44.  With cells the rounds end when every cell is down to one cluster.
         constexpr int kRoundsPerBatch = 8;
         while (m > n_cells) {
+            if (!split && m <= kSmallClusters) {                 // the last rounds: one workgroup, one launch
+                hipLaunchKernelGGL(k_ploc_small, dim3(1), dim3(1024), 0, s, a, cl_in, cl_out, 1u);
+                B_TRY(hipGetLastError());
+                B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
+                B_TRY(hipStreamSynchronize(s));
+                if (h.m_cur != 1u) { res.error = hipErrorUnknown; res.where = "PLOC made no progress"; goto done; }
+                res.ploc_rounds += h.small_rounds; m = 1u; root = h.root; small_tail = true;
+                break;
+            }
             for (int k = 0; k < kRoundsPerBatch; ++k) {
                 hipLaunchKernelGGL(k_ploc_nn, dim3(blocks(m, 256)), dim3(256), 0, s, a, cl_in);
                 hipLaunchKernelGGL(k_ploc_flags, dim3(blocks(m, 256)), dim3(256), 0, s, a, m);
@@ -620,7 +761,6 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
             B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
             B_TRY(hipStreamSynchronize(s));
             if (h.m_cur >= m) { res.error = hipErrorUnknown; res.where = "PLOC made no progress"; goto done; }
-            for (int k = 0; k < kRoundsPerBatch; ++k) round_end.push_back(h.round_base[k]);
             m = h.m_cur;
         }
         if (m != n_cells) { res.error = hipErrorUnknown; res.where = "PLOC left fewer clusters than cells"; goto done; }
@@ -631,22 +771,17 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
             hipLaunchKernelGGL(k_top_link, dim3(blocks(sp.n_top, 256)), dim3(256), 0, s, a, sp.segs, sp.top_seg, cl_in, sp.n_top, node_base);
             B_TRY(hipGetLastError());
             root = node_base;
-        } else {
+        } else if (!small_tail) {
             B_TRY(hipMemcpyAsync(&root, cl_in, sizeof root, hipMemcpyDeviceToHost, s));
             B_TRY(hipStreamSynchronize(s));
         }
     }
-    // ---- cost tables: leaves, PLOC's rounds in order, the top-down phase's levels from the deepest up ----
-    hipLaunchKernelGGL(k_cost_range, dim3(blocks(nl, 256)), dim3(256), 0, s, a, 0u, nl, 1u);
-    {
-        uint32_t prev = nl;
-        for (uint32_t e : round_end) { if (e > prev) hipLaunchKernelGGL(k_cost_range, dim3(blocks(e - prev, 256)), dim3(256), 0, s, a, prev, e - prev, 0u); prev = e; }
-        if (split && sp.n_top)
-            for (size_t l = sp.top_level_begin.size() - 1; l-- > 0;) {
-                const uint32_t b0 = sp.top_level_begin[l], cnt = sp.top_level_begin[l + 1] - b0;
-                if (cnt) hipLaunchKernelGGL(k_cost_range, dim3(blocks(cnt, 256)), dim3(256), 0, s, a, node_base + b0, cnt, 0u);
-            }
-    }
+    // ---- cost tables: the leaves' and PLOC's nodes' were computed where the nodes were made; the top-down phase's levels from the deepest up ----
+    if (split && sp.n_top)
+        for (size_t l = sp.top_level_begin.size() - 1; l-- > 0;) {
+            const uint32_t b0 = sp.top_level_begin[l], cnt = sp.top_level_begin[l + 1] - b0;
+            if (cnt) hipLaunchKernelGGL(k_cost_range, dim3(blocks(cnt, 256)), dim3(256), 0, s, a, node_base + b0, cnt, 0u);
+        }
     B_TRY(hipGetLastError());
     // ---- emission, level by level ----
     {

@@ -963,7 +963,7 @@ def test_device_build_degenerate_geometry(hrt, oracle, gpu_available, monkeypatc
     if not gpu_available:
         pytest.skip("no GPU")
     rng = np.random.default_rng(11)
-    scene = hrt.scenes.mixed_test_scene(1500, 30, 21, 96, 64, 2)
+    scene = hrt.scenes.mixed_test_scene(6000, 30, 21, 96, 64, 2)         # (above 4096 primitives, so that HRT_CTX_FAST_TRACE does split on the device)
     tri = [it for it in scene["instances"] if it["geometry"] == "triangles"][0]
     v = tri["vertices"].reshape(-1, 9).copy()
     v[5, 3] = np.nan; v[17, 0] = np.inf; v[40, 8] = -np.inf               # non-finite primitives
@@ -1187,13 +1187,13 @@ def test_fast_trace_tree_with_spatial_splits(hrt, oracle, gpu_available, monkeyp
         got = oracle.bvh8_trace(blob.nodes, blob.triangles, o, d)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[3], want[3])      # distance and primitive: the tree loses nothing
         r.lib.hrt_host_free(C.byref(blob))
-        scene2 = hrt.scenes.mixed_test_scene(4000, 30, 5, w, h, spp)
+        scene2 = hrt.scenes.mixed_test_scene(6000, 30, 5, w, h, spp)        # (above 4096 primitives: below, the device leaves the splits out)
         r.load_scene(scene2)
         _moved_scene_matches_oracle(hrt, oracle, r, scene2, w, h, 4, spp)
         moved = [it["transform"].copy() for it in scene2["instances"]]
         moved[0][3] += 0.1
         before = r.stats()
-        assert before.bvh_bytes - before.bvh_nodes * 80 > (4000 + 30) * 48          # this tree has split references too
+        assert before.bvh_bytes - before.bvh_nodes * 80 > (6000 + 30) * 48          # this tree has split references too
         r.update_instances(moved)
         after = r.stats()
         assert after.tlas_rebuilds == before.tlas_rebuilds + 1      # a tree with split references is not refitted: the update rebuilds (device build)
