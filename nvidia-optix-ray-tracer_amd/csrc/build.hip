@@ -279,8 +279,7 @@ __global__ __launch_bounds__(256) void k_ploc_apply(GpuBuildArgs a, const uint32
 // Few clusters (the whole of a small build, the last dozen rounds of a large one): ONE workgroup runs every remaining round, a barrier
 // where the large build has a launch -- a round of six launches costs 30 us of host time whatever its size.  Same arithmetic and the
 // same tie rules as k_ploc_nn / _flags / _apply, so a build is the same tree whichever kernels ran its rounds.
-constexpr uint32_t kSmallItems = 16u;                            // clusters per thread
-constexpr uint32_t kSmallClusters = 1024u * kSmallItems;
+constexpr uint32_t kSmallClusters = 16384u;
 __global__ __launch_bounds__(1024) void k_ploc_small(GpuBuildArgs a, uint32_t *cl_a, uint32_t *cl_b, uint32_t n_cells) {
     typedef hipcub::BlockScan<uint64_t, 1024> Scan;
     __shared__ typename Scan::TempStorage tmp;
@@ -290,10 +289,8 @@ __global__ __launch_bounds__(1024) void k_ploc_small(GpuBuildArgs a, uint32_t *c
     const int radius = a.ploc_radius;
     uint32_t rounds = 0u;
     while (m > n_cells) {
-        // nearest neighbours
-        for (uint32_t q = 0; q < kSmallItems; ++q) {
-            const uint32_t i = threadIdx.x * kSmallItems + q;
-            if (i >= m) break;
+        // nearest neighbours: a cluster per thread, tile after tile
+        for (uint32_t i = threadIdx.x; i < m; i += 1024u) {
             const uint32_t me = cin[i];
             const float4 mlo = a.node_lo[me], mhi = a.node_hi[me];
             const uint32_t my_cell = a.node_cell ? a.node_cell[me] : 0u;
@@ -309,26 +306,25 @@ __global__ __launch_bounds__(1024) void k_ploc_small(GpuBuildArgs a, uint32_t *c
             a.nn[i] = bj;
         }
         __syncthreads();
-        // flags, scan, apply
-        uint64_t f[kSmallItems], e[kSmallItems], total;
-        for (uint32_t q = 0; q < kSmallItems; ++q) {
-            const uint32_t i = threadIdx.x * kSmallItems + q;
-            uint64_t v = 0ull;
+        // flags, scan (tiles of 1024 clusters, the running totals carried from tile to tile), apply
+        uint64_t run = 0ull;
+        for (uint32_t base = 0; base < m; base += 1024u) {
+            const uint32_t i = base + threadIdx.x;
+            uint64_t f = 0ull, e, total;
+            uint32_t j = kNone;
             if (i < m) {
-                const uint32_t j = a.nn[i];
+                j = a.nn[i];
                 const bool mutual = j != kNone && a.nn[j] == i;
-                v = 1ull << 32;
-                if (mutual) v = i < j ? ((1ull << 32) | 1ull) : 0ull;
+                f = 1ull << 32;
+                if (mutual) f = i < j ? ((1ull << 32) | 1ull) : 0ull;
             }
-            f[q] = v;
-        }
-        Scan(tmp).ExclusiveSum(f, e, total);
-        for (uint32_t q = 0; q < kSmallItems; ++q) {
-            const uint32_t i = threadIdx.x * kSmallItems + q;
-            if (i >= m || (f[q] >> 32) == 0ull) continue;
-            const uint32_t pos = (uint32_t)(e[q] >> 32);
-            if ((f[q] & 1ull) == 0ull) { cout[pos] = cin[i]; continue; }
-            const uint32_t l = cin[i], r = cin[a.nn[i]], id = node_base + (uint32_t)(e[q] & 0xffffffffu);
+            Scan(tmp).ExclusiveSum(f, e, total);
+            __syncthreads();
+            e += run; run += total;
+            if (i >= m || (f >> 32) == 0ull) continue;
+            const uint32_t pos = (uint32_t)(e >> 32);
+            if ((f & 1ull) == 0ull) { cout[pos] = cin[i]; continue; }
+            const uint32_t l = cin[i], r = cin[j], id = node_base + (uint32_t)(e & 0xffffffffu);
             const float4 llo = a.node_lo[l], lhi = a.node_hi[l], rlo = a.node_lo[r], rhi = a.node_hi[r];
             a.node_lo[id] = make_float4(fminf(llo.x, rlo.x), fminf(llo.y, rlo.y), fminf(llo.z, rlo.z), __uint_as_float(l));
             a.node_hi[id] = make_float4(fmaxf(lhi.x, rhi.x), fmaxf(lhi.y, rhi.y), fmaxf(lhi.z, rhi.z), __uint_as_float(r));
@@ -339,10 +335,10 @@ __global__ __launch_bounds__(1024) void k_ploc_small(GpuBuildArgs a, uint32_t *c
         }
         __threadfence_block();
         __syncthreads();
-        const uint32_t merges = (uint32_t)(total & 0xffffffffull);
+        const uint32_t merges = (uint32_t)(run & 0xffffffffull);
         ++rounds;
         uint32_t *t2 = cin; cin = cout; cout = t2;
-        m = (uint32_t)(total >> 32); node_base += merges;
+        m = (uint32_t)(run >> 32); node_base += merges;
         if (merges == 0u) break;                                 // (cannot happen while a cell holds two clusters; never loop forever)
     }
     if (threadIdx.x == 0u) { c->m_cur = m; c->m_next = m; c->node_base = node_base; c->merges = 0u; c->root = m ? cin[0] : kNone; c->small_rounds = rounds; c->cl_in_b = cin == cl_b ? 1u : 0u; }
@@ -405,113 +401,132 @@ __device__ __forceinline__ bool first_of_its_prim(const uint32_t *gk, int w) {
     return true;
 }
 
-__device__ void emit_item(const GpuBuildArgs &a, uint32_t b2, uint32_t self, uint2 *__restrict__ items_next, uint32_t next_level_begin, uint32_t is_root_level) {
-    const float4 nlo = a.node_lo[b2], nhi = a.node_hi[b2];
-    Forest f;
+// One BVH8 node.  Eight lanes of a wave call this together, one per child slot (lane & 7 = slot): the forest and the slot assignment
+// are computed by all of them alike, then every lane walks, counts and writes ITS child -- a thread that did the eight children one
+// after the other spent ~100 us in some two hundred dependent loads, and a level cannot start before the one above is done.
+// (live: the group has an item; dead groups go through the shuffles without touching memory)
+__device__ void emit_item(const GpuBuildArgs &a, uint32_t b2, uint32_t self, uint2 *__restrict__ items_next, uint32_t next_level_begin, uint32_t is_root_level, bool live) {
+    const int lane = (int)(threadIdx.x & 63u), g0 = lane & ~7, s = lane & 7;
+    Forest f; f.n = 0;
     bool ch_leaf[8];
-    const bool node_is_leaf2 = __float_as_uint(nlo.w) == kNone;
-    if (node_is_leaf2 || (is_root_level && a.node_nprims[b2] <= a.max_leaf_prims)) {
-        f.n = 1; f.node[0] = b2; ch_leaf[0] = true;              // the whole scene fits one leaf: wrap it
-    } else {
-        collect_forest(a, b2, f);
-        for (int k = 0; k < f.n; ++k) {
-            const uint32_t c = f.node[k];
-            ch_leaf[k] = __float_as_uint(a.node_lo[c].w) == kNone || (__float_as_uint(a.cost[8 * (size_t)c]) & 1u);
-        }
-    }
-    // slot assignment: slot s is visited first by rays of octant s (bit2 = -x, bit1 = -y, bit0 = -z): greedy, as the host builder
-    float cost[8][8];
-    const float ncx[3] = {0.5f * (nlo.x + nhi.x), 0.5f * (nlo.y + nhi.y), 0.5f * (nlo.z + nhi.z)};
-    for (int k = 0; k < f.n; ++k) {
-        const float4 lo = a.node_lo[f.node[k]], hi = a.node_hi[f.node[k]];
-        const float d[3] = {0.5f * (lo.x + hi.x) - ncx[0], 0.5f * (lo.y + hi.y) - ncx[1], 0.5f * (lo.z + hi.z) - ncx[2]};
-        for (int s = 0; s < 8; ++s) {
-            const float sx = (s & 4) ? -1.0f : 1.0f, sy = (s & 2) ? -1.0f : 1.0f, sz = (s & 1) ? -1.0f : 1.0f;
-            cost[k][s] = d[0] * sx + d[1] * sy + d[2] * sz;
-        }
-    }
-    int slot_child[8]; bool child_done[8];
-    for (int s = 0; s < 8; ++s) { slot_child[s] = -1; child_done[s] = false; }
-    for (int round = 0; round < f.n; ++round) {
-        int bk = -1, bs = -1; float bc = INFINITY;
-        for (int k = 0; k < f.n; ++k) {
-            if (child_done[k]) continue;
-            for (int s = 0; s < 8; ++s) {
-                if (slot_child[s] >= 0) continue;
-                if (cost[k][s] < bc) { bc = cost[k][s]; bk = k; bs = s; }
+    int slot_child[8];
+    for (int q = 0; q < 8; ++q) { slot_child[q] = -1; ch_leaf[q] = false; f.node[q] = 0u; }
+    if (live) {
+        const float4 nlo = a.node_lo[b2], nhi = a.node_hi[b2];
+        const bool node_is_leaf2 = __float_as_uint(nlo.w) == kNone;
+        if (node_is_leaf2 || (is_root_level && a.node_nprims[b2] <= a.max_leaf_prims)) {
+            f.n = 1; f.node[0] = b2; ch_leaf[0] = true;              // the whole scene fits one leaf: wrap it
+        } else {
+            collect_forest(a, b2, f);
+            for (int k = 0; k < f.n; ++k) {
+                const uint32_t c = f.node[k];
+                ch_leaf[k] = __float_as_uint(a.node_lo[c].w) == kNone || (__float_as_uint(a.cost[8 * (size_t)c]) & 1u);
             }
         }
-        if (bk < 0) {   // NaN costs (degenerate boxes): first free pair
-            for (int k = 0; k < f.n && bk < 0; ++k) if (!child_done[k]) bk = k;
-            for (int s = 0; s < 8 && bs < 0; ++s) if (slot_child[s] < 0) bs = s;
+        // slot assignment: slot s is visited first by rays of octant s (bit2 = -x, bit1 = -y, bit0 = -z): greedy, as the host builder
+        float cost[8][8];
+        const float ncx[3] = {0.5f * (nlo.x + nhi.x), 0.5f * (nlo.y + nhi.y), 0.5f * (nlo.z + nhi.z)};
+        for (int k = 0; k < f.n; ++k) {
+            const float4 lo = a.node_lo[f.node[k]], hi = a.node_hi[f.node[k]];
+            const float d[3] = {0.5f * (lo.x + hi.x) - ncx[0], 0.5f * (lo.y + hi.y) - ncx[1], 0.5f * (lo.z + hi.z) - ncx[2]};
+            for (int q = 0; q < 8; ++q) {
+                const float sx = (q & 4) ? -1.0f : 1.0f, sy = (q & 2) ? -1.0f : 1.0f, sz = (q & 1) ? -1.0f : 1.0f;
+                cost[k][q] = d[0] * sx + d[1] * sy + d[2] * sz;
+            }
         }
-        slot_child[bs] = bk; child_done[bk] = true;
+        bool child_done[8];
+        for (int q = 0; q < 8; ++q) child_done[q] = false;
+        for (int round = 0; round < f.n; ++round) {
+            int bk = -1, bs = -1; float bc = INFINITY;
+            for (int k = 0; k < f.n; ++k) {
+                if (child_done[k]) continue;
+                for (int q = 0; q < 8; ++q) {
+                    if (slot_child[q] >= 0) continue;
+                    if (cost[k][q] < bc) { bc = cost[k][q]; bk = k; bs = q; }
+                }
+            }
+            if (bk < 0) {   // NaN costs (degenerate boxes): first free pair
+                for (int k = 0; k < f.n && bk < 0; ++k) if (!child_done[k]) bk = k;
+                for (int q = 0; q < 8 && bs < 0; ++q) if (slot_child[q] < 0) bs = q;
+            }
+            slot_child[bs] = bk; child_done[bk] = true;
+        }
     }
-    uint32_t n_inner = 0, n_leaf_prims = 0;
-    for (int s = 0; s < 8; ++s) {
-        const int k = slot_child[s];
-        if (k < 0) continue;
-        if (!ch_leaf[k]) { ++n_inner; continue; }
-        uint32_t gk[3], lf[3];
-        const int nr = leaf_refs(a, f.node[k], gk, lf);
-        for (int w = 0; w < nr; ++w) if (first_of_its_prim(gk, w)) ++n_leaf_prims;
+    // this lane's child
+    int k = -1;
+    for (int q = 0; q < 8; ++q) if (q == s) k = slot_child[q];
+    uint32_t c = 0u; bool leaf = false;
+    for (int q = 0; q < 8; ++q) if (q == k) { c = f.node[q]; leaf = ch_leaf[q]; }
+    uint32_t gks[3] = {0u, 0u, 0u}, lf[3] = {0u, 0u, 0u}; int nr = 0; uint32_t np = 0u;
+    if (k >= 0 && leaf) {
+        nr = leaf_refs(a, c, gks, lf);
+        for (int w = 0; w < nr; ++w) if (first_of_its_prim(gks, w)) ++np;
     }
-    const uint32_t child_base = n_inner ? atomicAdd(&a.counters->next_node, n_inner) : 0u;
-    const uint32_t prim_base = n_leaf_prims ? atomicAdd(&a.counters->next_prim, n_leaf_prims) : 0u;
+    const uint32_t inner = (k >= 0 && !leaf) ? 1u : 0u;
+    // the group's running counts: where this lane's records and its inner child go
+    uint32_t inc_np = np, inc_in = inner;
+    for (int off = 1; off < 8; off <<= 1) {
+        const uint32_t t1 = __shfl_up(inc_np, off, 8), t2 = __shfl_up(inc_in, off, 8);
+        if (s >= off) { inc_np += t1; inc_in += t2; }
+    }
+    const uint32_t n_leaf_prims = __shfl(inc_np, g0 + 7), n_inner = __shfl(inc_in, g0 + 7);
+    const uint32_t prim_off = inc_np - np, rank = inc_in - inner;
+    uint32_t child_base = 0u, prim_base = 0u;
+    if (live && s == 0) {
+        child_base = n_inner ? atomicAdd(&a.counters->next_node, n_inner) : 0u;
+        prim_base = n_leaf_prims ? atomicAdd(&a.counters->next_prim, n_leaf_prims) : 0u;
+    }
+    child_base = __shfl(child_base, g0); prim_base = __shfl(prim_base, g0);
+    const uint32_t imask = (uint32_t)((__ballot(inner != 0u) >> g0) & 0xffull);
+    if (!live) return;
 
     unsigned char *nd = a.out_nodes + (size_t)self * a.node_stride;
-    uint32_t meta_lo = 0u, meta_hi = 0u, imask = 0u, prim_off = 0u, rank = 0u;
-    for (int s = 0; s < 8; ++s) {
-        const int k = slot_child[s];
-        uint32_t meta = 0u;
-        if (k >= 0) {
-            const uint32_t c = f.node[k];
-            if (ch_leaf[k]) {
-                uint32_t gks[3], lf[3];
-                const int nr = leaf_refs(a, c, gks, lf);
-                uint32_t np = 0u;
-                for (int w = 0; w < nr; ++w) {
-                    if (!first_of_its_prim(gks, w)) continue;
-                    const uint32_t gk = gks[w];                                     // global primitive number
-                    const uint32_t inst = find_instance(a.inst_first, a.n_inst, gk), p = gk - a.inst_first[inst];
-                    uint32_t *rec = reinterpret_cast<uint32_t *>(a.out_prims + (size_t)(prim_base + prim_off + np) * a.prim_stride);
-                    const uint32_t kind = a.inst_kind[inst];
-                    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, b0 = 0.0f;
-                    if (kind == kPrimKindSphere) {
-                        const float *src = reinterpret_cast<const float *>(a.inst_src[inst]) + 4 * (size_t)p;
-                        a0 = src[0]; a1 = src[1]; a2 = src[2]; b0 = src[3];
-                    }
-                    rec[0] = __float_as_uint(a0); rec[1] = __float_as_uint(a1); rec[2] = __float_as_uint(a2); rec[3] = p;
-                    rec[4] = __float_as_uint(b0); rec[5] = 0u; rec[6] = 0u; rec[7] = inst;
-                    rec[8] = 0u; rec[9] = 0u; rec[10] = 0u; rec[11] = kind;
-                    if (a.out_clip) {       // the box the refit takes for this record: the reference's (the union of its pieces in this leaf)
-                        float4 lo = a.node_lo[lf[w]], hi = a.node_hi[lf[w]];
-                        for (int u = w + 1; u < nr; ++u)
-                            if (gks[u] == gk) {
-                                const float4 l2 = a.node_lo[lf[u]], h2 = a.node_hi[lf[u]];
-                                lo.x = fminf(lo.x, l2.x); lo.y = fminf(lo.y, l2.y); lo.z = fminf(lo.z, l2.z);
-                                hi.x = fmaxf(hi.x, h2.x); hi.y = fmaxf(hi.y, h2.y); hi.z = fmaxf(hi.z, h2.z);
-                            }
-                        float *cb = a.out_clip + 6 * (size_t)(prim_base + prim_off + np);
-                        cb[0] = lo.x; cb[1] = lo.y; cb[2] = lo.z; cb[3] = hi.x; cb[4] = hi.y; cb[5] = hi.z;
-                    }
-                    ++np;
-                }
-                meta = (((1u << np) - 1u) << 5) | prim_off;
-                prim_off += np;
-            } else {
-                meta = 0x20u | (24u + (uint32_t)s);
-                imask |= 1u << s;
-                const uint32_t out = child_base + rank++;
-                items_next[out - next_level_begin] = make_uint2(c, out);
+    uint32_t meta = 0u;
+    if (k >= 0 && leaf) {
+        uint32_t w_out = 0u;
+        uint32_t last_inst = 0u;
+        for (int w = 0; w < nr; ++w) {
+            if (!first_of_its_prim(gks, w)) continue;
+            const uint32_t gk = gks[w];                                     // global primitive number
+            // (the primitives of a leaf are mostly of one instance: look there before the binary search)
+            const uint32_t inst = (gk >= a.inst_first[last_inst] && gk < a.inst_first[last_inst + 1u]) ? last_inst : find_instance(a.inst_first, a.n_inst, gk);
+            last_inst = inst;
+            const uint32_t p = gk - a.inst_first[inst];
+            uint32_t *rec = reinterpret_cast<uint32_t *>(a.out_prims + (size_t)(prim_base + prim_off + w_out) * a.prim_stride);
+            const uint32_t kind = a.inst_kind[inst];
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, b0 = 0.0f;
+            if (kind == kPrimKindSphere) {
+                const float *src = reinterpret_cast<const float *>(a.inst_src[inst]) + 4 * (size_t)p;
+                a0 = src[0]; a1 = src[1]; a2 = src[2]; b0 = src[3];
             }
+            rec[0] = __float_as_uint(a0); rec[1] = __float_as_uint(a1); rec[2] = __float_as_uint(a2); rec[3] = p;
+            rec[4] = __float_as_uint(b0); rec[5] = 0u; rec[6] = 0u; rec[7] = inst;
+            rec[8] = 0u; rec[9] = 0u; rec[10] = 0u; rec[11] = kind;
+            if (a.out_clip) {       // the box the refit takes for this record: the reference's (the union of its pieces in this leaf)
+                float4 lo = a.node_lo[lf[w]], hi = a.node_hi[lf[w]];
+                for (int u = w + 1; u < nr; ++u)
+                    if (gks[u] == gk) {
+                        const float4 l2 = a.node_lo[lf[u]], h2 = a.node_hi[lf[u]];
+                        lo.x = fminf(lo.x, l2.x); lo.y = fminf(lo.y, l2.y); lo.z = fminf(lo.z, l2.z);
+                        hi.x = fmaxf(hi.x, h2.x); hi.y = fmaxf(hi.y, h2.y); hi.z = fmaxf(hi.z, h2.z);
+                    }
+                float *cb = a.out_clip + 6 * (size_t)(prim_base + prim_off + w_out);
+                cb[0] = lo.x; cb[1] = lo.y; cb[2] = lo.z; cb[3] = hi.x; cb[4] = hi.y; cb[5] = hi.z;
+            }
+            ++w_out;
         }
-        if (s < 4) meta_lo |= meta << (8 * s); else meta_hi |= meta << (8 * (s - 4));
+        meta = (((1u << np) - 1u) << 5) | prim_off;
+    } else if (k >= 0) {
+        meta = 0x20u | (24u + (uint32_t)s);
+        const uint32_t out = child_base + rank;
+        items_next[out - next_level_begin] = make_uint2(c, out);
     }
+    nd[24 + s] = (unsigned char)meta;
+    if (s != 0) return;
     uint32_t *w32 = reinterpret_cast<uint32_t *>(nd);
     // origin / exponents / quantised boxes are the refit's to fill in; a valid empty encoding meanwhile
     w32[0] = 0u; w32[1] = 0u; w32[2] = 0u; w32[3] = (imask << 24) | 0x007f7f7fu;
-    w32[4] = child_base; w32[5] = prim_base; w32[6] = meta_lo; w32[7] = meta_hi;
+    w32[4] = child_base; w32[5] = prim_base;
     for (int q = 8; q < 14; ++q) w32[q] = 0xffffffffu;           // qlo = 255
     for (int q = 14; q < 20; ++q) w32[q] = 0u;                   // qhi = 0
     // refit quality weight: primitives below this node (normalised afterwards)
@@ -522,9 +537,10 @@ __device__ void emit_item(const GpuBuildArgs &a, uint32_t b2, uint32_t self, uin
 
 __global__ __launch_bounds__(128) void k_emit_level(GpuBuildArgs a, const uint2 *__restrict__ items, uint32_t n_items, uint2 *__restrict__ items_next,
                                                     uint32_t next_level_begin, uint32_t is_root_level) {
-    const uint32_t t = blockIdx.x * 128u + threadIdx.x;
-    if (t >= n_items) return;
-    emit_item(a, items[t].x, items[t].y, items_next, next_level_begin, is_root_level);
+    const uint32_t t = blockIdx.x * 16u + (threadIdx.x >> 3);       // eight lanes per item
+    const bool live = t < n_items;
+    const uint2 it = items[live ? t : 0u];
+    emit_item(a, it.x, it.y, items_next, next_level_begin, is_root_level, live);
 }
 
 // a small tree: every level by one workgroup, no trip to the host in between (level_begin goes back with the counters)
@@ -538,7 +554,12 @@ __global__ __launch_bounds__(1024) void k_emit_small(GpuBuildArgs a, uint2 *item
     uint32_t level_begin = 0u, count = 1u, depth = 0u;
     while (count > 0u) {
         const uint32_t next_begin = level_begin + count;
-        for (uint32_t t = threadIdx.x; t < count; t += 1024u) emit_item(a, in[t].x, in[t].y, out, next_begin, depth == 0u ? 1u : 0u);
+        for (uint32_t base = 0; base < count; base += 128u) {          // eight lanes per item, 128 items at a time
+            const uint32_t t = base + (threadIdx.x >> 3);
+            const bool live = t < count;
+            const uint2 it = in[live ? t : 0u];
+            emit_item(a, it.x, it.y, out, next_begin, depth == 0u ? 1u : 0u, live);
+        }
         __threadfence();
         __syncthreads();
         if (threadIdx.x == 0u) {
@@ -792,7 +813,7 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
         res.level_begin.push_back(0u);
         while (level_count > 0u) {
             const uint32_t next_begin = level_begin + level_count;
-            hipLaunchKernelGGL(k_emit_level, dim3(blocks(level_count, 128)), dim3(128), 0, s, a, it_in, level_count, it_out, next_begin, depth == 0 ? 1u : 0u);
+            hipLaunchKernelGGL(k_emit_level, dim3(blocks(level_count, 16)), dim3(128), 0, s, a, it_in, level_count, it_out, next_begin, depth == 0 ? 1u : 0u);
             B_TRY(hipGetLastError());
             B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
             B_TRY(hipStreamSynchronize(s));

@@ -58,25 +58,76 @@ void scratch_release(HrtContext *ctx, ScratchArena a) {
     if (drop.p) (void)hipFree(drop.p);
 }
 
-void free_tlas_device(Tlas &t) {
-    if (t.d_nodes) (void)hipFree(t.d_nodes);
-    if (t.d_prims) (void)hipFree(t.d_prims);
-    if (t.d_inst_inv) (void)hipFree(t.d_inst_inv);
-    if (t.d_inst_identity) (void)hipFree(t.d_inst_identity);
-    if (t.d_node_box) (void)hipFree(t.d_node_box);
-    if (t.d_node_ref) (void)hipFree(t.d_node_ref);
-    if (t.d_order) (void)hipFree(t.d_order);
-    if (t.d_inst_xf) (void)hipFree(t.d_inst_xf);
-    if (t.d_area) (void)hipFree(t.d_area);
-    if (t.d_inst_src) (void)hipFree((void *)t.d_inst_src);
-    if (t.d_inst_first) (void)hipFree(t.d_inst_first);
-    if (t.d_inst_kind) (void)hipFree(t.d_inst_kind);
+// Device memory of the trees (nodes, records, a dozen small per-instance tables), kept by the context when a tree is freed and handed
+// out again to the next build: an update that rebuilds (every file's first frame in the reference's Time mode) otherwise spends more
+// time in ~20 hipMalloc / hipFree pairs -- each hipFree waits for the device -- than in its kernels.  Eight size classes per octave;
+// blocks above 64 MiB and anything beyond 1 GiB in all go back to the runtime.
+static size_t pool_class(size_t bytes) {
+    bytes = std::max<size_t>(bytes, 256);
+    size_t p2 = 256;
+    while (p2 * 2 <= bytes) p2 *= 2;
+    const size_t step = p2 / 8;
+    return (bytes + step - 1) / step * step;
+}
+hipError_t pool_alloc(HrtContext *ctx, void **p, size_t bytes) {
+    const size_t cls = pool_class(bytes);
+    {
+        std::lock_guard<std::mutex> lk(ctx->pool_mu);
+        for (size_t i = 0; i < ctx->pool_free.size(); ++i)
+            if (ctx->pool_free[i].bytes == cls) {
+                *p = ctx->pool_free[i].p;
+                ctx->pool_free.erase(ctx->pool_free.begin() + (long)i);
+                ctx->pool_bytes -= cls; ctx->pool_live[*p] = cls;
+                return hipSuccess;
+            }
+    }
+    const hipError_t e = hipMalloc(p, cls);
+    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(ctx->pool_mu); ctx->pool_live[*p] = cls; }
+    return e;
+}
+// (the caller has made sure the device is done with the block)
+void pool_release(HrtContext *ctx, void *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(ctx->pool_mu);
+        const auto it = ctx->pool_live.find(p);
+        if (it != ctx->pool_live.end()) {
+            const size_t bytes = it->second;
+            ctx->pool_live.erase(it);
+            if (bytes <= ((size_t)64 << 20) && ctx->pool_bytes + bytes <= ((size_t)1 << 30) && ctx->pool_free.size() < 512) {
+                ctx->pool_free.push_back({p, bytes}); ctx->pool_bytes += bytes;
+                return;
+            }
+        }
+    }
+    (void)hipFree(p);
+}
+void pool_drain(HrtContext *ctx) {
+    std::vector<ScratchArena> blocks;
+    { std::lock_guard<std::mutex> lk(ctx->pool_mu); blocks.swap(ctx->pool_free); ctx->pool_bytes = 0; }
+    for (const ScratchArena &b : blocks) (void)hipFree(b.p);
+}
+
+void free_tlas_device(HrtContext *ctx, Tlas &t) {
+    if (t.d_nodes || t.d_prims || t.d_inst_inv || t.d_inst_xf) (void)hipDeviceSynchronize();      // (what each hipFree used to do; the blocks go to the context's pool)
+    pool_release(ctx, (void *)t.d_nodes);
+    pool_release(ctx, (void *)t.d_prims);
+    pool_release(ctx, (void *)t.d_inst_inv);
+    pool_release(ctx, (void *)t.d_inst_identity);
+    pool_release(ctx, (void *)t.d_node_box);
+    pool_release(ctx, (void *)t.d_node_ref);
+    pool_release(ctx, (void *)t.d_order);
+    pool_release(ctx, (void *)t.d_inst_xf);
+    pool_release(ctx, (void *)t.d_area);
+    pool_release(ctx, (void *)t.d_inst_src);
+    pool_release(ctx, (void *)t.d_inst_first);
+    pool_release(ctx, (void *)t.d_inst_kind);
     t.d_inst_first = t.d_inst_kind = nullptr;
-    if (t.d_sig_handle) (void)hipFree(t.d_sig_handle);
-    if (t.d_sig_visibility) (void)hipFree(t.d_sig_visibility);
-    if (t.d_sig_sbt) (void)hipFree(t.d_sig_sbt);
-    if (t.d_blas_box) (void)hipFree(t.d_blas_box);
-    if (t.d_update_flags) (void)hipFree(t.d_update_flags);
+    pool_release(ctx, (void *)t.d_sig_handle);
+    pool_release(ctx, (void *)t.d_sig_visibility);
+    pool_release(ctx, (void *)t.d_sig_sbt);
+    pool_release(ctx, (void *)t.d_blas_box);
+    pool_release(ctx, (void *)t.d_update_flags);
     t.d_sig_handle = nullptr; t.d_sig_visibility = nullptr; t.d_sig_sbt = nullptr; t.d_blas_box = nullptr; t.d_update_flags = nullptr;
     t.d_nodes = t.d_prims = nullptr; t.d_inst_inv = nullptr; t.d_inst_identity = nullptr;
     t.d_node_box = t.d_node_ref = t.d_inst_xf = t.d_area = nullptr; t.d_inst_src = nullptr; t.d_order = nullptr;
@@ -325,7 +376,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
     if (!on_device && 2 * t.bvh.max_depth + 2 > (uint32_t)(8 + 56))
         return fail(ctx, HRT_ERR_INVALID, "BVH depth %u exceeds the traversal stack", t.bvh.max_depth);
 
-    free_tlas_device(t);
+    free_tlas_device(ctx, t);
     t.n_instances = n;
     t.blas_refs = std::move(refs);
     t.node_stride = (uint32_t)ctx->node_stride; t.prim_stride = (uint32_t)ctx->prim_stride;
@@ -337,18 +388,18 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
     const size_t pb = (size_t)t.prim_stride * std::max<size_t>(n_prims, 1);
     std::vector<const void *> src(std::max(n, 1u), nullptr);
     for (uint32_t i = 0; i < n; ++i) src[i] = t.blas_refs[i]->d_verts;
-    if (!on_device) HIP_TRY(ctx, hipMalloc(&t.d_nodes, nb));
-    if (!(on_device && device_split)) HIP_TRY(ctx, hipMalloc(&t.d_prims, pb));      // (a split build knows its record count afterwards)
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_inv, sizeof(float) * t.h_inv.size()));
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_xf, sizeof(float) * t.h_xf.size()));
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_identity, sizeof(uint32_t) * t.h_ident.size()));
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_src, sizeof(void *) * src.size()));
+    if (!on_device) HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_nodes, nb));
+    if (!(on_device && device_split)) HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_prims, pb));      // (a split build knows its record count afterwards)
+    HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_inv, sizeof(float) * t.h_inv.size()));
+    HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_xf, sizeof(float) * t.h_xf.size()));
+    HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_identity, sizeof(uint32_t) * t.h_ident.size()));
+    HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_src, sizeof(void *) * src.size()));
     if (!on_device) {
-        HIP_TRY(ctx, hipMalloc((void **)&t.d_node_box, sizeof(float) * std::max<size_t>(6 * n_nodes, 6)));
-        HIP_TRY(ctx, hipMalloc((void **)&t.d_node_ref, sizeof(float) * std::max<size_t>(2 * n_nodes, 2)));
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_node_box, sizeof(float) * std::max<size_t>(6 * n_nodes, 6)));
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_node_ref, sizeof(float) * std::max<size_t>(2 * n_nodes, 2)));
     }
-    HIP_TRY(ctx, hipMalloc((void **)&t.d_area, sizeof(float)));
-    if (!order.empty()) HIP_TRY(ctx, hipMalloc((void **)&t.d_order, sizeof(uint32_t) * order.size()));
+    HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_area, sizeof(float)));
+    if (!order.empty()) HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_order, sizeof(uint32_t) * order.size()));
     if (!t.h_area) HIP_TRY(ctx, hipHostMalloc((void **)&t.h_area, sizeof(float), hipHostMallocDefault));
     if (!t.area_ready) HIP_TRY(ctx, hipEventCreateWithFlags(&t.area_ready, hipEventDisableTiming));
     HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_inv, t.h_inv.data(), sizeof(float) * t.h_inv.size(), hipMemcpyHostToDevice, s));
@@ -360,11 +411,11 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         for (uint32_t i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) { bbox[6 * (size_t)i + a] = t.blas_refs[i]->lo[a]; bbox[6 * (size_t)i + 3 + a] = t.blas_refs[i]->hi[a]; }
         std::vector<unsigned long long> sigh(std::max(n, 1u), 0ull);
         for (uint32_t i = 0; i < n; ++i) sigh[i] = t.sig_handle[i];
-        HIP_TRY(ctx, hipMalloc((void **)&t.d_sig_handle, sizeof(unsigned long long) * sigh.size()));
-        HIP_TRY(ctx, hipMalloc((void **)&t.d_sig_visibility, sizeof(uint32_t) * std::max(n, 1u)));
-        HIP_TRY(ctx, hipMalloc((void **)&t.d_sig_sbt, sizeof(uint32_t) * std::max(n, 1u)));
-        HIP_TRY(ctx, hipMalloc((void **)&t.d_blas_box, sizeof(float) * bbox.size()));
-        HIP_TRY(ctx, hipMalloc((void **)&t.d_update_flags, sizeof(uint32_t) * 2));
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_sig_handle, sizeof(unsigned long long) * sigh.size()));
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_sig_visibility, sizeof(uint32_t) * std::max(n, 1u)));
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_sig_sbt, sizeof(uint32_t) * std::max(n, 1u)));
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_blas_box, sizeof(float) * bbox.size()));
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_update_flags, sizeof(uint32_t) * 2));
         if (!t.h_update_flags) HIP_TRY(ctx, hipHostMalloc((void **)&t.h_update_flags, sizeof(uint32_t) * 4, hipHostMallocDefault));
         t.h_update_flags[0] = t.h_update_flags[2] = 0x3f800000u; t.h_update_flags[1] = t.h_update_flags[3] = 0u;
         HIP_TRY(ctx, hipMemcpyAsync(t.d_sig_handle, sigh.data(), sizeof(unsigned long long) * sigh.size(), hipMemcpyHostToDevice, s));
@@ -380,8 +431,8 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
     ra.inst_src = t.d_inst_src; ra.pad = 4e-6f * std::max(1.0f, scene_scale); ra.write_reference = 1u;
     if (on_device) {
         // ---- the device build (build.hip): topology and primitive ids; the refit below computes everything else ----
-        HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_first, sizeof(uint32_t) * first.size()));
-        HIP_TRY(ctx, hipMalloc((void **)&t.d_inst_kind, sizeof(uint32_t) * std::max(n, 1u)));
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_first, sizeof(uint32_t) * first.size()));
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_kind, sizeof(uint32_t) * std::max(n, 1u)));
         HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_first, first.data(), sizeof(uint32_t) * first.size(), hipMemcpyHostToDevice, s));
         HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_kind, t.kind.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
         GpuBuildInput in{};
@@ -408,13 +459,13 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         if (r.error != hipSuccess) return fail(ctx, r.error == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, "device build failed: %s (%s)", hipGetErrorString(r.error), r.where);
         {   // the tree's own buffers, as large as the build turned out to need
             const size_t nn = std::max<size_t>(r.n_prims ? r.n_nodes : 1u, 1u);
-            HIP_TRY(ctx, hipMalloc(&t.d_nodes, (size_t)t.node_stride * nn));
-            HIP_TRY(ctx, hipMalloc((void **)&t.d_node_box, sizeof(float) * 6 * nn));
-            HIP_TRY(ctx, hipMalloc((void **)&t.d_node_ref, sizeof(float) * 2 * nn));
+            HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_nodes, (size_t)t.node_stride * nn));
+            HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_node_box, sizeof(float) * 6 * nn));
+            HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_node_ref, sizeof(float) * 2 * nn));
             size_t rec_bytes = pb;
             if (device_split) {
                 rec_bytes = (size_t)t.prim_stride * std::max<size_t>(r.n_records, 1);
-                HIP_TRY(ctx, hipMalloc(&t.d_prims, rec_bytes));
+                HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_prims, rec_bytes));
                 ra.prims = reinterpret_cast<unsigned char *>(t.d_prims);
                 if (r.n_records) HIP_TRY(ctx, hipMemcpyAsync(t.d_prims, in.out_prims, (size_t)t.prim_stride * r.n_records, hipMemcpyDeviceToDevice, s));
             }
@@ -492,12 +543,20 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
 // valid and traceable -- instead of half overwritten.
 int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s, bool instanced, bool fast_trace = false) {
     Tlas fresh;
+    // (the pinned host words and the event move to the new tree: hipHostMalloc / hipHostFree are as slow as their device counterparts)
+    if (t.area_ready && t.area_pending) (void)hipEventSynchronize(t.area_ready);
+    fresh.h_area = t.h_area; fresh.h_update_flags = t.h_update_flags; fresh.area_ready = t.area_ready;
+    t.h_area = nullptr; t.h_update_flags = nullptr; t.area_ready = nullptr;
     const int rc = build_tlas_fresh(ctx, fresh, inst, s, instanced, fast_trace);
-    if (rc != HRT_OK) { free_tlas_device(fresh); free_tlas_host(fresh); return rc; }
+    if (rc != HRT_OK) {
+        t.h_area = fresh.h_area; t.h_update_flags = fresh.h_update_flags; t.area_ready = fresh.area_ready;
+        fresh.h_area = nullptr; fresh.h_update_flags = nullptr; fresh.area_ready = nullptr;
+        free_tlas_device(ctx, fresh); free_tlas_host(fresh); return rc;
+    }
     fresh.generation = t.generation + 1;
     fresh.refits = t.refits; fresh.rebuilds = t.rebuilds + 1;
     std::swap(t, fresh);
-    free_tlas_device(fresh); free_tlas_host(fresh);        // the old tree
+    free_tlas_device(ctx, fresh); free_tlas_host(fresh);        // the old tree
     ctx->tlas_rebuilds++;
     return HRT_OK;
 }
@@ -612,7 +671,7 @@ int hrt_tlas_build(HrtContext *ctx, const HrtInstance *d_instances, uint32_t n, 
     std::vector<HrtInstance> inst;
     int rc = download_instances(ctx, d_instances, n, (hipStream_t)stream, inst);
     if (rc == HRT_OK) rc = build_tlas_into(ctx, *t, inst, (hipStream_t)stream, ctx->tlas_instanced > 0, (ctx->flags & HRT_CTX_FAST_TRACE) != 0);
-    if (rc != HRT_OK) { free_tlas_device(*t); free_tlas_host(*t); return rc; }
+    if (rc != HRT_OK) { free_tlas_device(ctx, *t); free_tlas_host(*t); return rc; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const uint64_t h = ctx->next_handle++;
     ctx->tlas[h] = std::move(t);
@@ -753,7 +812,7 @@ int hrt_tlas_destroy(HrtContext *ctx, HrtTraversable tlas) {
     auto it = ctx->tlas.find(tlas);
     if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "unknown TLAS handle");
     (void)hipDeviceSynchronize();
-    free_tlas_device(*it->second); free_tlas_host(*it->second);
+    free_tlas_device(ctx, *it->second); free_tlas_host(*it->second);
     ctx->tlas.erase(it);
     return HRT_OK;
 }

@@ -194,7 +194,8 @@ int hrt_ctx_destroy(HrtContext *ctx) {
     if (!ctx) return HRT_ERR_INVALID;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    for (auto &kv : ctx->tlas) { free_tlas_device(*kv.second); free_tlas_host(*kv.second); }
+    for (auto &kv : ctx->tlas) { free_tlas_device(ctx, *kv.second); free_tlas_host(*kv.second); }
+    pool_drain(ctx);
     Workspace &w = ctx->ws;
     for (SampleSet &st : w.set) {
         void *sp[] = {st.rays[0], st.rays[1], st.hit_tuvp, st.hit_inst, st.bin_items, st.chain, st.result, st.stages};

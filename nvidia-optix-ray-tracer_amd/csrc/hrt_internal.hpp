@@ -120,6 +120,7 @@ struct HrtContext {
     std::unordered_map<uint64_t, std::unique_ptr<hrt::Tlas>> tlas;
     uint64_t next_handle = 0x1000;
     std::mutex scratch_mu; std::vector<hrt::ScratchArena> scratch_free;      // scratch_acquire / scratch_release (hrt_accel.cpp)
+    std::mutex pool_mu; std::vector<hrt::ScratchArena> pool_free; std::unordered_map<void *, size_t> pool_live; size_t pool_bytes = 0;   // pool_alloc / pool_release: the trees' device memory
     // materials
     std::vector<HrtSbtRecord> records;
     HrtMissParams miss{{0.7f, 0.8f, 0.9f}};      // reference default, src/Global/RendererMesh.cu:262
@@ -225,7 +226,10 @@ void drain_spans(HrtContext *ctx);
 // hrt_accel.cpp
 hrt::ScratchArena scratch_acquire(HrtContext *ctx, size_t bytes);      // {nullptr, 0} when the device is out of memory
 void scratch_release(HrtContext *ctx, hrt::ScratchArena a);
-void free_tlas_device(Tlas &t);
+void free_tlas_device(HrtContext *ctx, Tlas &t);
+hipError_t pool_alloc(HrtContext *ctx, void **p, size_t bytes);
+void pool_release(HrtContext *ctx, void *p);
+void pool_drain(HrtContext *ctx);
 void free_tlas_host(Tlas &t);
 
 }  // namespace hrt

@@ -64,7 +64,16 @@ def run(name, scene, poses_of, frames, mode):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=20)
+    ap.add_argument("--only", default="", help="one case, e.g. particles-25:rebuild-merged (with --frames rebuilds: for API-level profiles)")
     a = ap.parse_args()
+    if a.only:
+        name, mode = a.only.split(":")
+        n_p, sub = (25, 2) if name == "particles-25" else (2000, 3)
+        sc = hrt.scenes.particle_scene(n_p, 1200, 800, 1, 0, subdiv=sub)
+        ground = sc["instances"][0]["transform"]
+        cache = {f: [ground] + hrt.scenes.particle_poses(n_p, f) for f in range(a.frames + 1)}
+        run(name, sc, lambda f: cache[f], a.frames, mode)
+        return
     # the reference's Time-mode structure: particles instancing shared shapes + ground sphere
     for n_p, sub in ((25, 2), (2000, 3)):
         sc = hrt.scenes.particle_scene(n_p, 1200, 800, 1, 0, subdiv=sub)
