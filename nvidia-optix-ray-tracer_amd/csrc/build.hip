@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_ploc_apply(GpuBuildArgs a, const uint32
 // Few clusters (the whole of a small build, the last dozen rounds of a large one): ONE workgroup runs every remaining round, a barrier
 // where the large build has a launch -- a round of six launches costs 30 us of host time whatever its size.  Same arithmetic and the
 // same tie rules as k_ploc_nn / _flags / _apply, so a build is the same tree whichever kernels ran its rounds.
-constexpr uint32_t kSmallClusters = 16384u;
+constexpr uint32_t kSmallClusters = 16384u;                     // (what k_ploc_small can take; the host hands it 4096 at most)
 __global__ __launch_bounds__(1024) void k_ploc_small(GpuBuildArgs a, uint32_t *cl_a, uint32_t *cl_b, uint32_t n_cells) {
     typedef hipcub::BlockScan<uint64_t, 1024> Scan;
     __shared__ typename Scan::TempStorage tmp;
@@ -663,6 +663,9 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     BuildCounters h{};
     uint32_t nv = 0, nl = 0, ns = 0, m = 0, node_base = 0, root = 0, n_cells = 1;
     bool split = false, small_tail = false;
+    // one workgroup per round beats six launches per round below a few thousand clusters (measured: 1024 .. 16384 all within 5 %; the
+    // reference's 8 k-triangle sample is a little quicker through the launches and the tail: profiles/r03_device_split_build.txt)
+    const uint32_t small_limit = 4096u;
     SplitPhaseResult sp{};
     // working memory comes out of the caller's arena while it lasts (a small build otherwise spends more time in ~25 hipMalloc /
     // hipFree pairs, each of which synchronises the device, than in its kernels)
@@ -717,7 +720,7 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     else hipLaunchKernelGGL(k_morton, dim3(blocks(n, 256)), dim3(256), 0, s, a);
     B_TRY(hipGetLastError());
     B_TRY(hipcub::DeviceRadixSort::SortPairs(temp, sort_bytes, a.keys, keys_out, a.vals, a.vals_sorted, (int)ns, 0, 64, s));
-    if (!split && n <= kSmallClusters) {
+    if (!split && n <= small_limit) {
         // ---- a small build (the reference's own scenes: a few thousand triangles): every PLOC round and every level of the emission in
         //      one workgroup each, and the host looks at the counters once, at the end ----
         hipLaunchKernelGGL(k_leaves, dim3(blocks(n, 256)), dim3(256), 0, s, a, kNone);
@@ -760,7 +763,7 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
         // 6 read-backs for a million primitives instead of 44.  With cells the rounds end when every cell is down to one cluster.
         constexpr int kRoundsPerBatch = 8;
         while (m > n_cells) {
-            if (!split && m <= kSmallClusters) {                 // the last rounds: one workgroup, one launch
+            if (!split && m <= small_limit) {                    // the last rounds: one workgroup, one launch
                 hipLaunchKernelGGL(k_ploc_small, dim3(1), dim3(1024), 0, s, a, cl_in, cl_out, 1u);
                 B_TRY(hipGetLastError());
                 B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));

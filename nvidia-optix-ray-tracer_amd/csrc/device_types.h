@@ -162,12 +162,15 @@ struct RefitArgs {
     float *node_ref;               // 2 floats per node: {weight, 1 / half area as built}
     uint32_t write_reference;      // 1: this refit completes a build -- record the areas instead of comparing with them
     float *area_sum;               // weighted mean of area now / area as built (quality after the refit), may be NULL
+    float *rec_box; uint32_t n_records;   // when set (small trees): 6 floats per record, the record's padded box, written by k_refit_records before the levels
+                                   // are walked -- the records' arithmetic then runs one thread per record instead of inside the walk up the tree
     const float *clip;             // when set (the refit that completes a device build with spatial splits): 6 floats per record, the box of the part
                                    // of the primitive this record stands for, taken instead of the primitive's own
 };
-constexpr uint32_t kRefitTopLevels = 16, kRefitTopLevelNodes = 1024;
+constexpr uint32_t kRefitTopLevels = 16, kRefitTopLevelNodes = 128;      // (one pass of the 1024-thread workgroup per level; wider levels are quicker as launches of their own: 95 -> ~45 us for the reference's sample)
 struct RefitLevels { uint32_t n_levels; uint32_t first[kRefitTopLevels], count[kRefitTopLevels]; };   // phases in processing order, each at most kRefitTopLevelNodes wide
 void launch_refit_level(const RefitArgs &a, hipStream_t s);
+void launch_refit_records(const RefitArgs &a, hipStream_t s);
 // per-instance tables of an update derived on the device from the caller's instance array (asynchronous updates)
 struct InstanceTableArgs {
     const void *instances;         // HrtInstance[] (80 B each): transform[12], instanceId, sbtOffset, visibilityMask, flags, handle (u64), pad

@@ -128,6 +128,7 @@ void free_tlas_device(HrtContext *ctx, Tlas &t) {
     pool_release(ctx, (void *)t.d_sig_sbt);
     pool_release(ctx, (void *)t.d_blas_box);
     pool_release(ctx, (void *)t.d_update_flags);
+    pool_release(ctx, (void *)t.d_rec_box); t.d_rec_box = nullptr;
     t.d_sig_handle = nullptr; t.d_sig_visibility = nullptr; t.d_sig_sbt = nullptr; t.d_blas_box = nullptr; t.d_update_flags = nullptr;
     t.d_nodes = t.d_prims = nullptr; t.d_inst_inv = nullptr; t.d_inst_identity = nullptr;
     t.d_node_box = t.d_node_ref = t.d_inst_xf = t.d_area = nullptr; t.d_inst_src = nullptr; t.d_order = nullptr;
@@ -167,6 +168,7 @@ float instance_tables(const std::vector<HrtInstance> &inst, const std::vector<st
 }
 
 void launch_refit_phases(RefitArgs ra, const std::vector<std::pair<uint32_t, uint32_t>> &phases, hipStream_t s);
+static void attach_rec_box(HrtContext *ctx, Tlas &t, RefitArgs &ra, uint32_t n_records);
 
 // The host builder needs the geometry on the host: fetched from the BLAS's device copy the first time it is asked for
 // (HRT_BUILD=host only; the device build never brings geometry across the bus).
@@ -187,10 +189,6 @@ int ensure_host_geometry(HrtContext *ctx, Blas &b, hipStream_t s) {
     b.host_geometry = true;
     return HRT_OK;
 }
-
-// one device build over a set of instances: tables up, build.hip, counts back.  The caller owns the output buffers.
-struct DeviceBuildTables { uint32_t *first = nullptr, *kind = nullptr; const void **src = nullptr; float *xf = nullptr; uint32_t *ident = nullptr;
-                           ~DeviceBuildTables() { for (void *p : {(void *)first, (void *)kind, (void *)src, (void *)xf, (void *)ident}) if (p) (void)hipFree(p); } };
 
 // Object-space BVH8 of one BLAS (built once): the subtree every instance of it gets in a tree over instances.  Built on the
 // device like everything else (one identity instance); only its topology -- nodes' child / primitive bases, masks, the
@@ -225,27 +223,32 @@ int ensure_template(HrtContext *ctx, Blas &b, hipStream_t s) {
     b.tmpl = Bvh8();
     const uint32_t n = b.n_prims;
     if (n == 0) { build_bvh8({}, b.tmpl, 1); b.tmpl_built = true; return HRT_OK; }
-    DeviceBuildTables tb;
-    unsigned char *d_nodes = nullptr, *d_prims = nullptr; float *d_ref = nullptr;
-    struct Guard { unsigned char *&a, *&b; float *&c; ~Guard() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (c) (void)hipFree(c); } } guard{d_nodes, d_prims, d_ref};
+    // one block of the context's working memory holds the five small tables, the staged output and the build's own arrays: a template
+    // build allocates and frees nothing (eight hipMalloc / hipFree pairs used to cost more than the build)
     const uint32_t h_first[2] = {0u, n}, h_kind = b.kind, h_ident = 1u;
     const float h_xf[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     const void *h_src = b.d_verts;
-    HIP_TRY(ctx, hipMalloc((void **)&tb.first, sizeof h_first)); HIP_TRY(ctx, hipMalloc((void **)&tb.kind, 4)); HIP_TRY(ctx, hipMalloc((void **)&tb.src, sizeof(void *)));
-    HIP_TRY(ctx, hipMalloc((void **)&tb.xf, sizeof h_xf)); HIP_TRY(ctx, hipMalloc((void **)&tb.ident, 4));
-    HIP_TRY(ctx, hipMalloc((void **)&d_nodes, sizeof(Bvh8Node) * (size_t)n)); HIP_TRY(ctx, hipMalloc((void **)&d_prims, sizeof(PrimRecord) * (size_t)n));
-    HIP_TRY(ctx, hipMalloc((void **)&d_ref, sizeof(float) * 2 * (size_t)n));
-    HIP_TRY(ctx, hipMemcpyAsync(tb.first, h_first, sizeof h_first, hipMemcpyHostToDevice, s)); HIP_TRY(ctx, hipMemcpyAsync(tb.kind, &h_kind, 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync((void *)tb.src, &h_src, sizeof(void *), hipMemcpyHostToDevice, s)); HIP_TRY(ctx, hipMemcpyAsync(tb.xf, h_xf, sizeof h_xf, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipMemcpyAsync(tb.ident, &h_ident, 4, hipMemcpyHostToDevice, s));
+    auto up = [](size_t x) { return (x + 255u) & ~(size_t)255u; };
+    const size_t o_first = 0, o_kind = o_first + 256, o_src = o_kind + 256, o_xf = o_src + 256, o_ident = o_xf + 256;
+    const size_t o_nodes = o_ident + 256, o_prims = o_nodes + up(sizeof(Bvh8Node) * (size_t)n), o_ref = o_prims + up(sizeof(PrimRecord) * (size_t)n);
+    const size_t o_scratch = o_ref + up(sizeof(float) * 2 * (size_t)n);
+    const ScratchArena arena = scratch_acquire(ctx, o_scratch + gpu_build_scratch_bytes(n));
+    if (!arena.p) return fail(ctx, HRT_ERR_OOM, "device build of a BLAS template: no working memory");
+    struct Release { HrtContext *c; ScratchArena a; ~Release() { scratch_release(c, a); } } release{ctx, arena};
+    unsigned char *base = static_cast<unsigned char *>(arena.p);
+    unsigned char *d_nodes = base + o_nodes, *d_prims = base + o_prims;
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_first, h_first, sizeof h_first, hipMemcpyHostToDevice, s)); HIP_TRY(ctx, hipMemcpyAsync(base + o_kind, &h_kind, 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_src, &h_src, sizeof(void *), hipMemcpyHostToDevice, s)); HIP_TRY(ctx, hipMemcpyAsync(base + o_xf, h_xf, sizeof h_xf, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(base + o_ident, &h_ident, 4, hipMemcpyHostToDevice, s));
     GpuBuildInput in{};
-    in.n_prims = n; in.n_inst = 1; in.d_inst_first = tb.first; in.d_inst_kind = tb.kind; in.d_inst_src = tb.src; in.d_inst_xf = tb.xf; in.d_inst_identity = tb.ident;
+    in.n_prims = n; in.n_inst = 1;
+    in.d_inst_first = reinterpret_cast<const uint32_t *>(base + o_first); in.d_inst_kind = reinterpret_cast<const uint32_t *>(base + o_kind);
+    in.d_inst_src = reinterpret_cast<const void *const *>(base + o_src); in.d_inst_xf = reinterpret_cast<const float *>(base + o_xf);
+    in.d_inst_identity = reinterpret_cast<const uint32_t *>(base + o_ident);
     in.max_leaf_prims = kMaxLeafPrims; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius;
-    in.out_nodes = d_nodes; in.node_stride = sizeof(Bvh8Node); in.out_prims = d_prims; in.prim_stride = sizeof(PrimRecord); in.out_node_ref = d_ref;
-    const ScratchArena arena = scratch_acquire(ctx, gpu_build_scratch_bytes(n));
-    in.scratch = arena.p; in.scratch_bytes = arena.bytes;
+    in.out_nodes = d_nodes; in.node_stride = sizeof(Bvh8Node); in.out_prims = d_prims; in.prim_stride = sizeof(PrimRecord); in.out_node_ref = reinterpret_cast<float *>(base + o_ref);
+    in.scratch = base + o_scratch; in.scratch_bytes = arena.bytes - o_scratch;
     const GpuBuildResult r = gpu_build_bvh8(in, s);      // (synchronises the stream before it returns)
-    scratch_release(ctx, arena);
     if (r.error != hipSuccess) return fail(ctx, HRT_ERR_HIP, "device build of a BLAS template failed: %s (%s)", hipGetErrorString(r.error), r.where);
     if (r.n_prims == 0) { build_bvh8({}, b.tmpl, 1); b.tmpl_built = true; return HRT_OK; }
     b.tmpl.nodes.resize(r.n_nodes); b.tmpl.prims.resize(r.n_prims);
@@ -490,6 +493,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
             // (a split build: every record's box is the one its cell is responsible for, not the primitive's -- this once; a later
             // update would recompute the boxes from whole primitives, so the first update rebuilds instead: has_split_refs)
             if (r.split_levels) { ra.clip = in.out_clip; t.has_split_refs = true; }
+            attach_rec_box(ctx, t, ra, r.n_records);
             launch_refit_phases(ra, t.phases, s);
             HIP_TRY(ctx, hipGetLastError());
             if (r.split_levels) HIP_TRY(ctx, hipStreamSynchronize(s));      // (the clip boxes live in the working memory)
@@ -524,6 +528,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
             // the device computes what the host left blank: world-space records, boxes, origins, exponents, quantised
             // children, and the built areas the quality guard compares later refits with
             ra.order = t.d_order;
+            attach_rec_box(ctx, t, ra, (uint32_t)n_prims);
             launch_refit_phases(ra, t.phases, s);
             HIP_TRY(ctx, hipGetLastError());
         }
@@ -573,12 +578,22 @@ int download_instances(HrtContext *ctx, const HrtInstance *d_instances, uint32_t
 // The phases of a refit, children before parents: wide phases get a launch each, the narrow ones at the end (the top
 // of the tree, or all of a small tree) run in one single-workgroup launch.
 void launch_refit_phases(RefitArgs ra, const std::vector<std::pair<uint32_t, uint32_t>> &phases, hipStream_t s) {
+    launch_refit_records(ra, s);                               // (small trees: ra.rec_box)
     size_t tail = phases.size();
     while (tail > 0 && phases.size() - tail < kRefitTopLevels && phases[tail - 1].second <= kRefitTopLevelNodes) --tail;
     for (size_t i = 0; i < tail; ++i) { ra.first_node = phases[i].first; ra.n_nodes = phases[i].second; launch_refit_level(ra, s); }
     RefitLevels top{};
     for (size_t i = tail; i < phases.size(); ++i) { top.first[top.n_levels] = phases[i].first; top.count[top.n_levels] = phases[i].second; ++top.n_levels; }
     launch_refit_top(ra, top, s);
+}
+
+// Small trees (the reference's own scenes) are refitted in one workgroup that walks the levels; the records' arithmetic -- most of the
+// work, and a chain of dependent loads -- runs before that, a thread per record, into 24 bytes per record (k_refit_records).
+constexpr uint32_t kRecBoxMaxRecords = 65536;
+static void attach_rec_box(HrtContext *ctx, Tlas &t, RefitArgs &ra, uint32_t n_records) {
+    if (n_records == 0u || n_records > kRecBoxMaxRecords) return;
+    if (!t.d_rec_box && pool_alloc(ctx, (void **)&t.d_rec_box, sizeof(float) * 6 * (size_t)n_records) != hipSuccess) { (void)hipGetLastError(); t.d_rec_box = nullptr; return; }
+    ra.rec_box = t.d_rec_box; ra.n_records = n_records;
 }
 
 // Device refit of a built tree under new instance transforms: upload the per-instance tables, then one
@@ -596,6 +611,7 @@ int refit_tlas(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, h
     ra.pad = 4e-6f * std::max(1.0f, scene_scale);
     ra.area_sum = t.d_area;
     ra.order = t.d_order;
+    attach_rec_box(ctx, t, ra, t.n_prims);
     { Timer tm(ctx, s, HRT_K_REFIT); launch_refit_phases(ra, t.phases, s); }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(t.h_area, t.d_area, sizeof(float), hipMemcpyDeviceToHost, s));
@@ -714,6 +730,7 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
             ra.prims = reinterpret_cast<unsigned char *>(t->d_prims); ra.prim_stride = t->prim_stride;
             ra.node_box = t->d_node_box; ra.node_ref = t->d_node_ref; ra.inst_xf = t->d_inst_xf; ra.inst_identity = t->d_inst_identity; ra.inst_src = t->d_inst_src;
             ra.scale_bits = t->d_update_flags; ra.area_sum = t->d_area; ra.order = t->d_order;
+            attach_rec_box(ctx, *t, ra, t->n_prims);
             { Timer tm(ctx, s, HRT_K_REFIT); launch_refit_phases(ra, t->phases, s); }
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipMemcpyAsync(t->h_area, t->d_area, sizeof(float), hipMemcpyDeviceToHost, s));

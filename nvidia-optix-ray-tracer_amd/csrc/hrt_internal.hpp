@@ -73,6 +73,7 @@ struct Tlas {
     const void **d_inst_src = nullptr;
     float *h_area = nullptr;                             // pinned: area sum of the last refit
     hipEvent_t area_ready = nullptr; bool area_pending = false;
+    float *d_rec_box = nullptr;                          // small trees: 6 floats per record, the refit's per-record pass (refit.hip k_refit_records)
     uint64_t refits = 0, rebuilds = 0, refits_since_build = 0;
 };
 

@@ -20,6 +20,51 @@ namespace hrt {
 
 __device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
 
+// One primitive record: its world-space form from the object-space source and the instance's transform, and (a.rec_box) its padded box.
+// Returns the box in lo / hi (empty when the primitive is not finite).
+__device__ __forceinline__ void refit_record(const RefitArgs &a, size_t r, float pad, float *lo, float *hi) {
+    unsigned char *rec = a.prims + r * a.prim_stride;
+    float *rf = reinterpret_cast<float *>(rec);
+    const uint32_t *ru = reinterpret_cast<const uint32_t *>(rec);
+    const uint32_t prim = ru[3], inst = ru[7], kind = ru[11];
+    const float *m = a.inst_xf + 12 * (size_t)inst;
+    const bool ident = a.inst_identity[inst] != 0u;
+    float plo[3], phi[3];
+    if (kind == 0u) {
+        const float *src = reinterpret_cast<const float *>(a.inst_src[inst]) + 9 * (size_t)prim;
+        float s9[9];
+        for (int q = 0; q < 9; ++q) s9[q] = src[q];
+        float v0[3], e1[3], e2[3];
+        triangle_world(s9, m, ident, v0, e1, e2, plo, phi);
+        rf[0] = v0[0]; rf[1] = v0[1]; rf[2] = v0[2];
+        rf[4] = e1[0]; rf[5] = e1[1]; rf[6] = e1[2];
+        rf[8] = e2[0]; rf[9] = e2[1]; rf[10] = e2[2];
+    } else {
+        const float c3[3] = {rf[0], rf[1], rf[2]};
+        sphere_world_bounds(c3, rf[4], m, ident, plo, phi);
+    }
+    if (a.clip) {                                      // a reference of a spatial split: the box its cell is responsible for
+        const float *cb = a.clip + 6 * r;
+        for (int q = 0; q < 3; ++q) { plo[q] = cb[q]; phi[q] = cb[3 + q]; }
+    }
+    const bool ok = finite_box(plo, phi);
+    for (int q = 0; q < 3; ++q) { lo[q] = ok ? plo[q] - pad : INFINITY; hi[q] = ok ? phi[q] + pad : -INFINITY; }
+}
+
+// small trees: every record by its own thread, before the levels are walked
+__global__ __launch_bounds__(256) void k_refit_records(RefitArgs a) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= a.n_records) return;
+    const float pad = a.scale_bits ? 4e-6f * fmaxf(1.0f, __uint_as_float(a.scale_bits[0])) : a.pad;
+    float lo[3], hi[3];
+    refit_record(a, r, pad, lo, hi);
+    float *b = a.rec_box + 6 * (size_t)r;
+    for (int q = 0; q < 3; ++q) { b[q] = lo[q]; b[3 + q] = hi[q]; }
+}
+void launch_refit_records(const RefitArgs &a, hipStream_t s) {
+    if (a.rec_box && a.n_records) hipLaunchKernelGGL(k_refit_records, dim3((a.n_records + 255u) / 256u), dim3(256), 0, s, a);
+}
+
 // One child slot of one node; the eight lanes of a node call this together (they exchange boxes by
 // shuffles), dead groups (live == false) go through the motions without touching memory.
 __device__ __forceinline__ void refit_slot(const RefitArgs &a, uint32_t node, uint32_t slot, bool live) {
@@ -41,32 +86,12 @@ __device__ __forceinline__ void refit_slot(const RefitArgs &a, uint32_t node, ui
                 const uint32_t cbits = meta >> 5, off = meta & 0x1fu;
                 const uint32_t cnt = cbits == 1u ? 1u : cbits == 3u ? 2u : 3u;
                 for (uint32_t k = 0; k < cnt; ++k) {
-                    unsigned char *rec = a.prims + (size_t)(prim_base + off + k) * a.prim_stride;
-                    float *rf = reinterpret_cast<float *>(rec);
-                    const uint32_t *ru = reinterpret_cast<const uint32_t *>(rec);
-                    const uint32_t prim = ru[3], inst = ru[7], kind = ru[11];
-                    const float *m = a.inst_xf + 12 * (size_t)inst;
-                    const bool ident = a.inst_identity[inst] != 0u;
                     float plo[3], phi[3];
-                    if (kind == 0u) {
-                        const float *src = reinterpret_cast<const float *>(a.inst_src[inst]) + 9 * (size_t)prim;
-                        float s9[9];
-                        for (int q = 0; q < 9; ++q) s9[q] = src[q];
-                        float v0[3], e1[3], e2[3];
-                        triangle_world(s9, m, ident, v0, e1, e2, plo, phi);
-                        rf[0] = v0[0]; rf[1] = v0[1]; rf[2] = v0[2];
-                        rf[4] = e1[0]; rf[5] = e1[1]; rf[6] = e1[2];
-                        rf[8] = e2[0]; rf[9] = e2[1]; rf[10] = e2[2];
-                    } else {
-                        const float c3[3] = {rf[0], rf[1], rf[2]};
-                        sphere_world_bounds(c3, rf[4], m, ident, plo, phi);
-                    }
-                    if (a.clip) {                                      // a reference of a spatial split: the box its cell is responsible for
-                        const float *cb = a.clip + 6 * (size_t)(prim_base + off + k);
-                        for (int q = 0; q < 3; ++q) { plo[q] = cb[q]; phi[q] = cb[3 + q]; }
-                    }
-                    if (finite_box(plo, phi))
-                        for (int q = 0; q < 3; ++q) { lo[q] = fminf(lo[q], plo[q] - pad); hi[q] = fmaxf(hi[q], phi[q] + pad); }
+                    if (a.rec_box) {                                   // (k_refit_records has been here)
+                        const float *b = a.rec_box + 6 * (size_t)(prim_base + off + k);
+                        for (int q = 0; q < 3; ++q) { plo[q] = b[q]; phi[q] = b[3 + q]; }
+                    } else refit_record(a, (size_t)(prim_base + off + k), pad, plo, phi);
+                    for (int q = 0; q < 3; ++q) { lo[q] = fminf(lo[q], plo[q]); hi[q] = fmaxf(hi[q], phi[q]); }
                 }
             }
         }
