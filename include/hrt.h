@@ -57,8 +57,8 @@ typedef struct HrtContext HrtContext;
 #define HRT_CTX_FAST_TRACE 0x4u  /* hrt_tlas_build prefers trace speed to build speed: the reference's OPTIX_BUILD_FLAG_PREFER_FAST_TRACE
                                     (its GAS builds, RendererImpl.cu:94,118,144).  The tree is then built WITH SPATIAL SPLITS: on the device
                                     (csrc/build_split.hip: top-down SAH splits of references level by level, PLOC within the cells that
-                                    remain; 1 M triangles: ~22 ms against ~8 ms for the default build, 11.5 % fewer node visits per ray,
-                                    1.3 records per triangle, ~1.2 KB of working memory per triangle), or -- environment
+                                    remain; 1 M triangles: ~15 ms against ~5 ms for the default build, 11.5 % fewer node visits per ray,
+                                    1.46 records per triangle, ~1.2 KB of working memory per triangle), or -- environment
                                     HRT_FAST_TRACE_BUILD=host -- by the host's binned-SAH builder from a host copy of the geometry (the same
                                     rules, ~1.3 s).  Such a tree is for static scenes: the first hrt_tlas_update replaces it by a
                                     default-built one (a refit cannot keep the split references' boxes), and rebuilds inside hrt_tlas_update

@@ -4,13 +4,17 @@
 //   1. world-space bounds of every primitive of every visible instance (same transform arithmetic as the refit: bvh8_geom.h),
 //      scene centroid bounds by wave reduction + ordered-integer atomics;
 //   2. 63-bit Morton codes of the centroids, radix sort (hipCUB);
+//   0. under HRT_CTX_FAST_TRACE, for scenes of more than 4096 primitives: the top-down phase with spatial splits (build_split.hip),
+//      after which the leaves are references grouped in cells and PLOC merges within cells only;
 //   3. PLOC (Meister & Bittner 2018): clusters in Morton order repeatedly merge with their nearest neighbour (smallest
-//      merged surface area within +-16 positions) when the choice is mutual -- a BVH2 of near-SAH quality in ~15 rounds,
-//      every round a handful of O(n) launches; node numbers come from prefix sums, so the BVH2 is deterministic;
+//      merged surface area within +-2 positions) when the choice is mutual -- a BVH2 of near-SAH quality in ~40 rounds,
+//      every round a handful of O(n) launches; node numbers come from prefix sums, so the BVH2 is deterministic.  The last rounds
+//      (4096 clusters or fewer: all rounds of a small build) are one workgroup's, a barrier where the others have a launch;
 //   4. the optimal SAH collapse to 8-wide nodes (Ylitie, Karras, Laine 2017, sec. 4.1: the same cost tables as the host
-//      builder bvh8_build.cpp) computed bottom-up, a launch per PLOC round (a round's nodes have children from earlier rounds only);
-//   5. emission of the packed BVH8 breadth first, one launch per level: forest roots from the tables, octant slot
-//      assignment, child / primitive blocks from atomic cursors -- topology and primitive ids only;
+//      builder bvh8_build.cpp): a node's table is computed where the node is made (its children are from earlier rounds);
+//   5. emission of the packed BVH8 breadth first, one launch per level (a small build: one workgroup for all levels), eight lanes
+//      per node: forest roots from the tables, octant slot assignment, child / primitive blocks from atomic cursors -- topology
+//      and primitive ids only;
 //   6. the refit kernels (refit.hip) then compute every world-space record, box, origin, exponent and quantised child box
 //      bottom-up, exactly as they do after an instance update: one arithmetic for build and refit.
 // The result does not depend on the tree: hits are defined by the canonical intersector over conservative boxes.

@@ -781,10 +781,10 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
                      force_rebuild ? "verdict of the previous asynchronous refit" : "handles / visibility changed or the refit just done degraded the tree", ctx->tlas_refit_ratio.load(),
                      (unsigned long long)t->refits_since_build);
     HIP_TRY(ctx, hipDeviceSynchronize());                 // launches on other streams may still read the old tree
-    // A rebuild in the middle of an animation.  Large scenes: the merged device build (6.6 ms for 2000 particles / 435 k
-    // triangles, 7.9 ms for a million triangles: profiles/r02_build_bench.txt) -- the better tree.  Small scenes, where the
-    // device build's fixed cost (a stream synchronisation per PLOC round and per level, ~2 ms) would dominate, and host-build
-    // contexts: the tree over instances, whose top tree the host assembles in well under a millisecond.
+    // A rebuild in the middle of an animation.  Large scenes: the merged device build (3.1 ms for 2000 particles / 435 k
+    // triangles, 3.3 ms for a million triangles: profiles/r03_device_split_build.txt) -- the better tree.  Small scenes and
+    // host-build contexts: the tree over instances, whose top tree the host assembles in well under a millisecond (the
+    // reference's 25-particle layout: 0.21 ms against 0.71 ms for the merged build).
     uint64_t total = 0;
     for (uint32_t i = 0; i < n; ++i) total += t->blas_refs[i] ? t->blas_refs[i]->n_prims : 0u;
     const bool over_instances = ctx->tlas_instanced >= 0 && n >= 2 && (!ctx->build_on_device || total < 100000ull || ctx->tlas_instanced > 0);
