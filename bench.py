@@ -211,11 +211,12 @@ def main():
     # The scene is static, so trace speed is preferred to build speed, as the reference does for its geometry
     # (OPTIX_BUILD_FLAG_PREFER_FAST_TRACE, RendererImpl.cu:94): HRT_CTX_FAST_TRACE = a tree with spatial splits, built on the device (top-down
     # SAH splits of references, then PLOC within the cells: build_split.hip; HRT_FAST_TRACE_BUILD=host: the host's binned-SAH builder, the same
-    # rules, ~1.3 s).  HRT_BENCH_DEVICE_BUILD=1 times the frame on the default tree instead (PLOC alone, no splits, refittable: 8 ms, ~13 % more
-    # node visits per ray); the line carries the other builders' rates as config.alt_builders.
+    # rules, ~1.3 s).  HRT_BENCH_DEVICE_BUILD=1 times the frame on the default tree instead (the same top-down phase without spatial splits,
+    # refittable: 8 ms, ~10 % more node visits per ray); the line carries the other builders' rates as config.alt_builders.
     device_build = os.environ.get("HRT_BENCH_DEVICE_BUILD") == "1"
     split_on_device = os.environ.get("HRT_FAST_TRACE_BUILD", "device") == "device"
-    LABEL_PLOC = "device PLOC (build.hip)"
+    LABEL_PLOC = "device top-down SAH (object splits) + PLOC in the cells: the default, refittable build (build_split.hip + build.hip)"
+    LABEL_PLOC_ALONE = "device PLOC alone (build.hip, HRT_BUILD_TOPDOWN=0)"
     LABEL_SPLIT = {True: "device top-down SAH with spatial splits + PLOC in the cells (build_split.hip, HRT_CTX_FAST_TRACE)",
                    False: "host binned SAH with spatial splits (bvh8_build.cpp, HRT_CTX_FAST_TRACE, HRT_FAST_TRACE_BUILD=host)"}
     # HRT_BENCH_NO_TIMING=1: no per-kernel HIP events (wavefront mode then replays its samples from a hipGraph; the roofline block has no kernel time)
@@ -342,21 +343,22 @@ def main():
         }
         if world == 1 and not args.no_alt_builder:
             # the same frame on the trees of the OTHER builders (a context each; a few steps are enough for a rate)
-            alts = [(LABEL_PLOC, 0, None)] if not device_build else [(LABEL_SPLIT[split_on_device], hrt.CTX_FAST_TRACE, None)]
-            alts.append((LABEL_SPLIT[not split_on_device], hrt.CTX_FAST_TRACE, "host" if split_on_device else "device"))
+            # (label, context flag, environment for the context's creation)
+            alts = [(LABEL_PLOC, 0, {})] if not device_build else [(LABEL_SPLIT[split_on_device], hrt.CTX_FAST_TRACE, {})]
+            alts.append((LABEL_SPLIT[not split_on_device], hrt.CTX_FAST_TRACE, {"HRT_FAST_TRACE_BUILD": "host" if split_on_device else "device"}))
+            alts.append((LABEL_PLOC_ALONE, 0, {"HRT_BUILD_TOPDOWN": "0"}))
             out["config"]["alt_builders"] = []
-            for label, flag, where in alts:
-                saved = os.environ.get("HRT_FAST_TRACE_BUILD")
-                if where is not None:
-                    os.environ["HRT_FAST_TRACE_BUILD"] = where           # (read when the context is created)
+            for label, flag, env in alts:
+                saved = {k: os.environ.get(k) for k in env}
+                os.environ.update(env)                                   # (read when the context is created)
                 try:
                     alt = hrt.Renderer(local_rank, hrt.CTX_TIMING | flag)
                 finally:
-                    if where is not None:
-                        if saved is None:
-                            os.environ.pop("HRT_FAST_TRACE_BUILD", None)
+                    for k, v in saved.items():
+                        if v is None:
+                            os.environ.pop(k, None)
                         else:
-                            os.environ["HRT_FAST_TRACE_BUILD"] = saved
+                            os.environ[k] = v
                 t0 = time.perf_counter()
                 alt.load_scene(scene)
                 alt_build_s = time.perf_counter() - t0

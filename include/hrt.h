@@ -57,7 +57,8 @@ typedef struct HrtContext HrtContext;
 #define HRT_CTX_FAST_TRACE 0x4u  /* hrt_tlas_build prefers trace speed to build speed: the reference's OPTIX_BUILD_FLAG_PREFER_FAST_TRACE
                                     (its GAS builds, RendererImpl.cu:94,118,144).  The tree is then built WITH SPATIAL SPLITS: on the device
                                     (csrc/build_split.hip: top-down SAH splits of references level by level, PLOC within the cells that
-                                    remain; 1 M triangles: ~15 ms against ~5 ms for the default build, 11.5 % fewer node visits per ray,
+                                    remain; 1 M triangles: ~15 ms against ~9 ms for the default build -- the same phase with object splits only,
+                                    which keeps the tree refittable --, 9.5 % fewer node visits per ray,
                                     1.46 records per triangle, ~1.2 KB of working memory per triangle), or -- environment
                                     HRT_FAST_TRACE_BUILD=host -- by the host's binned-SAH builder from a host copy of the geometry (the same
                                     rules, ~1.3 s).  Such a tree is for static scenes: the first hrt_tlas_update replaces it by a
@@ -84,8 +85,9 @@ int  hrt_blas_destroy(HrtContext *ctx, HrtTraversable blas);
 
 /* replaces buildIAS / updateIAS, src/Global/RendererImpl.cu:174-242.  d_instances lives in
  * device memory (reference: cudaMemcpy H2D then build, src/Global/RendererMesh.cu:151-160).
- * hrt_tlas_build flattens the instances into one world-space BVH8, built on the device (Morton sort, PLOC, optimal
- * 8-wide collapse: csrc/build.hip; under HRT_CTX_FAST_TRACE with spatial splits, csrc/build_split.hip).  hrt_tlas_update takes
+ * hrt_tlas_build flattens the instances into one world-space BVH8, built on the device (top-down SAH object splits down to
+ * cells of a few references, csrc/build_split.hip -- with spatial splits under HRT_CTX_FAST_TRACE --, then Morton sort, PLOC
+ * within the cells and the optimal 8-wide collapse, csrc/build.hip; scenes of at most 4096 primitives: PLOC alone).  hrt_tlas_update takes
  * the same number of instances: when only transforms (and sbtOffsets) changed, the tree is refitted on the
  * device, asynchronously on `stream` after one small read-back of the instance array; a changed BLAS handle
  * or visibility mask, or a refitted tree whose boxes have grown too far, rebuilds it (as a tree over

@@ -4,8 +4,10 @@
 //   1. world-space bounds of every primitive of every visible instance (same transform arithmetic as the refit: bvh8_geom.h),
 //      scene centroid bounds by wave reduction + ordered-integer atomics;
 //   2. 63-bit Morton codes of the centroids, radix sort (hipCUB);
-//   0. under HRT_CTX_FAST_TRACE, for scenes of more than 4096 primitives: the top-down phase with spatial splits (build_split.hip),
-//      after which the leaves are references grouped in cells and PLOC merges within cells only;
+//   0. for scenes of more than 4096 primitives: the top-down phase (build_split.hip: binned-SAH object splits level by level -- and
+//      spatial splits under HRT_CTX_FAST_TRACE --), after which the leaves are references grouped in cells of a few each and PLOC merges
+//      within cells only.  PLOC alone shapes a soup well enough, but not separate bodies over a huge ground sphere, the reference's
+//      kind of scene: 39 node visits per ray where the top-down phase leaves 5.5 (profiles/r03_particle_scene_trees.txt);
 //   3. PLOC (Meister & Bittner 2018): clusters in Morton order repeatedly merge with their nearest neighbour (smallest
 //      merged surface area within +-2 positions) when the choice is mutual -- a BVH2 of near-SAH quality in ~40 rounds,
 //      every round a handful of O(n) launches; node numbers come from prefix sums, so the BVH2 is deterministic.  The last rounds

@@ -442,7 +442,9 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         in.n_prims = first[n]; in.n_inst = n; in.d_inst_first = t.d_inst_first; in.d_inst_kind = t.d_inst_kind; in.d_inst_src = t.d_inst_src;
         in.d_inst_xf = t.d_inst_xf; in.d_inst_identity = t.d_inst_identity;
         in.max_leaf_prims = kMaxLeafPrims; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius;
-        in.split.enabled = device_split; in.split.budget_frac = ctx->split_budget; in.split.alpha = ctx->split_alpha; in.split.bias = ctx->split_bias; in.split.cut_bias = ctx->split_cut_bias;
+        // the top-down phase always (object splits: what gives the tree its shape above the cells PLOC builds -- on the reference's kind of
+        // scene, separate bodies over a huge ground sphere, PLOC alone costs seven times the node visits); spatial splits under HRT_CTX_FAST_TRACE
+        in.split.enabled = device_split || ctx->build_topdown != 0; in.split.budget_frac = device_split ? ctx->split_budget : 0.0f; in.split.alpha = ctx->split_alpha; in.split.bias = ctx->split_bias; in.split.cut_bias = ctx->split_cut_bias;
         in.split.cell_refs = (uint32_t)ctx->split_cell_refs; in.split.pad = ra.pad; in.split.verbose = std::getenv("HRT_BUILD_VERBOSE") != nullptr;
         // worst-case node output (one node and two reference floats per leaf: primitive, or reference of a spatial split) at the front of the
         // working memory; a split build's records and their clip boxes too (their number is known afterwards)
@@ -450,7 +452,11 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         const size_t stage_nodes = ((size_t)t.node_stride * max_leaves + 255u) & ~(size_t)255u, stage_ref = (sizeof(float) * 2 * max_leaves + 255u) & ~(size_t)255u;
         const size_t stage_prims = device_split ? ((size_t)t.prim_stride * max_leaves + 255u) & ~(size_t)255u : 0u, stage_clip = device_split ? (sizeof(float) * 6 * max_leaves + 255u) & ~(size_t)255u : 0u;
         const size_t stage_all = stage_nodes + stage_ref + stage_prims + stage_clip, want = gpu_build_scratch_bytes(in.n_prims, &in.split) + stage_all;
-        const ScratchArena arena = scratch_acquire(ctx, want);
+        ScratchArena arena = scratch_acquire(ctx, want);
+        if (!arena.p && in.split.enabled && !device_split) {      // no room for the top-down phase's buffers: PLOC alone
+            in.split.enabled = false;
+            arena = scratch_acquire(ctx, gpu_build_scratch_bytes(in.n_prims, nullptr) + stage_all);
+        }
         if (!arena.p) return fail(ctx, HRT_ERR_OOM, "device build: no working memory (%zu bytes)", want);
         struct Release { HrtContext *c; ScratchArena a; ~Release() { scratch_release(c, a); } } release{ctx, arena};
         unsigned char *stage = static_cast<unsigned char *>(arena.p);
@@ -492,11 +498,11 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
             for (size_t l = r.level_begin.size() - 1; l-- > 0;) t.phases.emplace_back(r.level_begin[l], r.level_begin[l + 1] - r.level_begin[l]);
             // (a split build: every record's box is the one its cell is responsible for, not the primitive's -- this once; a later
             // update would recompute the boxes from whole primitives, so the first update rebuilds instead: has_split_refs)
-            if (r.split_levels) { ra.clip = in.out_clip; t.has_split_refs = true; }
+            if (device_split && r.split_levels) { ra.clip = in.out_clip; t.has_split_refs = true; }
             attach_rec_box(ctx, t, ra, r.n_records);
             launch_refit_phases(ra, t.phases, s);
             HIP_TRY(ctx, hipGetLastError());
-            if (r.split_levels) HIP_TRY(ctx, hipStreamSynchronize(s));      // (the clip boxes live in the working memory)
+            if (device_split && r.split_levels) HIP_TRY(ctx, hipStreamSynchronize(s));      // (the clip boxes live in the working memory)
             ra.clip = nullptr;
             if (std::getenv("HRT_BUILD_VERBOSE"))
                 std::fprintf(stderr, "[hrt] device build: %u primitives -> %u records, %u nodes, depth %u, %u PLOC rounds (radius %d), %u split levels, %u cells\n",

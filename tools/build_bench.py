@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Acceleration-structure build: device (PLOC, build.hip), split (HRT_CTX_FAST_TRACE: the device's top-down phase with spatial splits +
+"""Acceleration-structure build: device (the default: top-down object splits + PLOC in the cells), ploc (PLOC alone, HRT_BUILD_TOPDOWN=0), split (HRT_CTX_FAST_TRACE: the device's top-down phase with spatial splits +
 PLOC in the cells, build_split.hip), host (binned SAH, bvh8_build.cpp) and host-split (the host builder with spatial splits) -- build time of
 hrt_tlas_build (call to completion) and what the tree is worth when traced (C3 / C4 frame, a few spp).
 Usage: tools/build_bench.py [C3|C4] [spp]      (HRT_BUILD_BENCH_MODES=device,split,host,host-split selects)"""
@@ -12,8 +12,10 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "C4"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 scene = hrt.scenes.BASELINE_CONFIGS[cfg]()
 W, H = scene["width"], scene["height"]
-for mode in os.environ.get("HRT_BUILD_BENCH_MODES", "device,split,host,host-split").split(","):
-    os.environ.pop("HRT_BUILD", None); os.environ.pop("HRT_FAST_TRACE_BUILD", None)
+for mode in os.environ.get("HRT_BUILD_BENCH_MODES", "device,ploc,split,host,host-split").split(","):
+    os.environ.pop("HRT_BUILD", None); os.environ.pop("HRT_FAST_TRACE_BUILD", None); os.environ.pop("HRT_BUILD_TOPDOWN", None)
+    if mode == "ploc":
+        os.environ["HRT_BUILD_TOPDOWN"] = "0"
     if mode == "host":
         os.environ["HRT_BUILD"] = "host"
     if mode == "host-split":
