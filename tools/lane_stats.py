@@ -5,8 +5,13 @@
 import importlib, sys
 sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
 hrt = importlib.import_module("nvidia-optix-ray-tracer_amd")
-scene = hrt.scenes.soup_1m(1920, 1080, 16)
-r = hrt.Renderer(0, hrt.CTX_FAST_TRACE); r.load_scene(scene); r.set_frame(1920, 1080, hrt.scenes.SEED_SALT, aov=False)      # (the tree bench.py times)
+if len(sys.argv) > 1 and sys.argv[1] == "particles":       # tools/lane_stats.py particles N: the reference's kind of scene, 1200x800
+    n_p = int(sys.argv[2])
+    scene = hrt.scenes.particle_scene(n_p, 1200, 800, 16, subdiv=2 if n_p <= 100 else 3)
+    r = hrt.Renderer(0, 0); r.load_scene(scene); r.set_frame(1200, 800, hrt.scenes.SEED_SALT, aov=False)
+else:
+    scene = hrt.scenes.soup_1m(1920, 1080, 16)
+    r = hrt.Renderer(0, hrt.CTX_FAST_TRACE); r.load_scene(scene); r.set_frame(1920, 1080, hrt.scenes.SEED_SALT, aov=False)      # (the tree bench.py times)
 r.render(2); r.reset_stats(); r.render(16)
 s = r.stats()
 it, alive, node, prim = s.debug[0], s.debug[1], s.debug[2], s.debug[3]
