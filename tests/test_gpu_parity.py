@@ -1206,6 +1206,43 @@ def test_fast_trace_tree_with_spatial_splits(hrt, oracle, gpu_available, monkeyp
         r.close()
 
 
+def test_default_build_shapes_the_reference_kind_of_scene(hrt, oracle, gpu_available, monkeypatch):
+    """The reference's kind of scene: hundreds of particles instancing a few closed shapes over a ground sphere of radius 1000.  PLOC
+    alone (bottom-up merges in Morton order, search radius 2) has no view of such a scene's large-scale structure and its tree costs
+    several times the node visits; the default device build therefore starts with the top-down phase (object splits only: the tree
+    stays refittable).  Node visits per closest-hit ray of the counting pass: at most 9 by default, more than twice that with
+    HRT_BUILD_TOPDOWN=0; the same hits either way, and the default tree is refitted, not rebuilt, by an update."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    w, h = 320, 200
+    scene = hrt.scenes.particle_scene(400, w, h, 1, subdiv=3)
+    visits = {}
+    hits = {}
+    for topdown in ("1", "0"):
+        monkeypatch.setenv("HRT_BUILD_TOPDOWN", topdown)
+        r = hrt.Renderer(0, hrt.CTX_COUNT)
+        try:
+            r.load_scene(scene)
+            r.set_frame(w, h, hrt.scenes.SEED_SALT, aov=False)
+            r.render(1)
+            st = r.stats()
+            assert st.bvh_triangles > 4096
+            visits[topdown] = st.node_visits_closest / max(st.rays_closest, 1)
+            o, d = oracle.random_rays(4000, 5)
+            hits[topdown] = r.trace_rays(o, d)
+            if topdown == "1":
+                before = r.stats()
+                r.update_instances([it["transform"] for it in scene["instances"]])      # (identity move: the first update checks the refit on the spot)
+                after = r.stats()
+                assert after.tlas_refits == before.tlas_refits + 1 and after.tlas_rebuilds == before.tlas_rebuilds
+        finally:
+            r.close()
+    assert visits["1"] <= 9.0 and visits["0"] >= 2.0 * visits["1"], visits
+    assert all(np.array_equal(a, b) for a, b in zip(hits["1"], hits["0"]))
+    rt, ru, rv, rprim, rinst = oracle.OracleScene(scene, force_brute=True).trace(*oracle.random_rays(4000, 5))
+    assert np.array_equal(hits["1"][3], rprim) and np.array_equal(hits["1"][4], rinst) and np.array_equal(hits["1"][0].view(np.uint32), rt.view(np.uint32))
+
+
 def test_device_split_build_with_full_segment_tables(hrt, oracle, gpu_available, monkeypatch):
     """The top-down phase keeps its segments in tables sized for twice what balanced splits make.  When they fill up (here: forced,
     HRT_SBVH_SEG_CAP) the level is planned again with every segment left as a cell, and PLOC builds the rest -- cells of thousands of
