@@ -39,7 +39,7 @@ else:
 r = hrt.Renderer(0, hrt.CTX_TIMING | (hrt.CTX_FAST_TRACE if args.fast_trace else 0))
 t0 = time.perf_counter(); r.load_scene(scene); load_s = time.perf_counter() - t0
 out = {"scene": scene["name"], "triangles": args.tris, "edge": hrt.scenes.soup_law_edge(args.tris) if args.tris != 1_000_000 else 0.014,
-       "builder": ("device top-down SAH with spatial splits + PLOC" if os.environ.get("HRT_FAST_TRACE_BUILD", "device") == "device" else "host binned SAH with spatial splits") if args.fast_trace else "device PLOC",
+       "builder": ("device top-down SAH with spatial splits + PLOC" if os.environ.get("HRT_FAST_TRACE_BUILD", "device") == "device" else "host binned SAH with spatial splits") if args.fast_trace else ("device top-down SAH (object splits) + PLOC: the default build" if os.environ.get("HRT_BUILD_TOPDOWN", "1") != "0" else "device PLOC alone"),
        "load_scene_s": round(load_s, 3)}
 if not args.no_count and (not args.fast_trace or os.environ.get("HRT_FAST_TRACE_BUILD", "device") == "device"):
     # the TLAS build alone: the same instance array once more, timed from call to stream idle
