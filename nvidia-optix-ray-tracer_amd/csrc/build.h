@@ -26,6 +26,7 @@ struct GpuBuildArgs {
     const void *const *inst_src;      // per instance: 9 floats per triangle, or {cx, cy, cz, r} per sphere (object space)
     const float *inst_xf; const uint32_t *inst_identity;
     uint32_t max_leaf_prims; float c_node, c_prim; int ploc_radius;
+    float quant_guard;                // emission: a node whose children's stored (8-bit) boxes would have more than this times their true area keeps its two BVH2 children (0: off)
     BuildCounters *counters;
     float4 *pb_lo, *pb_hi;            // per primitive: world bounds (lo.w = valid)
     uint64_t *keys; uint32_t *vals, *vals_sorted;
@@ -82,6 +83,7 @@ struct GpuBuildInput {
     const uint32_t *d_inst_first, *d_inst_kind; const void *const *d_inst_src;
     const float *d_inst_xf; const uint32_t *d_inst_identity;
     uint32_t max_leaf_prims; float c_node, c_prim; int ploc_radius;
+    float quant_guard = 1.25f;
     unsigned char *out_nodes; uint32_t node_stride;      // room for n_prims nodes (worst case)
     unsigned char *out_prims; uint32_t prim_stride;      // room for n_prims records
     float *out_node_ref;                                 // 2 floats per node

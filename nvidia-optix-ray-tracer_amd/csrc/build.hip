@@ -424,6 +424,26 @@ __device__ void emit_item(const GpuBuildArgs &a, uint32_t b2, uint32_t self, uin
             f.n = 1; f.node[0] = b2; ch_leaf[0] = true;              // the whole scene fits one leaf: wrap it
         } else {
             collect_forest(a, b2, f);
+            // The children's boxes are stored on THIS node's 8-bit grid (step ~ extent / 255 per axis).  Where one child dwarfs the others --
+            // an outlier far from the rest of the scene, a huge ground sphere beside small particles -- the small children's stored boxes are
+            // blown up by the grid's step and every ray that enters the node visits most of them.  Such a node keeps its two BVH2 children
+            // instead: the small side becomes ONE child, whose own node has a grid of its own size (one more visit, several fewer).
+            // Ordinary nodes store their children 3 % larger than they are; the guard acts above 25 %.
+            if (f.n > 2 && a.quant_guard > 0.0f) {
+                float step[3];
+                { const float ext[3] = {nhi.x - nlo.x, nhi.y - nlo.y, nhi.z - nlo.z}; for (int q = 0; q < 3; ++q) step[q] = exponent_scale(node_exponent(ext[q])); }
+                float sum_true = 0.0f, sum_stored = 0.0f;
+                for (int k = 0; k < f.n; ++k) {
+                    const float4 lo = a.node_lo[f.node[k]], hi = a.node_hi[f.node[k]];
+                    const float e[3] = {hi.x - lo.x, hi.y - lo.y, hi.z - lo.z};
+                    const float g[3] = {e[0] + step[0], e[1] + step[1], e[2] + step[2]};      // (a stored box is wider by a step per axis on average)
+                    sum_true += e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+                    sum_stored += g[0] * g[1] + g[1] * g[2] + g[2] * g[0];
+                }
+                if (sum_stored > a.quant_guard * sum_true) {
+                    f.n = 2; f.node[0] = __float_as_uint(nlo.w); f.node[1] = __float_as_uint(nhi.w);
+                }
+            }
             for (int k = 0; k < f.n; ++k) {
                 const uint32_t c = f.node[k];
                 ch_leaf[k] = __float_as_uint(a.node_lo[c].w) == kNone || (__float_as_uint(a.cost[8 * (size_t)c]) & 1u);
@@ -680,7 +700,7 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
 
     a.n = n; a.n_inst = in.n_inst; a.inst_first = in.d_inst_first; a.inst_kind = in.d_inst_kind; a.inst_src = in.d_inst_src;
     a.inst_xf = in.d_inst_xf; a.inst_identity = in.d_inst_identity;
-    a.max_leaf_prims = in.max_leaf_prims; a.c_node = in.c_node; a.c_prim = in.c_prim;
+    a.max_leaf_prims = in.max_leaf_prims; a.c_node = in.c_node; a.c_prim = in.c_prim; a.quant_guard = in.quant_guard;
     a.ploc_radius = in.ploc_radius < 1 ? 1 : (in.ploc_radius > kPlocMaxRadius ? kPlocMaxRadius : in.ploc_radius);
     a.out_nodes = in.out_nodes; a.node_stride = in.node_stride; a.out_prims = in.out_prims; a.prim_stride = in.prim_stride; a.out_node_ref = in.out_node_ref;
 

@@ -57,7 +57,7 @@ constexpr int kObjCnt = kBinMinMax, kSpEnter = kObjCnt + 3 * kObjBins, kSpLeave 
 constexpr int kBinWords = kSpLeave + 3 * kSpBins;                                      // 1104 words per segment
 constexpr uint32_t kChunk = 512u, kMaxLevels = 64u, kWave = 64u;
 
-struct SplitCounters { uint32_t n_act, n_chunks, src_total, n_cells, n_top, n_out, n_segs, gave_up, n_big, retry, n_cut; };
+struct SplitCounters { uint32_t n_act, n_chunks, src_total, n_cells, n_top, n_out, n_segs, gave_up, n_big, retry, n_cut; float bulk_area, bulk_area_next; };
 
 struct SplitArgs {
     GpuBuildArgs b;                                  // instance tables (the scatter clips triangles), primitive bounds, scene counters
@@ -72,7 +72,7 @@ struct SplitArgs {
     SplitCounters *counters;
     uint32_t n_act, n_chunks, cell_refs, level;
     uint32_t seg_base, cell_base, top_base, out_base;       // the running totals before this level (the host's copy of the counters)
-    float pad, alpha_area, bias, cut_bias;
+    float pad, alpha, bias, cut_bias; uint32_t n_total;
 };
 
 __device__ __forceinline__ float half_area3(const float *lo, const float *hi) {
@@ -119,6 +119,11 @@ __global__ __launch_bounds__(256) void k_split_first_level(SplitArgs a, uint32_t
     a.segs[0] = sg; a.act[0] = 0u;
     SplitCounters sc{};
     sc.n_act = 1u; sc.n_chunks = a.n_chunks; sc.src_total = n_valid; sc.n_segs = 1u; sc.n_big = n_valid > kChunk ? 1u : 0u;
+    {
+        float lo[3], hi[3];
+        seg_bounds(sg.nb, lo, hi);
+        sc.bulk_area = sc.bulk_area_next = half_area3(lo, hi);
+    }
     *a.counters = sc;
 }
 
@@ -203,6 +208,12 @@ __device__ __forceinline__ void select_split(const SplitArgs &a, SplitSeg &sg, c
     const float pad = a.pad;
     float nlo[3], nhi[3], clo[3], chi[3];
     seg_bounds(sg.nb, nlo, nhi); seg_bounds(sg.cb, clo, chi);
+    // The paper tries spatial splits where the object split's children overlap by more than alpha of the SCENE's area.  A scene with an
+    // outlier -- the reference's: a ground sphere of radius 1000 beside particles of size 0.1 -- has a root box that says nothing about
+    // the geometry, and no overlap would ever pass.  The yardstick is therefore the box of the BULK: the segment that still holds nine
+    // tenths of all references, followed down from the root (it takes effect a level later: plan_apply moves it, so that every segment
+    // of a level is judged by the same number whatever the order of the waves).
+    if (lane == 0u && (uint64_t)cnt * 10u >= (uint64_t)a.n_total * 9u) a.counters->bulk_area_next = half_area3(nlo, nhi);
     // ---- object split: candidate c = (axis, k): bins 0..k of the axis go left ----
     float o_cost = INFINITY, o_l[6], o_r[6]; uint32_t o_idx = 0xffffffffu, o_nl = 0u, o_nr = 0u;
     for (uint32_t c = lane; c < 3u * (uint32_t)(kObjBins - 1); c += kWave) {
@@ -230,7 +241,7 @@ __device__ __forceinline__ void select_split(const SplitArgs &a, SplitSeg &sg, c
             il[c] = fmaxf(o_l[c] - pad, o_r[c] - pad); ih[c] = fminf(o_l[3 + c] + pad, o_r[3 + c] + pad);
             if (!(il[c] < ih[c])) overlap = false;
         }
-        my_try = overlap && half_area3(il, ih) > a.alpha_area;
+        my_try = overlap && half_area3(il, ih) > a.alpha * a.counters->bulk_area;
     }
     const bool try_sp = sg.budget > 0u && (!obj_ok || __ballot(my_try) != 0ull);
     // ---- spatial split: candidate c = (axis, k): the plane between bins k and k + 1 ----
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(256) void k_split_plan_apply(SplitArgs a) {
     if (ai == 0u) {
         cn->n_act = 2u * tot_split; cn->n_chunks = (uint32_t)(t2 >> 32); cn->src_total = tot_dst; cn->n_big = (uint32_t)t2;
         cn->n_cells = cell_base + tot_cells; cn->n_top = top_base + tot_split; cn->n_out = out_base + tot_out;
-        cn->n_segs = seg_base + 2u * tot_split; cn->retry = 0u; cn->n_cut = 0u;
+        cn->n_segs = seg_base + 2u * tot_split; cn->retry = 0u; cn->n_cut = 0u; cn->bulk_area = cn->bulk_area_next;
     }
 }
 
@@ -556,15 +567,7 @@ SplitPhaseResult gpu_split_phase(const GpuBuildArgs &b, uint32_t n_valid, const 
     S_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, a.flags, a.scan, (int)(std::max(cap, b.n) + 4096u), s));      // (also the plan's scans over a level's segments: at most cap + 2)
     S_TRY(arena.alloc(&temp, scan_bytes));
 
-    {   // the scene's area for the alpha test: the host takes the unpadded box of all primitives
-        BuildCounters h{};
-        S_TRY(hipMemcpyAsync(&h, b.counters, sizeof h, hipMemcpyDeviceToHost, s));
-        S_TRY(hipStreamSynchronize(s));
-        float lo[3], hi[3];
-        for (int d = 0; d < 3; ++d) { lo[d] = ord2f(h.bmin[d]); hi[d] = ord2f(h.bmax[d]); }
-        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-        a.alpha_area = sp.alpha * (dx * dy + dy * dz + dz * dx);
-    }
+    a.alpha = sp.alpha; a.n_total = n_valid;
     // references of the valid primitives, in primitive order
     hipLaunchKernelGGL(k_split_valid_flags, dim3(blocks(b.n, 256)), dim3(256), 0, s, b, a.flags);
     S_TRY(hipcub::DeviceScan::ExclusiveSum(temp, scan_bytes, a.flags, a.scan, (int)b.n, s));

@@ -151,6 +151,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_PATHS_SHADE")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->paths_shade_threshold = v; }
     if (const char *e = std::getenv("HRT_TLAS_INSTANCED")) ctx->tlas_instanced = std::atoi(e);
     if (const char *e = std::getenv("HRT_BUILD")) ctx->build_on_device = std::strcmp(e, "host") != 0;
+    if (const char *e = std::getenv("HRT_QUANT_GUARD")) { const double q = std::atof(e); if (q >= 0.0) ctx->quant_guard = (float)q; }
     if (const char *e = std::getenv("HRT_BUILD_TOPDOWN")) ctx->build_topdown = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_FAST_TRACE_BUILD")) ctx->fast_trace_on_device = std::strcmp(e, "device") == 0;
     if (const char *e = std::getenv("HRT_SBVH_BUDGET")) { const double v = std::atof(e); if (v >= 0.0 && v <= 8.0) ctx->split_budget = (float)v; }

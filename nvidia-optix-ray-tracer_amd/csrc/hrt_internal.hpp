@@ -178,6 +178,7 @@ struct HrtContext {
     int substream_min_pixels = 32768;
     int tlas_instanced = 0;                     // 1: hrt_tlas_build makes trees over instances too, 0: only rebuilds during updates do, -1: never
     int build_on_device = 1;                    // 1: PLOC build on the GPU (build.hip), 0: binned-SAH build on the host (HRT_BUILD=host; needs a host copy of the geometry)
+    float quant_guard = 1.25f;                  // device builds (HRT_QUANT_GUARD; 0: off): see build.hip emit_item
     int build_topdown = 1;                      // device builds of more than 4096 primitives start with the top-down phase of build_split.hip (object splits; HRT_BUILD_TOPDOWN=0: PLOC alone)
     int fast_trace_on_device = 1;               // HRT_CTX_FAST_TRACE builds: 1 = on the device with spatial splits (build_split.hip), 0 = the host builder (HRT_FAST_TRACE_BUILD=device|host)
     float split_budget = 1.0f, split_alpha = 1e-5f, split_bias = 0.95f, split_cut_bias = 1.0f; int split_cell_refs = 16;      // the device's spatial splits (HRT_SBVH_BUDGET / _ALPHA / _BIAS / _CELL_REFS)
