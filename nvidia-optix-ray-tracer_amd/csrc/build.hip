@@ -246,7 +246,10 @@ __global__ __launch_bounds__(256) void k_ploc_nn(GpuBuildArgs a, const uint32_t 
         const int j = (int)i + d;
         if (d == 0 || j < 0 || j >= (int)m || s_cell[me + d] != my_cell) continue;
         const float ar = merged_half_area(mlo, mhi, s_lo[me + d], s_hi[me + d]);
-        if (ar < best || bj == kNone) { best = ar; bj = (uint32_t)j; }      // strict <: the first (lowest) position wins ties; NaN areas still pick something
+        // strict <: the first (lowest) position wins ties -- except that position i ^ 1 beats any other of the same area: among thousands of
+        // coinciding primitives every cluster would otherwise choose the lowest position in reach, one pair a round would be mutual and the
+        // tree a chain (6000 copies of a triangle: depth 860); with the pairing rule they halve every round.  NaN areas still pick something
+        if (ar < best || bj == kNone || (ar == best && (uint32_t)j == (i ^ 1u))) { best = ar; bj = (uint32_t)j; }
     }
     a.nn[i] = bj;
 }
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(1024) void k_ploc_small(GpuBuildArgs a, uint32_t *c
                 const uint32_t o = cin[j];
                 if (a.node_cell && a.node_cell[o] != my_cell) continue;
                 const float ar = merged_half_area(mlo, mhi, a.node_lo[o], a.node_hi[o]);
-                if (ar < best || bj == kNone) { best = ar; bj = (uint32_t)j; }
+                if (ar < best || bj == kNone || (ar == best && (uint32_t)j == (i ^ 1u))) { best = ar; bj = (uint32_t)j; }      // (k_ploc_nn's rule)
             }
             a.nn[i] = bj;
         }

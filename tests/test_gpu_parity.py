@@ -1206,6 +1206,39 @@ def test_fast_trace_tree_with_spatial_splits(hrt, oracle, gpu_available, monkeyp
         r.close()
 
 
+@pytest.mark.parametrize("case", ["identical", "two-clusters-far-apart"])
+def test_device_build_thousands_of_coinciding_primitives(hrt, oracle, gpu_available, case):
+    """6000 copies of one triangle among 6000 others: no plane separates them (they stay one cell of the top-down phase) and every merged
+    area ties, so PLOC's "lowest position wins" rule alone would pair one couple a round and hand the collapse a chain (depth 860: the
+    build used to fail on the traversal stack's depth limit); position i ^ 1 wins ties instead and the copies halve every round.  And a
+    scene of two clusters 5000 units apart (the scene's box says nothing about either).  Default build and HRT_CTX_FAST_TRACE; hits as
+    brute force finds them."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    scene = hrt.scenes.random_soup(12000, 0.1, 3, 96, 64, 1)
+    v = scene["instances"][0]["vertices"]
+    o, d = oracle.random_rays(3000, 9)
+    if case == "identical":
+        v[:6000] = v[0]
+    else:
+        v[:6000] += np.float32(5000.0)
+        o[:1500] += np.float32(5000.0)
+    scene["instances"][0]["normals"] = hrt.scenes.face_normals(v)
+    rt, ru, rv, rprim, rinst = oracle.OracleScene(scene, force_brute=True).trace(o, d)
+    assert (rprim != 0xFFFFFFFF).sum() > 1000
+    for flags in (0, hrt.CTX_FAST_TRACE):
+        r = hrt.Renderer(0, flags)
+        try:
+            r.load_scene(scene)
+            t, u, vv, prim, inst = r.trace_rays(o, d)
+            assert np.array_equal(prim, rprim) and np.array_equal(t.view(np.uint32), rt.view(np.uint32)) and np.array_equal(u.view(np.uint32), ru.view(np.uint32))
+            r.set_frame(96, 64, 3, aov=False)
+            r.render(1)
+            assert r.stats().bvh_depth <= 12
+        finally:
+            r.close()
+
+
 def test_default_build_shapes_the_reference_kind_of_scene(hrt, oracle, gpu_available, monkeypatch):
     """The reference's kind of scene: hundreds of particles instancing a few closed shapes over a ground sphere of radius 1000.  PLOC
     alone (bottom-up merges in Morton order, search radius 2) has no view of such a scene's large-scale structure and its tree costs
