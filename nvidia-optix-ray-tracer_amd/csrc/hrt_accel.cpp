@@ -38,7 +38,12 @@ ScratchArena scratch_acquire(HrtContext *ctx, size_t bytes) {
     }
     ScratchArena a;
     a.bytes = bytes + bytes / 4 + 4096;
-    if (hipMalloc(&a.p, a.bytes) != hipSuccess) { (void)hipGetLastError(); a = ScratchArena(); }
+    if (hipMalloc(&a.p, a.bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        pool_drain(ctx);                                   // (the trees' cached blocks first, then exactly what was asked for)
+        a.bytes = bytes;
+        if (hipMalloc(&a.p, a.bytes) != hipSuccess) { (void)hipGetLastError(); a = ScratchArena(); }
+    }
     return a;
 }
 void scratch_release(HrtContext *ctx, ScratchArena a) {
@@ -62,6 +67,7 @@ void scratch_release(HrtContext *ctx, ScratchArena a) {
 // out again to the next build: an update that rebuilds (every file's first frame in the reference's Time mode) otherwise spends more
 // time in ~20 hipMalloc / hipFree pairs -- each hipFree waits for the device -- than in its kernels.  Eight size classes per octave;
 // blocks above 64 MiB and anything beyond 1 GiB in all go back to the runtime.
+void pool_drain(HrtContext *ctx);
 static size_t pool_class(size_t bytes) {
     bytes = std::max<size_t>(bytes, 256);
     size_t p2 = 256;
@@ -81,7 +87,15 @@ hipError_t pool_alloc(HrtContext *ctx, void **p, size_t bytes) {
                 return hipSuccess;
             }
     }
-    const hipError_t e = hipMalloc(p, cls);
+    hipError_t e = hipMalloc(p, cls);
+    if (e != hipSuccess) {          // out of memory: what the pool and the builds' arenas keep goes back to the runtime first
+        (void)hipGetLastError();
+        pool_drain(ctx);
+        std::vector<ScratchArena> arenas;
+        { std::lock_guard<std::mutex> lk(ctx->scratch_mu); arenas.swap(ctx->scratch_free); }
+        for (const ScratchArena &a : arenas) (void)hipFree(a.p);
+        e = hipMalloc(p, cls);
+    }
     if (e == hipSuccess) { std::lock_guard<std::mutex> lk(ctx->pool_mu); ctx->pool_live[*p] = cls; }
     return e;
 }
