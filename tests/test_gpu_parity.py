@@ -1206,7 +1206,7 @@ def test_fast_trace_tree_with_spatial_splits(hrt, oracle, gpu_available, monkeyp
         r.close()
 
 
-@pytest.mark.parametrize("case", ["identical", "two-clusters-far-apart"])
+@pytest.mark.parametrize("case", ["identical", "points", "two-clusters-far-apart"])
 def test_device_build_thousands_of_coinciding_primitives(hrt, oracle, gpu_available, case):
     """6000 copies of one triangle among 6000 others: no plane separates them (they stay one cell of the top-down phase) and every merged
     area ties, so PLOC's "lowest position wins" rule alone would pair one couple a round and hand the collapse a chain (depth 860: the
@@ -1220,6 +1220,8 @@ def test_device_build_thousands_of_coinciding_primitives(hrt, oracle, gpu_availa
     o, d = oracle.random_rays(3000, 9)
     if case == "identical":
         v[:6000] = v[0]
+    elif case == "points":
+        v[:6000] = np.float32(0.25)          # 6000 triangles shrunk to one point: boxes without area (the collapse's costs would all tie)
     else:
         v[:6000] += np.float32(5000.0)
         o[:1500] += np.float32(5000.0)
