@@ -54,6 +54,15 @@ typedef struct HrtContext HrtContext;
                                     visibility bit or a degraded tree rebuilds, a changed sbtOffset refreshes the material tables.  The FIRST update
                                     after a build is synchronous in either mode (one small read-back per build): the reference builds every file's IAS
                                     with identity transforms and poses it afterwards, so that update is the one that has to rebuild. */
+#define HRT_CTX_TWO_LEVEL 0x10u  /* hrt_tlas_build keeps the reference's structure, an IAS over shared GASes (RendererImpl.cu:174-206; GAS by shapeID,
+                                    RendererTime.cu:116-130): a top level over the instances whose leaves are TRANSFORM NODES, one object-space tree per
+                                    unique BLAS behind it -- memory, build and update cost grow with instances + unique primitives instead of
+                                    instances x primitives; a ray entering an instance is transformed into its object space (csrc/bvh8.h, fused.hip).
+                                    Without the flag such a tree is built when the flattened one would leave the caches (more than 4 M flattened
+                                    primitives, at least 4 per unique one; HRT_TWO_LEVEL=1 / -1: always / never).  Hits of such a tree are pinned to the
+                                    oracle's INSTANCED mode (object-space triangle test), those of a flattened tree to its FLATTENED mode: the two
+                                    differ in rounding, not in geometry.  Trees too deep for the path kernel's stack, and contexts that count
+                                    (HRT_CTX_COUNT) or run another execution mode (HRT_FUSED != 1), flatten. */
 #define HRT_CTX_FAST_TRACE 0x4u  /* hrt_tlas_build prefers trace speed to build speed: the reference's OPTIX_BUILD_FLAG_PREFER_FAST_TRACE
                                     (its GAS builds, RendererImpl.cu:94,118,144).  The tree is then built WITH SPATIAL SPLITS: on the device
                                     (csrc/build_split.hip: top-down SAH splits of references level by level, PLOC within the cells that

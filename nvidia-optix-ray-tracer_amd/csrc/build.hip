@@ -416,8 +416,15 @@ __device__ __forceinline__ bool first_of_its_prim(const uint32_t *gk, int w) {
 // are computed by all of them alike, then every lane walks, counts and writes ITS child -- a thread that did the eight children one
 // after the other spent ~100 us in some two hundred dependent loads, and a level cannot start before the one above is done.
 // (live: the group has an item; dead groups go through the shuffles without touching memory)
-__device__ void emit_item(const GpuBuildArgs &a, uint32_t b2, uint32_t self, uint2 *__restrict__ items_next, uint32_t next_level_begin, uint32_t is_root_level, bool live) {
+// Two-level trees (a.instance_leaves: every primitive is an instance): a leaf child is not a record but a TRANSFORM NODE (bvh8.h) in
+// its parent's child block, so that the traversal meets instances where it meets inner children -- in the node step, nearest first.
+// Such a child goes to the next level's items with kXformItem set and is written there by lane 0 of its group: the marker and the
+// instance; the refit that completes the build (refit.hip) fills in the matrix, the BLAS's root and the box.
+constexpr uint32_t kXformItem = 0x80000000u;
+__device__ void emit_item(const GpuBuildArgs &a, uint32_t b2, uint32_t self, uint2 *__restrict__ items_next, uint32_t next_level_begin, uint32_t is_root_level, bool live_item) {
     const int lane = (int)(threadIdx.x & 63u), g0 = lane & ~7, s = lane & 7;
+    const bool xform_item = live_item && (b2 & kXformItem) != 0u;
+    const bool live = live_item && !xform_item;          // (a transform node has no children: its group goes through the shuffles like a dead one)
     Forest f; f.n = 0;
     bool ch_leaf[8];
     int slot_child[8];
@@ -492,6 +499,7 @@ __device__ void emit_item(const GpuBuildArgs &a, uint32_t b2, uint32_t self, uin
     if (k >= 0 && leaf) {
         nr = leaf_refs(a, c, gks, lf);
         for (int w = 0; w < nr; ++w) if (first_of_its_prim(gks, w)) ++np;
+        if (a.instance_leaves) { c = lf[0] | kXformItem; leaf = false; np = 0u; }      // (max_leaf_prims = 1: the child is one BVH2 leaf = one instance)
     }
     const uint32_t inner = (k >= 0 && !leaf) ? 1u : 0u;
     // the group's running counts: where this lane's records and its inner child go
@@ -509,6 +517,16 @@ __device__ void emit_item(const GpuBuildArgs &a, uint32_t b2, uint32_t self, uin
     }
     child_base = __shfl(child_base, g0); prim_base = __shfl(prim_base, g0);
     const uint32_t imask = (uint32_t)((__ballot(inner != 0u) >> g0) & 0xffull);
+    if (xform_item && s == 0) {
+        const uint32_t leaf2 = b2 & ~kXformItem;
+        const uint32_t gk = __float_as_uint(a.node_hi[leaf2].w);                    // global primitive number = which instance
+        uint32_t *w32 = reinterpret_cast<uint32_t *>(a.out_nodes + (size_t)self * a.node_stride);
+        for (int q = 0; q < 20; ++q) w32[q] = 0u;                                   // word 3 == 0: the marker
+        w32[5] = find_instance(a.inst_first, a.n_inst, gk);
+        a.out_node_ref[2 * (size_t)self] = 1.0f; a.out_node_ref[2 * (size_t)self + 1] = 0.0f;
+        atomicAdd(&a.counters->total_below, 1.0f);
+        atomicAdd(&a.counters->next_prim, 1u);                                      // (counted like a record: the host checks that every instance came out)
+    }
     if (!live) return;
 
     unsigned char *nd = a.out_nodes + (size_t)self * a.node_stride;
@@ -706,6 +724,7 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     a.n = n; a.n_inst = in.n_inst; a.inst_first = in.d_inst_first; a.inst_kind = in.d_inst_kind; a.inst_src = in.d_inst_src;
     a.inst_xf = in.d_inst_xf; a.inst_identity = in.d_inst_identity;
     a.max_leaf_prims = in.max_leaf_prims; a.c_node = in.c_node; a.c_prim = in.c_prim; a.quant_guard = in.quant_guard;
+    a.instance_leaves = in.instance_leaves ? 1u : 0u;
     a.ploc_radius = in.ploc_radius < 1 ? 1 : (in.ploc_radius > kPlocMaxRadius ? kPlocMaxRadius : in.ploc_radius);
     a.out_nodes = in.out_nodes; a.node_stride = in.node_stride; a.out_prims = in.out_prims; a.prim_stride = in.prim_stride; a.out_node_ref = in.out_node_ref;
 
@@ -718,7 +737,7 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     B_TRY(hipGetLastError());
     // ---- spatial splits: the top-down phase turns the primitives into references grouped in cells ----
     // (a few thousand primitives: the splits buy nothing a ray could notice, and the small build below is the quicker one)
-    split = in.split.enabled && in.max_leaf_prims == kMaxLeafPrims && n >= std::max(in.split.cell_refs, 2u) && n > kSmallClusters / 4u;
+    split = in.split.enabled && (in.max_leaf_prims == kMaxLeafPrims || in.instance_leaves) && n >= std::max(in.split.cell_refs, 2u) && n > kSmallClusters / 4u;
     if (split) {
         B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
         B_TRY(hipStreamSynchronize(s));

@@ -13,7 +13,16 @@
 //     word 8-9  qlo_x[8]   word 10-11 qlo_y[8]   word 12-13 qlo_z[8]
 //     word 14-15 qhi_x[8]  word 16-17 qhi_y[8]   word 18-19 qhi_z[8]
 //
-//   PrimRecord (48 B, three 16-byte loads per test), world space, leaf order:
+//   Transform node of a TWO-LEVEL tree (same 80 B, in the child block of its parent like any inner child): word 3 == 0 marks it
+//   (a box node's exponents are never 0).  The instance's BLAS -- an object-space BVH8 shared by every instance of it -- hangs below:
+//     word 4    index of the BLAS's root node (in the same node array)
+//     word 5    instance index (= what a hit reports, and the SBT offset's key)
+//     word 6    1 when the transform is the identity (the ray is then copied, not multiplied)
+//     word 8-19 world -> object, 3x4 row major (inverse by cofactors in double, rounded once: hrt_accel.cpp invert_affine)
+//   This is the reference's IAS over shared GASes (src/Global/RendererImpl.cu:174-206, GAS chosen by shapeID at
+//   src/Global/RendererTime.cu:116-130): memory and update cost grow with instances + unique primitives.
+//
+//   PrimRecord (48 B, three 16-byte loads per test), world space (object space inside a BLAS of a two-level tree), leaf order:
 //     triangle: {v0.xyz, prim} {e1.xyz, inst} {e2.xyz, 0}        e1 = v1 - v0, e2 = v2 - v0 (float)
 //     sphere:   {c.xyz,  prim} {r, 0, 0, inst} {0, 0, 0, 1}      object-space centre/radius
 #pragma once
@@ -43,6 +52,7 @@ static_assert(sizeof(PrimRecord) == 48, "primitive record is 48 bytes");
 
 constexpr uint32_t kMaxLeafPrims = 3;      // unary count in 3 bits
 constexpr uint32_t kPrimKindTriangle = 0, kPrimKindSphere = 1;
+constexpr uint32_t kPrimKindInstance = 2;      // builder input only: the "primitive" is an instance's BLAS box (the top level of a two-level tree)
 
 // Input primitive for the builder: a record plus its (unpadded) world-space bounds.
 struct BuildPrim {

@@ -53,6 +53,18 @@ HRT_HD void sphere_world_bounds(const float *c, float r, const float *m, bool id
     }
 }
 
+// World-space bounds of an object-space box (lo[3], hi[3]) under an instance transform: its transformed corners (the top level of a
+// two-level tree: an instance's BLAS box).
+HRT_HD void box_world_bounds(const float *b6, const float *m, bool identity, float *lo, float *hi) {
+    for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+    for (int k = 0; k < 8; ++k) {
+        const float q[3] = {(k & 1) ? b6[3] : b6[0], (k & 2) ? b6[4] : b6[1], (k & 4) ? b6[5] : b6[2]};
+        float w[3];
+        if (identity) { w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; } else xf_point(m, q, w);
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], w[a]); hi[a] = fmaxf(hi[a], w[a]); }
+    }
+}
+
 HRT_HD float box_half_area(const float *lo, const float *hi) {
     const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
     return ex * ey + ey * ez + ez * ex;

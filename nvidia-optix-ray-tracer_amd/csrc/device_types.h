@@ -155,7 +155,10 @@ struct RefitArgs {
     const uint32_t *order;         // NULL: node index = position (trees stored breadth first)
     const float *inst_xf;          // 12 floats per instance: object -> world
     const uint32_t *inst_identity;
-    const void *const *inst_src;   // per instance: object-space triangle vertices (9 floats per triangle) of its BLAS
+    const void *const *inst_src;   // per instance: object-space triangle vertices (9 floats per triangle) of its BLAS; the top level of a
+                                   // two-level tree: the BLAS's object-space box (6 floats)
+    const float *inst_inv;         // two-level trees: 12 floats per instance, world -> object (written into the transform nodes)
+    const uint32_t *inst_root;     // two-level trees: per instance, the node index of its BLAS's root
     float pad;
     const uint32_t *scale_bits;    // when set: pad = 4e-6 * max(1, scene scale) with the scale read from here (float bits; written by
                                    // k_instance_tables on the same stream), instead of the host's `pad`
@@ -169,6 +172,14 @@ struct RefitArgs {
 };
 constexpr uint32_t kRefitTopLevels = 16, kRefitTopLevelNodes = 128;      // (one pass of the 1024-thread workgroup per level; wider levels are quicker as launches of their own: 95 -> ~45 us for the reference's sample)
 struct RefitLevels { uint32_t n_levels; uint32_t first[kRefitTopLevels], count[kRefitTopLevels]; };   // phases in processing order, each at most kRefitTopLevelNodes wide
+// two-level trees: copy of one BLAS's template tree (packed: 80-byte nodes, 48-byte records) into a TLAS's arrays
+struct PackBlasArgs {
+    const unsigned char *src_nodes, *src_prims; uint32_t n_nodes, n_prims;
+    unsigned char *dst_nodes, *dst_prims; uint32_t node_stride, prim_stride;
+    uint32_t node_off, prim_off;   // where the tree lands: index of its root in the TLAS's node array, of its first record
+    uint32_t slot;                 // the BLAS's number in the tables of the pack's refit (written to the records' instance field)
+};
+void launch_pack_blas(const PackBlasArgs &a, hipStream_t s);
 void launch_refit_level(const RefitArgs &a, hipStream_t s);
 void launch_refit_records(const RefitArgs &a, hipStream_t s);
 // per-instance tables of an update derived on the device from the caller's instance array (asynchronous updates)
@@ -206,6 +217,7 @@ void launch_paths_v1(const TraverseArgs &a, bool has_spheres, uint32_t grid_bloc
 constexpr int kFusedBlocksPerCu = 16;  // k_fused is compiled for 4 waves per SIMD (125 VGPRs, nothing spilled): more workgroups per CU would only queue
 constexpr int kFusedMaxDepth = 12;     // deepest tree (levels below the root) k_fused takes: its per-lane node stack in LDS (trav_lean.h: kNodeStackLds)
 void launch_fused(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s);
+void launch_fused_instanced(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s);      // two-level trees (transform nodes, bvh8.h)
 void launch_trace_queue(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s);   // k_trace_queue (fused_queue.hip): wavefront mode's traverse kernel, the loop of k_fused over ray queues      // k_fused (fused.hip): the default
 void launch_sum(float4 *accum, const float4 *result, uint32_t n, uint32_t first_sample, hipStream_t s);
 void launch_bin(const BinArgs &a, uint32_t grid_blocks, hipStream_t s);

@@ -35,7 +35,16 @@ namespace hrt {
 #define HRT_PRIO_REGEN 2     // shading, next pixel, new ray
 #endif
 
-template <bool HAS_SPHERES>
+struct InstLane { uint32_t inst_cur = kNoWork, frame = 0u; };
+struct NoInstLane { static constexpr uint32_t inst_cur = 0u; };
+
+// INSTANCED: the tree has two levels (bvh8.h: transform nodes; the reference's IAS over shared GASes, RendererImpl.cu:174-206).  A lane
+// whose next node turns out to be a transform node leaves its world ray in LDS, goes on with the ray in the instance's object space
+// (row-major 3x4 inverse from the node; identity: copied) and the BLAS's root as the only child; its node stack continues ABOVE what it
+// held (`base` = the frame's bottom), so the bookkeeping sequence is the one-level kernel's, unchanged.  When it reports the frame
+// empty the lane takes its world ray back and pops what it had left in world space.  A separate instantiation: the one-level kernels
+// and their register budget are untouched.
+template <bool HAS_SPHERES, bool INSTANCED>
 #ifndef HRT_FUSED_WAVES_PER_SIMD
 #define HRT_FUSED_WAVES_PER_SIMD 4      // 128 VGPRs, a dozen kernel constants spilled; 5 waves (96 VGPRs, 95 spilled around the shading): 2560 against 3122 Mrays/s
 #endif
@@ -54,6 +63,10 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
     const float tmin = a.tmin, tmax_ray = a.tmax;
     const uint32_t tx = threadIdx.x;
     const uint32_t ldsn = (uint32_t)reinterpret_cast<uintptr_t>(&s_nodes[0][tx]), ldsl = (uint32_t)reinterpret_cast<uintptr_t>(&s_leaves[0][tx]);
+
+    // INSTANCED: the instance whose BLAS this lane is in (kNoWork: none), and what its node stack looked like when it went in
+    // (base | entries << 8); the lane's world ray waits in LDS meanwhile (the mailboxes' memory: tail splitting is off for two-level trees)
+    std::conditional_t<INSTANCED, InstLane, NoInstLane> I;
 
     LeanLane L;
     lean_reset(L);
@@ -190,6 +203,7 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
                 any = px_depth >= kRayTraceDepth;      // a hit at the depth limit is black whatever it is (Shader.cu:102-107)
                 if (any) ++px_rays_any; else ++px_rays_closest;
                 lean_start(L, ro, rd, tmax_ray);
+                if constexpr (INSTANCED) I.inst_cur = kNoWork;      // (an any-hit ray may have ended inside an instance)
                 alive = true;
             }
         }
@@ -211,7 +225,7 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
                 //      the lane that owns the ray: a piece publishes every improvement there (canonical order: the result does not
                 //      depend on who found what, or when) and adopts what the others found closer, so every piece culls with the
                 //      ray's best hit so far. ----
-                if (kTail && a.tail_split) {          // (one donation per busy lane and iteration: more rounds of this change nothing, r02_sweep_tile_tail.txt)
+                if (kTail && !INSTANCED && a.tail_split) {          // (one donation per busy lane and iteration: more rounds of this change nothing, r02_sweep_tile_tail.txt)
                     const bool is_free = !alive && !waiting && !have_pixel && !shared;
                     const uint64_t free_m = __ballot(is_free);
                     const uint64_t donors = __ballot(alive && L.nsp > L.base);
@@ -273,11 +287,11 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
                     if (L.pidx != kNoWork) {
                         const float4 pa = make_float4(rpa.x, rpa.y, rpa.z, rpa.w), pb = make_float4(rpb.x, rpb.y, rpb.z, rpb.w),
                                      pc = make_float4(rpc.x, rpc.y, rpc.z, rpc.w);
-                        improved = test_prim<HAS_SPHERES>(pa, pb, pc, L.s, tmin, tmax_ray, a.inst_inv, a.inst_identity);
+                        improved = test_prim<HAS_SPHERES, INSTANCED>(pa, pb, pc, L.s, tmin, tmax_ray, a.inst_inv, a.inst_identity, I.inst_cur);
                         hit_any = any && improved;
                     }
                 }
-                if (kTail && a.tail_split) {
+                if (kTail && !INSTANCED && a.tail_split) {
                     // pieces of split rays publish their improvements one lane at a time (rare: a few per ray) ...
                     uint64_t pub = __ballot(improved && shared);
                     while (pub) {
@@ -307,7 +321,33 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
                 uint2 child = make_uint2(0u, 0u), tri = make_uint2(0u, 0u);
                 __builtin_amdgcn_s_setprio(HRT_PRIO_NODE);
                 wait_node_loads(rn0, rn1, rn2, rn3, rn4);
-                if (L.nidx != kNoWork && !hit_any) lean_node(L.s, tmin, rn0, rn1, rn2, rn3, rn4, child, tri);
+                [[maybe_unused]] bool enter = false;
+                if constexpr (!INSTANCED) {
+                    if (L.nidx != kNoWork && !hit_any) lean_node(L.s, tmin, rn0, rn1, rn2, rn3, rn4, child, tri);
+                } else {
+                    enter = L.nidx != kNoWork && !hit_any && rn0.w == 0u;          // a transform node: word 3 == 0
+                    if (L.nidx != kNoWork && !hit_any && !enter) lean_node(L.s, tmin, rn0, rn1, rn2, rn3, rn4, child, tri);
+                    if (__ballot(enter) != 0ull) {
+                        if (enter) {
+                            TravState &s = L.s;
+                            s_mb_t[tx] = s.ox; s_mb_u[tx] = s.oy; s_mb_v[tx] = s.oz;
+                            s_mb_prim[tx] = __float_as_uint(s.dx); s_mb_inst[tx] = __float_as_uint(s.dy); s_mb_pending[tx] = __float_as_uint(s.dz);
+                            I.inst_cur = rn1.y;
+                            if (rn1.z == 0u) {          // not the identity: xf_point / xf_vector of the oracle, operation for operation
+                                const float m0 = __uint_as_float(rn2.x), m1 = __uint_as_float(rn2.y), m2 = __uint_as_float(rn2.z), m3 = __uint_as_float(rn2.w);
+                                const float m4 = __uint_as_float(rn3.x), m5 = __uint_as_float(rn3.y), m6 = __uint_as_float(rn3.z), m7 = __uint_as_float(rn3.w);
+                                const float m8 = __uint_as_float(rn4.x), m9 = __uint_as_float(rn4.y), m10 = __uint_as_float(rn4.z), m11 = __uint_as_float(rn4.w);
+                                const float ox = s.ox, oy = s.oy, oz = s.oz, dx = s.dx, dy = s.dy, dz = s.dz;
+                                s.ox = ((m0 * ox + m1 * oy) + m2 * oz) + m3; s.oy = ((m4 * ox + m5 * oy) + m6 * oz) + m7; s.oz = ((m8 * ox + m9 * oy) + m10 * oz) + m11;
+                                s.dx = (m0 * dx + m1 * dy) + m2 * dz; s.dy = (m4 * dx + m5 * dy) + m6 * dz; s.dz = (m8 * dx + m9 * dy) + m10 * dz;
+                            }
+                            s.idx = safe_rcp_dir<false>(s.dx); s.idy = safe_rcp_dir<false>(s.dy); s.idz = safe_rcp_dir<false>(s.dz);
+                            const uint32_t oct = (s.dx < 0.0f ? 4u : 0u) | (s.dy < 0.0f ? 2u : 0u) | (s.dz < 0.0f ? 1u : 0u);
+                            s.oct_inv4 = (7u - oct) * 0x01010101u;
+                            child = make_uint2(rn1.x, 0x01000000u);      // one child, no inner-mask bits: the pick below is child base + 0 = the BLAS's root
+                        }
+                    }
+                }
                 // ---- B. bookkeeping (trav_lean.h: one hand-written sequence): file the new groups; the leaf pass (ONE per iteration, one
                 //      primitive per lane, skipped while few lanes have leaf work and none depends on it); the primitive and the node of
                 //      the next iteration; finished? ----
@@ -317,8 +357,28 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
                 // dropped when the lane's next ray starts, lean_start)
                 if (hit_any) { L.nidx = kNoWork; L.pidx = kNoWork; done = true; }
                 if (alive && !done) done = lean_bookkeeping_asm(L, child, tri, ldsn, ldsl, (uint32_t)a.postpone_pct, (uint32_t)a.leaf_quorum) != 0u;
+                if constexpr (INSTANCED) {
+                    // in: the frame starts above what the lane holds (siblings still in hand have just been pushed, step 2 of the sequence)
+                    if (enter) { I.frame = (uint32_t)L.base | ((uint32_t)L.nsp << 8); L.base = L.nsp; }
+                    // out: the frame is empty -- nothing in hand, on the node stack above `base`, or in the leaf stack -- but the ray is not done
+                    const bool leave = done && !hit_any && I.inst_cur != kNoWork;
+                    if (__ballot(leave) != 0ull) {
+                        if (leave) {
+                            TravState &s = L.s;
+                            s.ox = s_mb_t[tx]; s.oy = s_mb_u[tx]; s.oz = s_mb_v[tx];
+                            s.dx = __uint_as_float(s_mb_prim[tx]); s.dy = __uint_as_float(s_mb_inst[tx]); s.dz = __uint_as_float(s_mb_pending[tx]);
+                            s.idx = safe_rcp_dir<false>(s.dx); s.idy = safe_rcp_dir<false>(s.dy); s.idz = safe_rcp_dir<false>(s.dz);
+                            const uint32_t oct = (s.dx < 0.0f ? 4u : 0u) | (s.dy < 0.0f ? 2u : 0u) | (s.dz < 0.0f ? 1u : 0u);
+                            s.oct_inv4 = (7u - oct) * 0x01010101u;
+                            I.inst_cur = kNoWork;
+                            L.base = (int)(I.frame & 0xffu); L.nsp = (int)(I.frame >> 8);
+                            if (L.nsp != L.base) { --L.nsp; s.cur = s_nodes[L.nsp][tx]; }      // (only groups with hits are ever pushed)
+                            if (s.cur.y > 0x00ffffffu) { lean_pick_node(L); done = false; }
+                        }
+                    }
+                }
                 if (done && (!kTail || !shared)) { alive = false; waiting = true; }
-                if (kTail && a.tail_split) {
+                if (kTail && !INSTANCED && a.tail_split) {
                     // a piece that has finished has nothing left to merge: the mailbox holds the ray's best hit
                     if (alive && done && shared) {
                         atomicSub(&s_mb_pending[home], 1u);
@@ -359,8 +419,14 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
 // one launch renders every sample of every pixel of the tile
 void launch_fused(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s) {
     const dim3 g(grid_blocks), b(kTraverseBlock);
-    if (has_spheres) hipLaunchKernelGGL((k_fused<true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_fused<false>), g, b, 0, s, a);
+    if (has_spheres) hipLaunchKernelGGL((k_fused<true, false>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_fused<false, false>), g, b, 0, s, a);
+}
+// ... through a two-level tree (transform nodes over shared BLASes)
+void launch_fused_instanced(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s) {
+    const dim3 g(grid_blocks), b(kTraverseBlock);
+    if (has_spheres) hipLaunchKernelGGL((k_fused<true, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_fused<false, true>), g, b, 0, s, a);
 }
 
 }  // namespace hrt

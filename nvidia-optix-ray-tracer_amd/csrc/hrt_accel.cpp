@@ -136,7 +136,8 @@ void free_tlas_device(HrtContext *ctx, Tlas &t) {
     pool_release(ctx, (void *)t.d_inst_src);
     pool_release(ctx, (void *)t.d_inst_first);
     pool_release(ctx, (void *)t.d_inst_kind);
-    t.d_inst_first = t.d_inst_kind = nullptr;
+    pool_release(ctx, (void *)t.d_inst_root);
+    t.d_inst_first = t.d_inst_kind = t.d_inst_root = nullptr;
     pool_release(ctx, (void *)t.d_sig_handle);
     pool_release(ctx, (void *)t.d_sig_visibility);
     pool_release(ctx, (void *)t.d_sig_sbt);
@@ -207,13 +208,23 @@ int ensure_host_geometry(HrtContext *ctx, Blas &b, hipStream_t s) {
 // Object-space BVH8 of one BLAS (built once): the subtree every instance of it gets in a tree over instances.  Built on the
 // device like everything else (one identity instance); only its topology -- nodes' child / primitive bases, masks, the
 // primitive ids -- comes back to the host, where assemble_instanced_bvh8 stitches instance subtrees under a top tree.
-int ensure_template(HrtContext *ctx, Blas &b, hipStream_t s) {
+// keep_device: the topology also stays on the device (Blas::d_tmpl_*), for two-level TLASes to copy from
+static int template_to_device(HrtContext *ctx, Blas &b, hipStream_t s) {
+    if (b.d_tmpl_nodes || b.tmpl.nodes.empty()) return HRT_OK;
+    HIP_TRY(ctx, hipMalloc((void **)&b.d_tmpl_nodes, sizeof(Bvh8Node) * b.tmpl.nodes.size()));
+    HIP_TRY(ctx, hipMalloc((void **)&b.d_tmpl_prims, sizeof(PrimRecord) * std::max<size_t>(b.tmpl.prims.size(), 1)));
+    HIP_TRY(ctx, hipMemcpyAsync(b.d_tmpl_nodes, b.tmpl.nodes.data(), sizeof(Bvh8Node) * b.tmpl.nodes.size(), hipMemcpyHostToDevice, s));
+    if (!b.tmpl.prims.empty()) HIP_TRY(ctx, hipMemcpyAsync(b.d_tmpl_prims, b.tmpl.prims.data(), sizeof(PrimRecord) * b.tmpl.prims.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    return HRT_OK;
+}
+int ensure_template(HrtContext *ctx, Blas &b, hipStream_t s, bool keep_device = false) {
     if (!ctx->build_on_device) {
         const int rc = ensure_host_geometry(ctx, b, s);
         if (rc != HRT_OK) return rc;
     }
     std::lock_guard<std::mutex> lk(b.tmpl_mu);
-    if (b.tmpl_built) return HRT_OK;
+    if (b.tmpl_built) return keep_device ? template_to_device(ctx, b, s) : HRT_OK;
     if (!ctx->build_on_device) {
         std::vector<BuildPrim> prims;
         prims.reserve(b.n_prims);
@@ -232,7 +243,7 @@ int ensure_template(HrtContext *ctx, Blas &b, hipStream_t s) {
         }
         build_bvh8(prims, b.tmpl, 0);
         b.tmpl_built = true;
-        return HRT_OK;
+        return keep_device ? template_to_device(ctx, b, s) : HRT_OK;
     }
     b.tmpl = Bvh8();
     const uint32_t n = b.n_prims;
@@ -272,7 +283,7 @@ int ensure_template(HrtContext *ctx, Blas &b, hipStream_t s) {
     b.tmpl.max_depth = r.max_depth; b.tmpl.level_begin = r.level_begin;
     if (b.kind == kPrimKindTriangle) b.tmpl.n_triangles = r.n_prims; else b.tmpl.n_spheres = r.n_prims;
     b.tmpl_built = true;
-    return HRT_OK;
+    return keep_device ? template_to_device(ctx, b, s) : HRT_OK;
 }
 
 // Build a TLAS on the host and upload it together with the tables the device refit needs (hrt_tlas_update).
@@ -283,7 +294,9 @@ int ensure_template(HrtContext *ctx, Blas &b, hipStream_t s) {
 //    computes every box and world-space record.  The shape the reference's own scenes have (particles instancing a
 //    few shapes); used when a refitted tree has degraded and has to be rebuilt while frames are being rendered.
 // Either way the result is one world-space BVH8: the traversal kernels do not know the difference.
-static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s, bool instanced, bool fast_trace) {
+constexpr int kRetryFlattened = 1;      // build_tlas_fresh: the two-level tree asked for cannot be had (too deep for the path kernel's stack): build the flattened one
+
+static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s, bool instanced, bool fast_trace, int two_level_mode) {
     const uint32_t n = (uint32_t)inst.size();
     std::vector<std::shared_ptr<Blas>> refs(n);
     {
@@ -318,6 +331,26 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         first[i + 1] = first[i] + cnt;
         if (refs[i]->kind == kPrimKindTriangle) n_tri_in += cnt; else n_sph_in += cnt;
         (void)n_sph_in;
+    }
+    // ---- two levels or one?  Flattening costs memory, build and refit time in proportion to instances x primitives; a two-level tree
+    //      (transform nodes over one shared tree per BLAS) in proportion to instances + unique primitives, at the price of a ray
+    //      transform per instance entered.  Asked for (two_level_mode > 0), or chosen when the flattened tree would leave the caches
+    //      while the shared one stays in them.  Only k_fused walks such trees: not under HRT_CTX_COUNT / HRT_FUSED != 1. ----
+    bool two_level = false;
+    std::vector<Blas *> uniq; std::vector<uint32_t> slot_of(n, 0u);
+    if (two_level_mode >= 0 && !instanced && device_merged && !device_split && first[n] != 0u && (ctx->flags & HRT_CTX_COUNT) == 0 && ctx->fused == 1) {
+        std::unordered_map<Blas *, uint32_t> seen;
+        uint64_t unique_prims = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            Blas *b = refs[i].get();
+            if ((inst[i].visibilityMask & 1u) == 0 || b->n_prims == 0u || !(b->lo[0] <= b->hi[0])) continue;
+            auto it = seen.find(b);
+            if (it == seen.end()) { it = seen.emplace(b, (uint32_t)uniq.size()).first; uniq.push_back(b); unique_prims += b->n_prims; }
+            slot_of[i] = it->second;
+        }
+        two_level = !uniq.empty() && (two_level_mode > 0 || ((uint64_t)first[n] >= ctx->two_level_min_prims &&
+                                                             (double)first[n] >= (double)ctx->two_level_min_share * (double)unique_prims));
+        if (two_level && fast_trace && two_level_mode <= 0) two_level = false;      // (a static scene that asks for the best tree gets the flattened one with spatial splits)
     }
     if (device_split) {
         // the split build's working memory (~1.2 KB per primitive with the staged output) has to be there: otherwise the default build
@@ -405,8 +438,12 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
     const size_t pb = (size_t)t.prim_stride * std::max<size_t>(n_prims, 1);
     std::vector<const void *> src(std::max(n, 1u), nullptr);
     for (uint32_t i = 0; i < n; ++i) src[i] = t.blas_refs[i]->d_verts;
+    if (two_level) {      // the top level's "geometry" is the instances' BLAS boxes
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_blas_box, sizeof(float) * 6 * (size_t)std::max(n, 1u)));
+        for (uint32_t i = 0; i < n; ++i) src[i] = t.d_blas_box + 6 * (size_t)i;
+    }
     if (!on_device) HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_nodes, nb));
-    if (!(on_device && device_split)) HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_prims, pb));      // (a split build knows its record count afterwards)
+    if (!(on_device && (device_split || two_level))) HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_prims, pb));      // (a split build knows its record count afterwards; a two-level tree holds the unique primitives' records only)
     HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_inv, sizeof(float) * t.h_inv.size()));
     HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_xf, sizeof(float) * t.h_xf.size()));
     HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_identity, sizeof(uint32_t) * t.h_ident.size()));
@@ -431,7 +468,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_sig_handle, sizeof(unsigned long long) * sigh.size()));
         HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_sig_visibility, sizeof(uint32_t) * std::max(n, 1u)));
         HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_sig_sbt, sizeof(uint32_t) * std::max(n, 1u)));
-        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_blas_box, sizeof(float) * bbox.size()));
+        if (!t.d_blas_box) HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_blas_box, sizeof(float) * bbox.size()));
         HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_update_flags, sizeof(uint32_t) * 2));
         if (!t.h_update_flags) HIP_TRY(ctx, hipHostMalloc((void **)&t.h_update_flags, sizeof(uint32_t) * 4, hipHostMallocDefault));
         t.h_update_flags[0] = t.h_update_flags[2] = 0x3f800000u; t.h_update_flags[1] = t.h_update_flags[3] = 0u;
@@ -446,7 +483,142 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
     ra.prims = reinterpret_cast<unsigned char *>(t.d_prims); ra.prim_stride = t.prim_stride;
     ra.node_box = t.d_node_box; ra.node_ref = t.d_node_ref; ra.inst_xf = t.d_inst_xf; ra.inst_identity = t.d_inst_identity;
     ra.inst_src = t.d_inst_src; ra.pad = 4e-6f * std::max(1.0f, scene_scale); ra.write_reference = 1u;
-    if (on_device) {
+    if (on_device && two_level) {
+        // ---- a two-level tree.  (1) every unique BLAS has its object-space tree (topology), built once per BLAS and kept on the device;
+        //      (2) the device build over the instances' boxes, whose leaves come out as transform nodes; (3) the BLAS trees are copied in
+        //      behind the top level and refitted in object space; (4) the top level's refit -- the only part an update repeats. ----
+        const uint32_t nu = (uint32_t)uniq.size();
+        std::vector<uint32_t> node_off(nu + 1, 0u), prim_off(nu + 1, 0u);
+        uint32_t blas_depth = 0;
+        for (uint32_t j = 0; j < nu; ++j) {
+            const int rc = ensure_template(ctx, *uniq[j], s, true);
+            if (rc != HRT_OK) return rc;
+            const Bvh8 &tp = uniq[j]->tmpl;
+            if ((uint64_t)node_off[j] + tp.nodes.size() > 0x7fffffffull || (uint64_t)prim_off[j] + tp.prims.size() > 0x7fffffffull) return fail(ctx, HRT_ERR_INVALID, "two-level tree: more than 2^31 nodes or records");
+            node_off[j + 1] = node_off[j] + (uint32_t)tp.nodes.size(); prim_off[j + 1] = prim_off[j] + (uint32_t)tp.prims.size();
+            blas_depth = std::max(blas_depth, tp.max_depth);
+        }
+        // the top level's primitives: one per visible instance of a non-empty BLAS
+        std::vector<uint32_t> first2(n + 1, 0u), kind2(std::max(n, 1u), kPrimKindInstance);
+        for (uint32_t i = 0; i < n; ++i) {
+            const Blas &b = *t.blas_refs[i];
+            first2[i + 1] = first2[i] + (((inst[i].visibilityMask & 1u) != 0 && b.n_prims != 0u && b.lo[0] <= b.hi[0]) ? 1u : 0u);
+        }
+        const uint32_t n2 = first2[n];
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_first, sizeof(uint32_t) * first2.size()));
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_kind, sizeof(uint32_t) * kind2.size()));
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_root, sizeof(uint32_t) * std::max(n, 1u)));
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_first, first2.data(), sizeof(uint32_t) * first2.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_kind, kind2.data(), sizeof(uint32_t) * kind2.size(), hipMemcpyHostToDevice, s));
+        GpuBuildInput in{};
+        in.n_prims = n2; in.n_inst = n; in.d_inst_first = t.d_inst_first; in.d_inst_kind = t.d_inst_kind; in.d_inst_src = t.d_inst_src;
+        in.d_inst_xf = t.d_inst_xf; in.d_inst_identity = t.d_inst_identity;
+        in.max_leaf_prims = 1; in.instance_leaves = true; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius; in.quant_guard = ctx->quant_guard;
+        in.split.enabled = ctx->build_topdown != 0; in.split.budget_frac = 0.0f; in.split.alpha = ctx->split_alpha; in.split.bias = ctx->split_bias; in.split.cut_bias = ctx->split_cut_bias;
+        in.split.cell_refs = (uint32_t)ctx->split_cell_refs; in.split.pad = ra.pad; in.split.verbose = std::getenv("HRT_BUILD_VERBOSE") != nullptr;
+        // worst case: a transform node per instance and fewer box nodes than instances
+        const size_t max_nodes = 2 * (size_t)n2 + 2;
+        const size_t stage_nodes = ((size_t)t.node_stride * max_nodes + 255u) & ~(size_t)255u, stage_ref = (sizeof(float) * 2 * max_nodes + 255u) & ~(size_t)255u;
+        // (the pack's refit tables and walk order share the block: nu small tables, one entry per BLAS node)
+        const size_t tab_xf = ((sizeof(float) * 12 * nu) + 255u) & ~(size_t)255u, tab_id = ((sizeof(uint32_t) * nu) + 255u) & ~(size_t)255u, tab_src = ((sizeof(void *) * nu) + 255u) & ~(size_t)255u;
+        const size_t tab_order = ((sizeof(uint32_t) * (size_t)node_off[nu]) + 255u) & ~(size_t)255u;
+        const size_t stage_all = stage_nodes + stage_ref + tab_xf + tab_id + tab_src + tab_order, want = gpu_build_scratch_bytes(n2, &in.split) + stage_all;
+        ScratchArena arena = scratch_acquire(ctx, want);
+        if (!arena.p) return fail(ctx, HRT_ERR_OOM, "device build: no working memory (%zu bytes)", want);
+        struct Release { HrtContext *c; ScratchArena a; hipStream_t st; ~Release() { (void)hipStreamSynchronize(st); scratch_release(c, a); } } release{ctx, arena, s};
+        unsigned char *stage = static_cast<unsigned char *>(arena.p);
+        in.out_nodes = stage; in.node_stride = t.node_stride; in.out_node_ref = reinterpret_cast<float *>(stage + stage_nodes);
+        in.out_prims = stage; in.prim_stride = t.prim_stride;        // (no record is written: the leaves are transform nodes)
+        in.scratch = stage + stage_all; in.scratch_bytes = arena.bytes - stage_all;
+        const GpuBuildResult r = gpu_build_bvh8(in, s);      // (synchronises the stream before it returns)
+        if (r.error != hipSuccess) return fail(ctx, r.error == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, "device build of the top level failed: %s (%s)", hipGetErrorString(r.error), r.where);
+        if (r.n_prims == 0u) return kRetryFlattened;                                 // nothing valid to instance: the flattened path emits the empty root
+        // the path kernel keeps one sibling group per level of BOTH trees on its node stack
+        if (r.max_depth + 1u + blas_depth > (uint32_t)ctx->fused_max_depth) return kRetryFlattened;
+        const uint32_t n_top = r.n_nodes, n_all = n_top + node_off[nu], n_rec = prim_off[nu];
+        if ((uint64_t)n_all * t.node_stride >= ctx->fused_max_bytes || (uint64_t)std::max(n_rec, 1u) * t.prim_stride >= ctx->fused_max_bytes) return kRetryFlattened;
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_nodes, (size_t)t.node_stride * n_all + 16));       // (+16: the path kernel reads 80 bytes of the last node whatever its stride)
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_node_box, sizeof(float) * 6 * (size_t)n_all));
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_node_ref, sizeof(float) * 2 * (size_t)n_all));
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_prims, (size_t)t.prim_stride * std::max(n_rec, 1u)));
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, stage, (size_t)t.node_stride * n_top, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_node_ref, in.out_node_ref, sizeof(float) * 2 * (size_t)n_top, hipMemcpyDeviceToDevice, s));
+        // (3) the BLAS trees behind the top level
+        std::vector<uint32_t> roots(std::max(n, 1u), 0u);
+        for (uint32_t i = 0; i < n; ++i) roots[i] = n_top + node_off[slot_of[i]];
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_root, roots.data(), sizeof(uint32_t) * roots.size(), hipMemcpyHostToDevice, s));
+        for (uint32_t j = 0; j < nu; ++j) {
+            PackBlasArgs pa{};
+            pa.src_nodes = uniq[j]->d_tmpl_nodes; pa.src_prims = uniq[j]->d_tmpl_prims; pa.n_nodes = node_off[j + 1] - node_off[j]; pa.n_prims = prim_off[j + 1] - prim_off[j];
+            pa.dst_nodes = reinterpret_cast<unsigned char *>(t.d_nodes); pa.dst_prims = reinterpret_cast<unsigned char *>(t.d_prims); pa.node_stride = t.node_stride; pa.prim_stride = t.prim_stride;
+            pa.node_off = n_top + node_off[j]; pa.prim_off = prim_off[j]; pa.slot = j;
+            launch_pack_blas(pa, s);
+        }
+        // their refit, all BLASes at once: phase k = the k-th level from the bottom of every tree (a template is stored breadth first,
+        // children one level below their parents), walked through an order array; per-BLAS tables with the identity transform
+        std::vector<float> pxf(12 * (size_t)nu, 0.0f); std::vector<uint32_t> pid(nu, 1u); std::vector<const void *> psrc(nu, nullptr);
+        std::vector<uint32_t> order; order.reserve(node_off[nu]);
+        std::vector<std::pair<uint32_t, uint32_t>> pack_phases;
+        float obj_coord = 1.0f;
+        for (uint32_t j = 0; j < nu; ++j) {
+            pxf[12 * (size_t)j] = pxf[12 * (size_t)j + 5] = pxf[12 * (size_t)j + 10] = 1.0f; psrc[j] = uniq[j]->d_verts;
+            for (int a = 0; a < 3; ++a) obj_coord = std::max(obj_coord, std::max(std::fabs(uniq[j]->lo[a]), std::fabs(uniq[j]->hi[a])));
+        }
+        for (uint32_t k = 0; k <= blas_depth; ++k) {
+            const uint32_t begin = (uint32_t)order.size();
+            for (uint32_t j = 0; j < nu; ++j) {
+                const std::vector<uint32_t> &lb = uniq[j]->tmpl.level_begin;
+                const uint32_t levels = lb.empty() ? 0u : (uint32_t)lb.size() - 1u;
+                if (k >= levels) continue;
+                const uint32_t l = levels - 1u - k;
+                for (uint32_t x = lb[l]; x < lb[l + 1]; ++x) order.push_back(n_top + node_off[j] + x);
+            }
+            if (order.size() > begin) pack_phases.emplace_back(begin, (uint32_t)order.size() - begin);
+        }
+        if (order.size() != node_off[nu]) return fail(ctx, HRT_ERR_HIP, "two-level tree: a BLAS template's levels do not cover its nodes");
+        unsigned char *tabs = stage + stage_nodes + stage_ref;
+        float *d_pxf = reinterpret_cast<float *>(tabs); uint32_t *d_pid = reinterpret_cast<uint32_t *>(tabs + tab_xf);
+        const void **d_psrc = reinterpret_cast<const void **>(tabs + tab_xf + tab_id); uint32_t *d_porder = reinterpret_cast<uint32_t *>(tabs + tab_xf + tab_id + tab_src);
+        HIP_TRY(ctx, hipMemcpyAsync(d_pxf, pxf.data(), sizeof(float) * pxf.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(d_pid, pid.data(), sizeof(uint32_t) * nu, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync((void *)d_psrc, psrc.data(), sizeof(void *) * nu, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipMemcpyAsync(d_porder, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice, s));
+        // The boxes inside a BLAS are padded for the object-space rays that will come: the slab test's error grows with the distance
+        // of the ray's origin, which in object space is the world's extent seen through the instance's inverse (a rigid pose: the
+        // world's own extent, as for the flattened tree).
+        float reach = 1.0f;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (first2[i + 1] == first2[i]) continue;
+            const float *v = &t.h_inv[12 * (size_t)i];
+            float rown = 0.0f;
+            for (int rr = 0; rr < 3; ++rr) rown = std::max(rown, std::fabs(v[4 * rr]) + std::fabs(v[4 * rr + 1]) + std::fabs(v[4 * rr + 2]));
+            if (std::isfinite(rown)) reach = std::max(reach, rown * scene_scale);
+        }
+        t.built_reach = std::max(reach, obj_coord);
+        RefitArgs rp{};
+        rp.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); rp.node_stride = t.node_stride; rp.prims = reinterpret_cast<unsigned char *>(t.d_prims); rp.prim_stride = t.prim_stride;
+        rp.node_box = t.d_node_box; rp.node_ref = t.d_node_ref; rp.inst_xf = d_pxf; rp.inst_identity = d_pid; rp.inst_src = d_psrc; rp.order = d_porder;
+        rp.pad = 4e-6f * t.built_reach; rp.write_reference = 1u;
+        launch_refit_phases(rp, pack_phases, s);
+        HIP_TRY(ctx, hipGetLastError());
+        // (4) the top level
+        ra.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); ra.prims = reinterpret_cast<unsigned char *>(t.d_prims); ra.node_box = t.d_node_box; ra.node_ref = t.d_node_ref;
+        ra.inst_inv = t.d_inst_inv; ra.inst_root = t.d_inst_root;
+        for (size_t l = r.level_begin.size() - 1; l-- > 0;) t.phases.emplace_back(r.level_begin[l], r.level_begin[l + 1] - r.level_begin[l]);
+        launch_refit_phases(ra, t.phases, s);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        if (std::getenv("HRT_BUILD_VERBOSE"))
+            std::fprintf(stderr, "[hrt] two-level build: %u instances over %u BLASes -> %u top nodes (depth %u, %u split levels), %u BLAS nodes (depth <= %u), %u records (flattened: %u)\n",
+                         n2, nu, n_top, r.max_depth, r.split_levels, node_off[nu], blas_depth, n_rec, first[n]);
+        t.bvh = Bvh8();
+        t.two_level = true; t.n_top_nodes = n_top; t.n_unique_blas = nu;
+        t.n_nodes = n_all; t.n_prims = n_rec; t.max_depth = r.max_depth + 1u + blas_depth;
+        t.n_triangles = t.n_spheres = 0;
+        for (uint32_t j = 0; j < nu; ++j) { t.n_triangles += uniq[j]->tmpl.n_triangles; t.n_spheres += uniq[j]->tmpl.n_spheres; }
+        t.alloc_bytes = (uint64_t)t.node_stride * n_all + sizeof(float) * 8 * (uint64_t)n_all + (uint64_t)t.prim_stride * std::max(n_rec, 1u);
+        for (int a = 0; a < 3; ++a) { t.lo[a] = r.lo[a]; t.hi[a] = r.hi[a]; }
+    } else if (on_device) {
         // ---- the device build (build.hip): topology and primitive ids; the refit below computes everything else ----
         HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_first, sizeof(uint32_t) * first.size()));
         HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_kind, sizeof(uint32_t) * std::max(n, 1u)));
@@ -566,13 +738,18 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
 // (Re)build the tree of a TLAS.  The new tree is built on the side and takes the place of the old one only when
 // everything has succeeded: a failed rebuild (depth limit, out of memory) leaves the registered TLAS as it was --
 // valid and traceable -- instead of half overwritten.
-int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s, bool instanced, bool fast_trace = false) {
+int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s, bool instanced, bool fast_trace = false, int two_level_mode = -1) {
     Tlas fresh;
     // (the pinned host words and the event move to the new tree: hipHostMalloc / hipHostFree are as slow as their device counterparts)
     if (t.area_ready && t.area_pending) (void)hipEventSynchronize(t.area_ready);
     fresh.h_area = t.h_area; fresh.h_update_flags = t.h_update_flags; fresh.area_ready = t.area_ready;
     t.h_area = nullptr; t.h_update_flags = nullptr; t.area_ready = nullptr;
-    const int rc = build_tlas_fresh(ctx, fresh, inst, s, instanced, fast_trace);
+    int rc = build_tlas_fresh(ctx, fresh, inst, s, instanced, fast_trace, two_level_mode);
+    if (rc == kRetryFlattened) {
+        free_tlas_device(ctx, fresh);
+        fresh.two_level = false; fresh.phases.clear();
+        rc = build_tlas_fresh(ctx, fresh, inst, s, instanced, fast_trace, -1);
+    }
     if (rc != HRT_OK) {
         t.h_area = fresh.h_area; t.h_update_flags = fresh.h_update_flags; t.area_ready = fresh.area_ready;
         fresh.h_area = nullptr; fresh.h_update_flags = nullptr; fresh.area_ready = nullptr;
@@ -631,7 +808,8 @@ int refit_tlas(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, h
     ra.pad = 4e-6f * std::max(1.0f, scene_scale);
     ra.area_sum = t.d_area;
     ra.order = t.d_order;
-    attach_rec_box(ctx, t, ra, t.n_prims);
+    if (t.two_level) { ra.inst_inv = t.d_inst_inv; ra.inst_root = t.d_inst_root; }      // (the top level only: transform nodes and the boxes above them)
+    else attach_rec_box(ctx, t, ra, t.n_prims);
     { Timer tm(ctx, s, HRT_K_REFIT); launch_refit_phases(ra, t.phases, s); }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(t.h_area, t.d_area, sizeof(float), hipMemcpyDeviceToHost, s));
@@ -706,7 +884,8 @@ int hrt_tlas_build(HrtContext *ctx, const HrtInstance *d_instances, uint32_t n, 
     std::unique_ptr<Tlas> t(new Tlas());
     std::vector<HrtInstance> inst;
     int rc = download_instances(ctx, d_instances, n, (hipStream_t)stream, inst);
-    if (rc == HRT_OK) rc = build_tlas_into(ctx, *t, inst, (hipStream_t)stream, ctx->tlas_instanced > 0, (ctx->flags & HRT_CTX_FAST_TRACE) != 0);
+    const int two_level_mode = (ctx->flags & HRT_CTX_TWO_LEVEL) != 0 ? 1 : ctx->two_level;
+    if (rc == HRT_OK) rc = build_tlas_into(ctx, *t, inst, (hipStream_t)stream, ctx->tlas_instanced > 0 && two_level_mode <= 0, (ctx->flags & HRT_CTX_FAST_TRACE) != 0, two_level_mode);
     if (rc != HRT_OK) { free_tlas_device(ctx, *t); free_tlas_host(*t); return rc; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const uint64_t h = ctx->next_handle++;
@@ -750,7 +929,8 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
             ra.prims = reinterpret_cast<unsigned char *>(t->d_prims); ra.prim_stride = t->prim_stride;
             ra.node_box = t->d_node_box; ra.node_ref = t->d_node_ref; ra.inst_xf = t->d_inst_xf; ra.inst_identity = t->d_inst_identity; ra.inst_src = t->d_inst_src;
             ra.scale_bits = t->d_update_flags; ra.area_sum = t->d_area; ra.order = t->d_order;
-            attach_rec_box(ctx, *t, ra, t->n_prims);
+            if (t->two_level) { ra.inst_inv = t->d_inst_inv; ra.inst_root = t->d_inst_root; }
+            else attach_rec_box(ctx, *t, ra, t->n_prims);
             { Timer tm(ctx, s, HRT_K_REFIT); launch_refit_phases(ra, t->phases, s); }
             HIP_TRY(ctx, hipGetLastError());
             HIP_TRY(ctx, hipMemcpyAsync(t->h_area, t->d_area, sizeof(float), hipMemcpyDeviceToHost, s));
@@ -807,6 +987,7 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
     // reference's 25-particle layout: 0.21 ms against 0.71 ms for the merged build).
     uint64_t total = 0;
     for (uint32_t i = 0; i < n; ++i) total += t->blas_refs[i] ? t->blas_refs[i]->n_prims : 0u;
+    if (t->two_level) return build_tlas_into(ctx, *t, inst, s, false, false, 1);      // a two-level tree stays one: its top level is rebuilt, the BLAS trees are copied in again
     const bool over_instances = ctx->tlas_instanced >= 0 && n >= 2 && (!ctx->build_on_device || total < 100000ull || ctx->tlas_instanced > 0);
     return build_tlas_into(ctx, *t, inst, s, over_instances);
 }

@@ -150,6 +150,8 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_PATHS_MIN_BATCH")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->paths_min_batch = v; }
     if (const char *e = std::getenv("HRT_PATHS_SHADE")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->paths_shade_threshold = v; }
     if (const char *e = std::getenv("HRT_TLAS_INSTANCED")) ctx->tlas_instanced = std::atoi(e);
+    if (const char *e = std::getenv("HRT_TWO_LEVEL")) ctx->two_level = std::atoi(e);
+    if (const char *e = std::getenv("HRT_TWO_LEVEL_MIN_PRIMS")) { const unsigned long long v = std::strtoull(e, nullptr, 0); if (v >= 1) ctx->two_level_min_prims = v; }
     if (const char *e = std::getenv("HRT_BUILD")) ctx->build_on_device = std::strcmp(e, "host") != 0;
     if (const char *e = std::getenv("HRT_QUANT_GUARD")) { const double q = std::atof(e); if (q >= 0.0) ctx->quant_guard = (float)q; }
     if (const char *e = std::getenv("HRT_BUILD_TOPDOWN")) ctx->build_topdown = std::atoi(e) != 0;
@@ -352,6 +354,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
 
     // ---- fused path mode: ONE launch, every lane owns a pixel and runs all its samples (generate,
     //      traverse, shade, accumulate in place).  No stage barriers.  The default (HRT_FUSED=1). ----
+    if (t->two_level && (count || ctx->fused != 1)) return fail(ctx, HRT_ERR_STATE, "a two-level TLAS is traced by the default path kernel only (not under HRT_CTX_COUNT / HRT_FUSED != 1)");
     const bool use_fused = !count && (ctx->fused > 0 || (ctx->fused < 0 && n <= (uint32_t)ctx->fused_max_pixels));
     if (use_fused) {
         StageCounters *stg = w.set[0].stages;
@@ -377,6 +380,8 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         // registers around the shading: 2560), 20 = 5 per SIMD for round 1's kernel (96 VGPRs, a few spills: 2905).
         const bool v1 = ctx->fused != 3;            // 3: the slot pipeline k_paths (paths.hip); otherwise a fused kernel: k_fused (fused.hip), 2: round 1's (kernels.hip)
         // k_fused keeps one sibling group per tree level in LDS and has no overflow path: deeper trees take round 1's kernel
+        if (t->two_level && (!v1 || ctx->fused == 2 || !fits_fused_kernel(ctx, *t)))
+            return fail(ctx, HRT_ERR_STATE, "a two-level TLAS needs the default path kernel (HRT_FUSED=1)");
         const bool lean = v1 && ctx->fused != 2 && fits_fused_kernel(ctx, *t);
         if (lean) ta.postpone_pct = ctx->fused_postpone_pct;
         else if (v1 && ctx->fused != 2) ctx->fused_fallback_launches++;        // the tree does not fit k_fused
@@ -398,8 +403,10 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
             }
             pa.slots = w.slots;
         }
+        if (t->two_level) ta.tail_split = 0;        // (the pieces of a split ray would have to carry the instance they are in)
         auto launch = [&]() {
-            if (lean) launch_fused(ta, t->has_spheres, grid, s);
+            if (lean && t->two_level) launch_fused_instanced(ta, t->has_spheres, grid, s);
+            else if (lean) launch_fused(ta, t->has_spheres, grid, s);
             else if (v1) launch_paths_v1(ta, t->has_spheres, grid, s);
             else launch_paths(ta, t->has_spheres, ctx->paths_slots, grid, s);
         };
@@ -732,6 +739,7 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
     ta.fetch_counter = fetch; ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
     ta.tmin = tmin; ta.tmax = tmax; ta.postpone_pct = ctx->postpone_pct; ta.leaf_quorum = ctx->leaf_quorum; ta.tail_regen = ctx->fused_tail_regen;
     const bool count = (ctx->flags & HRT_CTX_COUNT) != 0;
+    if (t->two_level && (count || ctx->fused != 1 || !fits_fused_kernel(ctx, *t))) return fail(ctx, HRT_ERR_STATE, "a two-level TLAS is traced by the default path kernel only");
     if (!count && ctx->fused > 0) {
         // the production configuration: the rays go through the very kernel hrt_render_launch runs (fused path kernel, v_rcp_f32
         // slab test, regeneration thresholds), each ray standing in for a pixel that is traced once and not shaded
@@ -746,7 +754,8 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
         const uint32_t blocks_per_cu = lean ? std::min<uint32_t>((uint32_t)ctx->fused_blocks_per_cu, (uint32_t)kFusedBlocksPerCu) : (uint32_t)ctx->fused_blocks_per_cu;
         const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * blocks_per_cu, (n_rays + 63u) / 64u);
         Timer tm(ctx, s, HRT_K_PATHS);
-        if (lean) launch_fused(ta, t->has_spheres, grid, s); else launch_paths_v1(ta, t->has_spheres, grid, s);
+        if (t->two_level) { ta.tail_split = 0; launch_fused_instanced(ta, t->has_spheres, grid, s); }
+        else if (lean) launch_fused(ta, t->has_spheres, grid, s); else launch_paths_v1(ta, t->has_spheres, grid, s);
     } else {
         ta.seg[0].rays = rays; ta.seg[0].n_ptr = nullptr; ta.seg[0].n = n_rays; ta.seg[0].any_hit = any_hit ? 1u : 0u;
         ta.seg[0].hit_tuvp = tuvp; ta.seg[0].hit_inst = inst;

@@ -39,7 +39,9 @@ struct Blas {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};   // object-space bounds
     // object-space BVH8 of this geometry alone: the per-instance subtree of the trees over instances (built on first use)
     std::mutex tmpl_mu; bool tmpl_built = false; Bvh8 tmpl;
-    ~Blas() { if (d_verts) (void)hipFree(d_verts); }
+    // ... and its device copy (topology, packed 80 / 48 byte records): what a two-level TLAS copies in behind its top level
+    unsigned char *d_tmpl_nodes = nullptr, *d_tmpl_prims = nullptr;
+    ~Blas() { if (d_verts) (void)hipFree(d_verts); if (d_tmpl_nodes) (void)hipFree(d_tmpl_nodes); if (d_tmpl_prims) (void)hipFree(d_tmpl_prims); }
 };
 
 struct Tlas {
@@ -69,6 +71,12 @@ struct Tlas {
     uint32_t *h_update_flags = nullptr;                  // pinned: [0..1] copy of the above after the last update, [2..3] their initial values
     std::vector<std::pair<uint32_t, uint32_t>> phases;   // (first, count) in processing order, children before parents
     bool instanced = false;
+    // TWO-LEVEL tree (bvh8.h: transform nodes; the reference's IAS over shared GASes): nodes [0, n_top_nodes) are the top level -- box nodes and
+    // one transform node per visible instance, what an update refits --, behind them one object-space tree per UNIQUE BLAS; d_prims holds those
+    // trees' records only.  Memory and update cost: instances + unique primitives.
+    bool two_level = false; uint32_t n_top_nodes = 0, n_unique_blas = 0;
+    uint32_t *d_inst_root = nullptr;                     // per instance: node index of its BLAS's root
+    float built_reach = 1.0f;                            // the largest object-space |coordinate| a ray origin was assumed to have when the BLAS trees were padded
     bool has_split_refs = false;                         // built with spatial splits (HRT_CTX_FAST_TRACE): a refit would recompute the leaf boxes from whole primitives, so the first update rebuilds instead
     const void **d_inst_src = nullptr;
     float *h_area = nullptr;                             // pinned: area sum of the last refit
@@ -176,6 +184,10 @@ struct HrtContext {
     int lds_gather = 0;                         // 1: cooperative LDS-DMA gathers, 0: per-lane register loads
     int fetch_chunk = 64;
     int substream_min_pixels = 32768;
+    int two_level = 0;                          // hrt_tlas_build: 1 = two-level trees (transform nodes over shared BLASes) whenever the path kernel can take them,
+                                                // -1 = never, 0 = when flattening would leave the caches: more than two_level_min_prims flattened primitives,
+                                                // at least two_level_min_share times the unique ones (HRT_TWO_LEVEL, HRT_CTX_TWO_LEVEL)
+    uint64_t two_level_min_prims = 4000000ull; float two_level_min_share = 4.0f;
     int tlas_instanced = 0;                     // 1: hrt_tlas_build makes trees over instances too, 0: only rebuilds during updates do, -1: never
     int build_on_device = 1;                    // 1: PLOC build on the GPU (build.hip), 0: binned-SAH build on the host (HRT_BUILD=host; needs a host copy of the geometry)
     float quant_guard = 1.25f;                  // device builds (HRT_QUANT_GUARD; 0: off): see build.hip emit_item

@@ -74,7 +74,19 @@ __device__ __forceinline__ void refit_slot(const RefitArgs &a, uint32_t node, ui
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     uint32_t meta = 0;
     const float pad = a.scale_bits ? 4e-6f * fmaxf(1.0f, __uint_as_float(a.scale_bits[0])) : a.pad;
-    if (live) {
+    // A transform node of a two-level tree (bvh8.h: word 3 == 0): its box is the instance's BLAS box under the instance's transform --
+    // lane k of the group transforms corner k, the butterfly below joins them -- and lane 0 writes what the traversal reads there:
+    // the BLAS's root, the identity flag, world -> object.  Cost per instance: this, whatever the BLAS holds.
+    const bool xform = live && ndw[3] == 0u;
+    if (xform) {
+        const uint32_t inst = ndw[5];
+        const float *b6 = reinterpret_cast<const float *>(a.inst_src[inst]);
+        const float q[3] = {(slot & 1u) ? b6[3] : b6[0], (slot & 2u) ? b6[4] : b6[1], (slot & 4u) ? b6[5] : b6[2]};
+        float w[3];
+        if (a.inst_identity[inst] != 0u) { w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; } else xf_point(a.inst_xf + 12 * (size_t)inst, q, w);
+        const bool ok = b6[0] <= b6[3];
+        for (int k = 0; k < 3; ++k) { lo[k] = ok ? w[k] : INFINITY; hi[k] = ok ? w[k] : -INFINITY; }
+    } else if (live) {
         const uint32_t imask = ndw[3] >> 24, child_base = ndw[4], prim_base = ndw[5];
         meta = nd[24 + slot];
         if (meta != 0u) {
@@ -106,6 +118,26 @@ __device__ __forceinline__ void refit_slot(const RefitArgs &a, uint32_t node, ui
         nlo[k] = l; nhi[k] = h;
     }
     if (!live) return;
+    if (xform) {
+        if (slot != 0u) return;
+        const uint32_t inst = ndw[5];
+        const bool ok = finite_box(nlo, nhi) && nlo[0] <= nhi[0];
+        float *b = a.node_box + 6 * (size_t)node;
+        for (int k = 0; k < 3; ++k) { b[k] = ok ? nlo[k] - pad : INFINITY; b[3 + k] = ok ? nhi[k] + pad : -INFINITY; }
+        uint32_t *w32 = reinterpret_cast<uint32_t *>(nd);
+        w32[4] = a.inst_root[inst]; w32[6] = a.inst_identity[inst] != 0u ? 1u : 0u;
+        const float *inv = a.inst_inv + 12 * (size_t)inst;
+        float *pf = reinterpret_cast<float *>(nd);
+        for (int k = 0; k < 12; ++k) pf[8 + k] = inv[k];
+        if (ok) {
+            float2 *ref = reinterpret_cast<float2 *>(a.node_ref) + node;
+            const float plo[3] = {nlo[0] - pad, nlo[1] - pad, nlo[2] - pad}, phi[3] = {nhi[0] + pad, nhi[1] + pad, nhi[2] + pad};
+            const float area = box_half_area(plo, phi);
+            if (a.write_reference) ref->y = (area > 0.0f && area < 3.0e38f) ? 1.0f / area : 0.0f;
+            else if (a.area_sum) { const float2 r = *ref; const float g = area * r.y; if (r.x > 0.0f && g < 3.0e38f) atomicAdd(a.area_sum, r.x * g); }
+        }
+        return;
+    }
     const bool empty_node = !(nlo[0] <= nhi[0]);
     if (empty_node) for (int k = 0; k < 3; ++k) { nlo[k] = 0.0f; nhi[k] = 0.0f; }
     uint8_t e[3];
@@ -215,6 +247,29 @@ __global__ __launch_bounds__(256) void k_instance_tables(InstanceTableArgs a) {
 }
 void launch_instance_tables(const InstanceTableArgs &a, hipStream_t s) {
     if (a.n) hipLaunchKernelGGL(k_instance_tables, dim3((a.n + 255u) / 256u), dim3(256), 0, s, a);
+}
+
+// ---- two-level trees: a BLAS's object-space tree (topology: the template, built once per BLAS) goes into the TLAS's arrays behind the
+// top level -- its node and record numbers move by where it lands, its records name its slot in the table of BLASes the pack's refit
+// reads (geometry source, identity transform); everything else is the refit's to compute, as after any build. ----
+__global__ __launch_bounds__(256) void k_pack_blas(PackBlasArgs a) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < a.n_nodes) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.src_nodes + 80u * (size_t)i);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(a.dst_nodes + (size_t)(a.node_off + i) * a.node_stride);
+        for (int q = 0; q < 20; ++q) dst[q] = src[q];
+        dst[4] = src[4] + a.node_off; dst[5] = src[5] + a.prim_off;
+    }
+    if (i < a.n_prims) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(a.src_prims + 48u * (size_t)i);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(a.dst_prims + (size_t)(a.prim_off + i) * a.prim_stride);
+        for (int q = 0; q < 12; ++q) dst[q] = src[q];
+        dst[7] = a.slot;
+    }
+}
+void launch_pack_blas(const PackBlasArgs &a, hipStream_t s) {
+    const uint32_t n = a.n_nodes > a.n_prims ? a.n_nodes : a.n_prims;
+    if (n) hipLaunchKernelGGL(k_pack_blas, dim3((n + 255u) / 256u), dim3(256), 0, s, a);
 }
 
 void launch_refit_level(const RefitArgs &a, hipStream_t s) {

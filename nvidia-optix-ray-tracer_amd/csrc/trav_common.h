@@ -228,17 +228,19 @@ __device__ __forceinline__ float safe_rcp_dir(float d) {
 }
 
 // canonical primitive test (DESIGN.md "canonical intersector"); updates the best hit.
-template <bool HAS_SPHERES>
+// INSTANCED (two-level trees, fused.hip): the record is a shared BLAS's, in object space, and so is the ray in `s` by now (the transform
+// node did that for triangles and spheres alike); the record does not know who instances it: `inst_cur` does.
+template <bool HAS_SPHERES, bool INSTANCED = false>
 __device__ __forceinline__ bool test_prim(const float4 A, const float4 B, const float4 C, TravState &s,
                                           float tmin, float tmax_ray,
-                                          const float *__restrict__ inst_inv, const uint32_t *__restrict__ inst_identity) {
+                                          const float *__restrict__ inst_inv, const uint32_t *__restrict__ inst_identity, uint32_t inst_cur = 0u) {
     float t, u = 0.0f, v = 0.0f;
     uint32_t prim = __float_as_uint(A.w), inst;
     const V3 o = mk3(s.ox, s.oy, s.oz), d = mk3(s.dx, s.dy, s.dz);
     if (HAS_SPHERES && __float_as_uint(C.w) == 1u) {
-        inst = __float_as_uint(B.w);
+        inst = INSTANCED ? inst_cur : __float_as_uint(B.w);
         V3 oo = o, dd = d;
-        if (!inst_identity[inst]) {
+        if (!INSTANCED && !inst_identity[inst]) {
             const float *m = inst_inv + 12 * (size_t)inst;
             oo = mk3(((m[0] * o.x + m[1] * o.y) + m[2] * o.z) + m[3], ((m[4] * o.x + m[5] * o.y) + m[6] * o.z) + m[7],
                      ((m[8] * o.x + m[9] * o.y) + m[10] * o.z) + m[11]);
@@ -267,7 +269,7 @@ __device__ __forceinline__ bool test_prim(const float4 A, const float4 B, const 
         // (profiles/r02_valu_issue_patterns_microbench.txt).  Same decisions, same values: a rejected lane's later
         // quantities are never used, det == 0 gives inv = inf and u = NaN or +-inf, which fails the u test like the
         // explicit one does.
-        inst = __float_as_uint(B.w);
+        inst = INSTANCED ? inst_cur : __float_as_uint(B.w);
         const V3 e1 = mk3(B.x, B.y, B.z), e2 = mk3(C.x, C.y, C.z);
         const V3 pvec = cross3(d, e2);
         const float det = dot3(e1, pvec);

@@ -310,4 +310,40 @@ def particle_scene(n_particles=25, width=96, height=64, spp=1, frame=0, subdiv=2
             "width": width, "height": height, "spp": spp}
 
 
+def particle_cloud(n_particles=2000, width=96, height=64, spp=1, subdiv=2, seed=9, spacing=0.2):
+    """A DEM-sized scene of the reference's kind: ``n_particles`` instances of three shared shapes on a jittered cubic grid (``spacing``
+    apart, randomly rotated) over the ground sphere -- what ``particle_scene`` is to the shipped 25-particle sample, this is to a run
+    with 10^3 .. 10^5 particles.  Flattened it has ~57 triangles per particle at subdiv 2 (~217 at subdiv 3); as an IAS over three GASes it has the three shapes."""
+    shapes = [_blob_shape(subdiv, 0.06, seed), _blob_shape(max(subdiv - 1, 0), 0.05, seed + 1),
+              np.asarray(_box((-0.04, -0.04, -0.04), (0.04, 0.04, 0.04), skip_bottom=False), dtype=np.float32)]
+    normals = [face_normals(v) for v in shapes]
+    side = int(np.ceil(n_particles ** (1.0 / 3.0)))
+    i = np.arange(n_particles)
+    gx, gy, gz = i % side, (i // side) % side, i // (side * side)
+    jit = uniform_f32(seed * 53 + 1, 3 * n_particles, -0.25, 0.25).reshape(n_particles, 3) * np.float32(spacing)
+    half = 0.5 * spacing * (side - 1)
+    pos = np.stack([gx * spacing - half, gy * spacing - half, gz * spacing + 0.1], axis=1).astype(np.float64) + jit
+    ax = uniform_f32(seed * 53 + 2, 3 * n_particles, -1.0, 1.0).reshape(n_particles, 3).astype(np.float64) + 1e-3
+    ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    ang = uniform_f32(seed * 53 + 3, n_particles, 0.0, 6.28).astype(np.float64)
+    c, s_ = np.cos(ang), np.sin(ang)
+    x, y, z = ax[:, 0], ax[:, 1], ax[:, 2]
+    rot = np.stack([c + x * x * (1 - c), x * y * (1 - c) - z * s_, x * z * (1 - c) + y * s_, pos[:, 0],
+                    y * x * (1 - c) + z * s_, c + y * y * (1 - c), y * z * (1 - c) - x * s_, pos[:, 1],
+                    z * x * (1 - c) - y * s_, z * y * (1 - c) + x * s_, c + z * z * (1 - c), pos[:, 2]], axis=1).astype(np.float32)
+    albedos = [RED, WHITE, GREEN, SAND]
+    ground = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, -1000.5], dtype=np.float32)
+    inst = [_sphere_instance([[0, 0, 0]], [1000.0], SAND, "rough", 0.0, ground)]
+    for k in range(n_particles):
+        sid = k % len(shapes)
+        metal = k % 4 == 3
+        inst.append({"geometry": "triangles", "vertices": shapes[sid], "normals": normals[sid], "albedo": STEEL if metal else albedos[k % 4],
+                     "material": "metal" if metal else "rough", "fuzz": 0.1 if metal else 0.0, "transform": rot[k], "shape": sid})
+    ext = spacing * side
+    cam = {"center": np.array([1.6 * ext + 1.0, 0.35 * ext, 0.9 * ext + 0.4], dtype=np.float32), "target": np.array([0, 0, 0.45 * ext], dtype=np.float32),
+           "up": np.array([0, 0, 1], dtype=np.float32), "opengl": False}
+    return {"name": "cloud-%d" % n_particles, "instances": inst, "camera": cam, "background": BACKGROUND.copy(),
+            "width": width, "height": height, "spp": spp}
+
+
 BASELINE_CONFIGS = {"C1": cornell_box, "C2": sphere_in_box, "C3": soup_100k, "C4": soup_1m, "C5": soup_1m_8mat}

@@ -307,6 +307,7 @@ typedef struct {
     uint32_t *refs; float *plo, *phi;   /* per-ref padded AABB */
     bnode *nodes; uint32_t n_nodes;
     int brute;
+    int object_space;               /* 1: the INSTANCED canonical mode (below): triangles of transformed instances stay in object space */
 } oracle_scene;
 
 /* point / vector transform with a fixed operation order (shared definition with the product) */
@@ -388,7 +389,11 @@ static inline void test_ref(const oracle_scene *sc, uint32_t ref, f3 o, f3 d, fl
     float t, u = 0.0f, v = 0.0f;
     if (ref < sc->n_tri) {
         const wtri *tr = &sc->tri[ref];
-        if (isect_tri(tr, o, d, tmin, tmax, &t, &u, &v)) consider(best, t, u, v, tr->prim, tr->inst);
+        f3 oo = o, dd = d;
+        /* INSTANCED mode: the ray goes into the instance's object space (what OptiX does at an IAS leaf, src/Global/RendererImpl.cu:174-206),
+         * the ray parameter t is common to both spaces */
+        if (sc->object_space && !sc->identity[tr->inst]) { oo = xf_point(sc->inv[tr->inst], o); dd = xf_vector(sc->inv[tr->inst], d); }
+        if (isect_tri(tr, oo, dd, tmin, tmax, &t, &u, &v)) consider(best, t, u, v, tr->prim, tr->inst);
     } else {
         const wsph *s = &sc->sph[ref - sc->n_tri];
         f3 oo = o, dd = d;
@@ -500,9 +505,18 @@ static void build_rec(oracle_scene *sc, uint32_t node, uint32_t lo, uint32_t hi)
     build_rec(sc, l + 1, mid, hi);
 }
 
-oracle_scene *oracle_scene_create(const oracle_instance *inst, int n_inst, int force_brute) {
+/*
+ * Two canonical modes, one per shape of the product's acceleration structure -- both are "the reference's IAS over GASes" with the
+ * closed OptiX intersector replaced by the canonical one; they differ in WHERE the triangle test is evaluated, hence in rounding:
+ *   object_space = 0 (FLATTENED): triangle vertices are transformed to world space once (xf_point), the world ray meets world triangles;
+ *   object_space = 1 (INSTANCED): the ray is transformed into the instance's object space (inverse by cofactors in double, rounded once:
+ *     exactly what both modes already do for spheres) and meets the object-space triangle (v0, v1 - v0, v2 - v0).  Instances with an
+ *     identity transform are the same in both modes.  t, u, v of a hit, and ties between instances, are compared as computed.
+ */
+oracle_scene *oracle_scene_create_mode(const oracle_instance *inst, int n_inst, int force_brute, int object_space) {
     oracle_scene *sc = (oracle_scene *)calloc(1, sizeof *sc);
     sc->n_inst = n_inst;
+    sc->object_space = object_space != 0;
     sc->inst = (oracle_instance *)malloc(sizeof(oracle_instance) * (size_t)n_inst);
     memcpy(sc->inst, inst, sizeof(oracle_instance) * (size_t)n_inst);
     sc->inv = malloc(sizeof(float[12]) * (size_t)n_inst);
@@ -530,7 +544,12 @@ oracle_scene *oracle_scene_create(const oracle_instance *inst, int n_inst, int f
                     if (!sc->identity[i]) v[k] = xf_point(in->transform, v[k]);   /* world-space flattening */
                 }
                 wtri *t = &sc->tri[ti];
-                t->v0 = v[0]; t->e1 = sub3(v[1], v[0]); t->e2 = sub3(v[2], v[0]); t->prim = p; t->inst = (uint32_t)i;
+                if (sc->object_space) {      /* the record stays in object space; the bounds below are the world-space triangle's */
+                    f3 ov[3];
+                    for (int k = 0; k < 3; ++k) ov[k] = mk3(in->vertices[9 * p + 3 * k], in->vertices[9 * p + 3 * k + 1], in->vertices[9 * p + 3 * k + 2]);
+                    t->v0 = ov[0]; t->e1 = sub3(ov[1], ov[0]); t->e2 = sub3(ov[2], ov[0]);
+                } else { t->v0 = v[0]; t->e1 = sub3(v[1], v[0]); t->e2 = sub3(v[2], v[0]); }
+                t->prim = p; t->inst = (uint32_t)i;
                 float *lo = &sc->plo[3 * ti], *hi = &sc->phi[3 * ti];
                 lo[0] = fminf(v[0].x, fminf(v[1].x, v[2].x)); hi[0] = fmaxf(v[0].x, fmaxf(v[1].x, v[2].x));
                 lo[1] = fminf(v[0].y, fminf(v[1].y, v[2].y)); hi[1] = fmaxf(v[0].y, fmaxf(v[1].y, v[2].y));
@@ -569,6 +588,9 @@ oracle_scene *oracle_scene_create(const oracle_instance *inst, int n_inst, int f
         build_rec(sc, 0, 0, sc->n_prim);
     }
     return sc;
+}
+oracle_scene *oracle_scene_create(const oracle_instance *inst, int n_inst, int force_brute) {
+    return oracle_scene_create_mode(inst, n_inst, force_brute, 0);
 }
 void oracle_scene_destroy(oracle_scene *sc) {
     if (!sc) return;
@@ -795,11 +817,14 @@ void oracle_bvh8_trace(const void *nodes_blob, const void *prims_blob,
     uint64_t tot_nodes = 0, tot_prims = 0, tot_empty = 0;
     #pragma omp parallel for schedule(dynamic, 256) reduction(+:tot_nodes, tot_prims, tot_empty)
     for (long ri = 0; ri < (long)n_rays; ++ri) {
-        const f3 o = mk3(origins[3 * ri], origins[3 * ri + 1], origins[3 * ri + 2]);
-        const f3 d = mk3(dirs[3 * ri], dirs[3 * ri + 1], dirs[3 * ri + 2]);
-        const float idx = safe_rcp_dir(d.x), idy = safe_rcp_dir(d.y), idz = safe_rcp_dir(d.z);
-        const uint32_t oct = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u);
-        const uint32_t oct_inv = 7u - oct;
+        const f3 ow = mk3(origins[3 * ri], origins[3 * ri + 1], origins[3 * ri + 2]);
+        const f3 dw = mk3(dirs[3 * ri], dirs[3 * ri + 1], dirs[3 * ri + 2]);
+        /* the ray in the space being walked: world, or -- below a transform node of a two-level tree -- the instance's object space */
+        f3 o = ow, d = dw;
+        float idx = safe_rcp_dir(d.x), idy = safe_rcp_dir(d.y), idz = safe_rcp_dir(d.z);
+        uint32_t oct = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u);
+        uint32_t oct_inv = 7u - oct;
+        uint32_t cur_inst = 0xffffffffu;         /* the instance whose BLAS is being walked (two-level trees) */
         hit_rec best; best.hit = 0; best.t = tmax; best.u = best.v = 0.0f; best.prim = best.inst = 0xffffffffu;
         uint32_t stack_x[64], stack_y[64]; int sp = 0;
         uint32_t cur_x = 0, cur_y = 0x80000000u;
@@ -816,8 +841,20 @@ void oracle_bvh8_trace(const void *nodes_blob, const void *prims_blob,
                 const uint32_t rel = (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot_index));
                 const uint32_t *nd = nodes + 20 * (size_t)(cur_x + rel);
                 ++tot_nodes; ++my_nodes;
-                float p[3]; memcpy(p, nd, 12);
                 const uint32_t e_imask = nd[3];
+                if (e_imask == 0u) {
+                    /* a transform node (two-level trees, csrc/bvh8.h): word 4 = root of the instance's BLAS, word 5 = instance,
+                     * word 6 = identity flag, words 8..19 = world -> object.  The ray goes into object space; a marker on the stack
+                     * brings the world ray back when the BLAS has been walked. */
+                    stack_x[sp] = 0xffffffffu; stack_y[sp] = 0u; ++sp;
+                    cur_inst = nd[5];
+                    if (!nd[6]) { const float *m = (const float *)(nd + 8); o = xf_point(m, ow); d = xf_vector(m, dw); }
+                    idx = safe_rcp_dir(d.x); idy = safe_rcp_dir(d.y); idz = safe_rcp_dir(d.z);
+                    oct = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u); oct_inv = 7u - oct;
+                    cur_x = nd[4]; cur_y = 0x01000000u;          /* one child: the root (no inner-mask bits: index = base) */
+                    continue;
+                }
+                float p[3]; memcpy(p, nd, 12);
                 uint32_t eb; float sx, sy, sz;
                 eb = (e_imask & 0xffu) << 23; memcpy(&sx, &eb, 4);
                 eb = ((e_imask >> 8) & 0xffu) << 23; memcpy(&sy, &eb, 4);
@@ -851,20 +888,27 @@ void oracle_bvh8_trace(const void *nodes_blob, const void *prims_blob,
                 tri_y &= tri_y - 1u;
                 ++tot_prims;
                 const prim48 *pr = &prims[tri_x + k];
+                const uint32_t pinst = cur_inst != 0xffffffffu ? cur_inst : pr->inst;      /* a shared BLAS does not know who instances it */
                 float t, u = 0.0f, v = 0.0f; int h = 0;
                 if (pr->kind == 1u) {
                     wsph s; s.c = mk3(pr->a[0], pr->a[1], pr->a[2]); s.r = pr->b[0];
                     f3 oo = o, dd = d;
-                    if (inst_identity && !inst_identity[pr->inst]) { oo = xf_point(inst_inv + 12 * (size_t)pr->inst, o); dd = xf_vector(inst_inv + 12 * (size_t)pr->inst, d); }
+                    if (cur_inst == 0xffffffffu && inst_identity && !inst_identity[pr->inst]) { oo = xf_point(inst_inv + 12 * (size_t)pr->inst, o); dd = xf_vector(inst_inv + 12 * (size_t)pr->inst, d); }
                     h = isect_sph(&s, oo, dd, tmin, tmax, &t);
                 } else {
                     wtri tr; tr.v0 = mk3(pr->a[0], pr->a[1], pr->a[2]); tr.e1 = mk3(pr->b[0], pr->b[1], pr->b[2]); tr.e2 = mk3(pr->c[0], pr->c[1], pr->c[2]);
                     h = isect_tri(&tr, o, d, tmin, tmax, &t, &u, &v);
                 }
-                if (h) { consider(&best, t, u, v, pr->prim, pr->inst); if (any_hit) { done = 1; break; } }
+                if (h) { consider(&best, t, u, v, pr->prim, pinst); if (any_hit) { done = 1; break; } }
             }
-            if (!done && cur_y <= 0x00ffffffu) {
-                if (sp > 0) { --sp; cur_x = stack_x[sp]; cur_y = stack_y[sp]; } else done = 1;
+            while (!done && cur_y <= 0x00ffffffu) {
+                if (sp == 0) { done = 1; break; }
+                --sp; cur_x = stack_x[sp]; cur_y = stack_y[sp];
+                if (cur_x == 0xffffffffu && cur_y == 0u) {       /* the marker: back to world space */
+                    o = ow; d = dw; cur_inst = 0xffffffffu;
+                    idx = safe_rcp_dir(d.x); idy = safe_rcp_dir(d.y); idz = safe_rcp_dir(d.z);
+                    oct = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u); oct_inv = 7u - oct;
+                }
             }
         }
         t_out[ri] = best.hit ? best.t : tmax; u_out[ri] = best.u; v_out[ri] = best.v;

@@ -33,6 +33,8 @@ def lib():
     L = C.CDLL(os.environ.get("HRT_ORACLE_LIB") or str(LIB))      # HRT_ORACLE_LIB: the sanitizer build (make asan-test)
     L.oracle_scene_create.restype = C.c_void_p
     L.oracle_scene_create.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.oracle_scene_create_mode.restype = C.c_void_p
+    L.oracle_scene_create_mode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.oracle_scene_destroy.argtypes = [C.c_void_p]
     L.oracle_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
                                 C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -78,9 +80,11 @@ def _p(a):
 
 
 class OracleScene:
-    """Oracle-side scene built from the same dict the product's Renderer.load_scene takes."""
+    """Oracle-side scene built from the same dict the product's Renderer.load_scene takes.
+    instanced=True: the INSTANCED canonical mode (oracle.c: rays go into the instance's object space, as at an IAS leaf) -- what a
+    two-level TLAS of the product is pinned to; the default is the FLATTENED mode (triangles transformed to world space)."""
 
-    def __init__(self, scene, force_brute=False):
+    def __init__(self, scene, force_brute=False, instanced=False):
         L = lib()
         insts = scene["instances"]
         self._keep = []
@@ -110,7 +114,7 @@ class OracleScene:
                 arr[i].radii = r.ctypes.data
         self._arr = arr
         self.scene = scene
-        self.handle = C.c_void_p(L.oracle_scene_create(arr, len(insts), int(force_brute)))
+        self.handle = C.c_void_p(L.oracle_scene_create_mode(arr, len(insts), int(force_brute), int(instanced)))
 
     def camera12(self):
         L = lib()
