@@ -114,6 +114,8 @@ uint32_t gpu_build_max_refs(uint32_t n_prims, const SplitParams *split);        
 SplitPhaseResult gpu_split_phase(const GpuBuildArgs &a, uint32_t n_valid, const SplitParams &sp, BuildArena &arena, hipStream_t s);
 constexpr size_t kBoundsScratchBytes = 512;           // ... of gpu_blas_bounds
 hipError_t gpu_blas_bounds(const float *d_src, uint32_t n_prims, uint32_t kind, float *lo, float *hi, void *d_scratch, hipStream_t s);
+// bounding sphere of a BLAS around `center` (radius < 0: none)
+hipError_t gpu_blas_radius(const float *d_src, uint32_t n_prims, uint32_t kind, const float *center, float *radius, void *d_scratch, hipStream_t s);
 void launch_pack_spheres(const float *centers, const float *radii, uint32_t n, float *out, hipStream_t s);
 
 }  // namespace hrt

@@ -654,6 +654,30 @@ __global__ __launch_bounds__(1024) void k_blas_bounds(const float *src, uint32_t
         for (int d = 0; d < 3; ++d) { atomicMin(&c->bmin[d], f2ord(lo[d])); atomicMax(&c->bmax[d], f2ord(hi[d])); }
 }
 
+// radius of the bounding sphere of one BLAS around a given centre (two-level trees: bvh8_geom.h clamp_to_sphere_bounds): the largest
+// distance of a vertex (a sphere: its far side) from it; non-negative floats order like their bits
+__global__ __launch_bounds__(1024) void k_blas_radius(const float *src, uint32_t n_prims, uint32_t kind, float cx, float cy, float cz, BuildCounters *c) {
+    const uint32_t p = blockIdx.x * 1024u + threadIdx.x;
+    float lo[1] = {0.0f}, far[1] = {0.0f};
+    if (p < n_prims) {
+        if (kind == kPrimKindTriangle) {
+            for (int v = 0; v < 3; ++v) {
+                const float *q = src + 9 * (size_t)p + 3 * v;
+                const float dx = q[0] - cx, dy = q[1] - cy, dz = q[2] - cz;
+                const float d = sqrtf((dx * dx + dy * dy) + dz * dz);
+                if (d <= 3.0e38f) far[0] = fmaxf(far[0], d);
+            }
+        } else {
+            const float *q = src + 4 * (size_t)p;
+            const float dx = q[0] - cx, dy = q[1] - cy, dz = q[2] - cz;
+            const float d = sqrtf((dx * dx + dy * dy) + dz * dz) + fabsf(q[3]);
+            if (d <= 3.0e38f) far[0] = d;
+        }
+    }
+    block_minmax<1>(lo, far);
+    if (threadIdx.x == 0u) atomicMax(&c->cmax[0], __float_as_uint(far[0]));
+}
+
 // spheres are kept as {cx, cy, cz, r}: interleave the caller's two arrays
 __global__ __launch_bounds__(256) void k_pack_spheres(const float *centers, const float *radii, uint32_t n, float *out) {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
@@ -688,6 +712,26 @@ hipError_t gpu_blas_bounds(const float *d_src, uint32_t n_prims, uint32_t kind, 
     if (e != hipSuccess) return e;
     if (h.bmin[0] <= h.bmax[0] && h.bmax[0] != 0u)
         for (int d = 0; d < 3; ++d) { lo[d] = ord2f(h.bmin[d]); hi[d] = ord2f(h.bmax[d]); }
+    return hipSuccess;
+}
+
+hipError_t gpu_blas_radius(const float *d_src, uint32_t n_prims, uint32_t kind, const float *center, float *radius, void *d_scratch, hipStream_t s) {
+    *radius = -1.0f;
+    if (n_prims == 0) return hipSuccess;
+    BuildCounters *c = reinterpret_cast<BuildCounters *>(d_scratch);
+    hipError_t e = c ? hipSuccess : hipMalloc((void **)&c, sizeof(BuildCounters));
+    if (e != hipSuccess) return e;
+    BuildCounters h{};
+    e = hipMemcpyAsync(c, &h, sizeof h, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_blas_radius, dim3(blocks(n_prims, 1024)), dim3(1024), 0, s, d_src, n_prims, kind, center[0], center[1], center[2], c); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, c, sizeof h, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (!d_scratch) (void)hipFree(c);
+    if (e != hipSuccess) return e;
+    float r; memcpy(&r, &h.cmax[0], 4);
+    // (the distances are rounded: a few ULPs of slack, and of the centre's coordinates)
+    const float cmax = std::max(std::fabs(center[0]), std::max(std::fabs(center[1]), std::fabs(center[2])));
+    if (r <= 3.0e38f) *radius = r * 1.000002f + 4e-7f * cmax;
     return hipSuccess;
 }
 
@@ -776,7 +820,7 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
         hipLaunchKernelGGL(k_leaves, dim3(blocks(n, 256)), dim3(256), 0, s, a, kNone);
         hipLaunchKernelGGL(k_ploc_small, dim3(1), dim3(1024), 0, s, a, a.cl_a, cl_b, 1u);
         hipLaunchKernelGGL(k_emit_small, dim3(1), dim3(1024), 0, s, a, items_a, items_b);
-        hipLaunchKernelGGL(k_normalise_weights, dim3(blocks(n, 256)), dim3(256), 0, s, in.out_node_ref, kNone, a.counters);
+        hipLaunchKernelGGL(k_normalise_weights, dim3(blocks(in.instance_leaves ? 2u * n + 2u : n, 256)), dim3(256), 0, s, in.out_node_ref, kNone, a.counters);      // (a node per thread: at most n of them, with transform nodes 2 n + 1)
         B_TRY(hipGetLastError());
         B_TRY(hipMemcpyAsync(&h, a.counters, sizeof h, hipMemcpyDeviceToHost, s));
         B_TRY(hipStreamSynchronize(s));

@@ -34,11 +34,11 @@ __device__ __forceinline__ bool prim_bounds(const GpuBuildArgs &a, uint32_t k, f
         for (int q = 0; q < 9; ++q) s9[q] = src[q];
         triangle_world(s9, m, ident, v0, e1, e2, lo, hi);
     } else if (a.inst_kind[inst] == kPrimKindInstance) {
-        const float *src = reinterpret_cast<const float *>(a.inst_src[inst]);      // the BLAS's object-space box
-        float b6[6];
-        for (int q = 0; q < 6; ++q) b6[q] = src[q];
-        if (!(b6[0] <= b6[3])) return false;                                       // an empty BLAS
-        box_world_bounds(b6, m, ident, lo, hi);
+        const float *src = reinterpret_cast<const float *>(a.inst_src[inst]);      // the BLAS's object-space box and bounding sphere
+        float b10[10];
+        for (int q = 0; q < 10; ++q) b10[q] = src[q];
+        if (!(b10[0] <= b10[3])) return false;                                     // an empty BLAS
+        instance_world_bounds(b10, m, ident, lo, hi);
     } else {
         const float *src = reinterpret_cast<const float *>(a.inst_src[inst]) + 4 * (size_t)p;
         const float c3[3] = {src[0], src[1], src[2]};

@@ -65,6 +65,27 @@ HRT_HD void box_world_bounds(const float *b6, const float *m, bool identity, flo
     }
 }
 
+// The bounding sphere of a BLAS (centre c, radius r >= 0 around all its geometry) under an affine map is an ellipsoid whose extent along
+// world axis k is r x |row k of the linear part|: its box, intersected with the transformed corners' box, bounds the instance.  For the
+// compact bodies a DEM run instances that is the tight one of the two: a cube turned by 45 degrees about two axes has a corners' box
+// 1.7 times its size, its sphere's box 1.0.  (The box is padded like every other by whoever stores it.)
+HRT_HD void clamp_to_sphere_bounds(const float *c3, float r, const float *m, bool identity, float *lo, float *hi) {
+    if (!(r >= 0.0f) || !(r <= 3.0e38f)) return;
+    float w[3];
+    if (identity) { w[0] = c3[0]; w[1] = c3[1]; w[2] = c3[2]; } else xf_point(m, c3, w);
+    for (int k = 0; k < 3; ++k) {
+        const float n = identity ? 1.0f : sqrtf((m[4 * k] * m[4 * k] + m[4 * k + 1] * m[4 * k + 1]) + m[4 * k + 2] * m[4 * k + 2]);
+        const float e = (r * n) * 1.000002f;
+        const float slo = w[k] - e, shi = w[k] + e;
+        if (slo <= shi) { lo[k] = fmaxf(lo[k], slo); hi[k] = fminf(hi[k], shi); }      // (NaN: the corners' box stands)
+    }
+}
+// an instance of a two-level tree: b10 = its BLAS's object-space box (lo, hi), bounding sphere centre and radius (negative: none)
+HRT_HD void instance_world_bounds(const float *b10, const float *m, bool identity, float *lo, float *hi) {
+    box_world_bounds(b10, m, identity, lo, hi);
+    clamp_to_sphere_bounds(b10 + 6, b10[9], m, identity, lo, hi);
+}
+
 HRT_HD float box_half_area(const float *lo, const float *hi) {
     const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
     return ex * ey + ey * ez + ez * ex;

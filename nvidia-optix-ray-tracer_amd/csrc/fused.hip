@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
     Xorwow px_rng{};
     uint32_t px_rays_closest = 0u, px_rays_any = 0u;
 #ifdef HRT_LANE_STATS
-    unsigned long long ls_iter = 0, ls_alive = 0, ls_node = 0, ls_prim = 0, ls_ppass = 0, ls_regen = 0;
+    unsigned long long ls_iter = 0, ls_alive = 0, ls_node = 0, ls_prim = 0, ls_ppass = 0, ls_regen = 0, ls_enter = 0;
 #endif
 
     // the wave's slice of the tile: [wbeg, wend); slices of fetch_chunk pixels are handed out by kFetchShards counters
@@ -328,6 +328,9 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
                     enter = L.nidx != kNoWork && !hit_any && rn0.w == 0u;          // a transform node: word 3 == 0
                     if (L.nidx != kNoWork && !hit_any && !enter) lean_node(L.s, tmin, rn0, rn1, rn2, rn3, rn4, child, tri);
                     if (__ballot(enter) != 0ull) {
+    #ifdef HRT_LANE_STATS
+                        ls_enter += __popcll(__ballot(enter));
+    #endif
                         if (enter) {
                             TravState &s = L.s;
                             s_mb_t[tx] = s.ox; s_mb_u[tx] = s.oy; s_mb_v[tx] = s.oz;
@@ -356,7 +359,17 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
                 // an any-hit ray is done with its first accepted intersection: nothing more to fetch (what is left on its stacks is
                 // dropped when the lane's next ray starts, lean_start)
                 if (hit_any) { L.nidx = kNoWork; L.pidx = kNoWork; done = true; }
-                if (alive && !done) done = lean_bookkeeping_asm(L, child, tri, ldsn, ldsl, (uint32_t)a.postpone_pct, (uint32_t)a.leaf_quorum) != 0u;
+                [[maybe_unused]] uint32_t lane = 0u;
+                if constexpr (!INSTANCED) {
+                    if (alive && !done) done = lean_bookkeeping_asm(L, child, tri, ldsn, ldsl, (uint32_t)a.postpone_pct, (uint32_t)a.leaf_quorum) != 0u;
+                } else {
+                    // (this instantiation is two registers over its budget and the compiler's choice of what to keep in scratch is the two
+                    // stack addresses, reloaded here in every iteration: they are a constant plus eight times the lane number -- two
+                    // instructions to make again)
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+                    const uint32_t ldsn_i = (uint32_t)reinterpret_cast<uintptr_t>(&s_nodes[0][0]) + 8u * lane, ldsl_i = (uint32_t)reinterpret_cast<uintptr_t>(&s_leaves[0][0]) + 8u * lane;
+                    if (alive && !done) done = lean_bookkeeping_asm(L, child, tri, ldsn_i, ldsl_i, (uint32_t)a.postpone_pct, (uint32_t)a.leaf_quorum) != 0u;
+                }
                 if constexpr (INSTANCED) {
                     // in: the frame starts above what the lane holds (siblings still in hand have just been pushed, step 2 of the sequence)
                     if (enter) { I.frame = (uint32_t)L.base | ((uint32_t)L.nsp << 8); L.base = L.nsp; }
@@ -372,7 +385,7 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
                             s.oct_inv4 = (7u - oct) * 0x01010101u;
                             I.inst_cur = kNoWork;
                             L.base = (int)(I.frame & 0xffu); L.nsp = (int)(I.frame >> 8);
-                            if (L.nsp != L.base) { --L.nsp; s.cur = s_nodes[L.nsp][tx]; }      // (only groups with hits are ever pushed)
+                            if (L.nsp != L.base) { --L.nsp; s.cur = s_nodes[L.nsp][lane]; }      // (only groups with hits are ever pushed)
                             if (s.cur.y > 0x00ffffffu) { lean_pick_node(L); done = false; }
                         }
                     }
@@ -403,7 +416,7 @@ __global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fu
 #ifdef HRT_LANE_STATS
     if (tx == 0u) {
         unsigned long long *d = reinterpret_cast<unsigned long long *>(a.path.rays_closest);
-        atomicAdd(d + 6, ls_iter); atomicAdd(d + 7, ls_alive); atomicAdd(d + 8, ls_node); atomicAdd(d + 9, ls_prim); atomicAdd(d + 2, ls_ppass); atomicAdd(d + 3, ls_regen);
+        atomicAdd(d + 6, ls_iter); atomicAdd(d + 7, ls_alive); atomicAdd(d + 8, ls_node); atomicAdd(d + 9, ls_prim); atomicAdd(d + 2, ls_ppass); atomicAdd(d + 3, ls_regen); atomicAdd(d + 4, ls_enter);
     }
 #endif
     for (int off = 32; off > 0; off >>= 1) {

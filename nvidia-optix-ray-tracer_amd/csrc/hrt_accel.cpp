@@ -136,7 +136,7 @@ void free_tlas_device(HrtContext *ctx, Tlas &t) {
     pool_release(ctx, (void *)t.d_inst_src);
     pool_release(ctx, (void *)t.d_inst_first);
     pool_release(ctx, (void *)t.d_inst_kind);
-    pool_release(ctx, (void *)t.d_inst_root);
+    pool_release(ctx, (void *)t.d_inst_root); pool_release(ctx, (void *)t.d_blas_bound); t.d_blas_bound = nullptr;
     t.d_inst_first = t.d_inst_kind = t.d_inst_root = nullptr;
     pool_release(ctx, (void *)t.d_sig_handle);
     pool_release(ctx, (void *)t.d_sig_visibility);
@@ -438,9 +438,30 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
     const size_t pb = (size_t)t.prim_stride * std::max<size_t>(n_prims, 1);
     std::vector<const void *> src(std::max(n, 1u), nullptr);
     for (uint32_t i = 0; i < n; ++i) src[i] = t.blas_refs[i]->d_verts;
-    if (two_level) {      // the top level's "geometry" is the instances' BLAS boxes
-        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_blas_box, sizeof(float) * 6 * (size_t)std::max(n, 1u)));
-        for (uint32_t i = 0; i < n; ++i) src[i] = t.d_blas_box + 6 * (size_t)i;
+    if (two_level) {      // the top level's "geometry": the instances' BLAS boxes and bounding spheres
+        std::vector<float> bound(10 * (size_t)std::max(n, 1u), 0.0f);
+        for (uint32_t i = 0; i < n; ++i) {
+            Blas &b = *t.blas_refs[i];
+            float *q = &bound[10 * (size_t)i];
+            for (int a = 0; a < 3; ++a) { q[a] = b.lo[a]; q[3 + a] = b.hi[a]; }
+            q[9] = -1.0f;
+            if (b.n_prims != 0u && b.lo[0] <= b.hi[0]) {
+                std::lock_guard<std::mutex> lk(b.tmpl_mu);
+                if (!b.bsphere_ready) {
+                    for (int a = 0; a < 3; ++a) b.bsphere[a] = 0.5f * b.lo[a] + 0.5f * b.hi[a];
+                    const ScratchArena arena = scratch_acquire(ctx, kBoundsScratchBytes);
+                    const hipError_t e = gpu_blas_radius(b.d_verts, b.n_prims, b.kind, b.bsphere, &b.bsphere[3], arena.p, s);
+                    scratch_release(ctx, arena);
+                    HIP_TRY(ctx, e);
+                    b.bsphere_ready = true;
+                }
+                for (int a = 0; a < 4; ++a) q[6 + a] = b.bsphere[a];
+            }
+        }
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_blas_bound, sizeof(float) * bound.size()));
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_blas_bound, bound.data(), sizeof(float) * bound.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        for (uint32_t i = 0; i < n; ++i) src[i] = t.d_blas_bound + 10 * (size_t)i;
     }
     if (!on_device) HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_nodes, nb));
     if (!(on_device && (device_split || two_level))) HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_prims, pb));      // (a split build knows its record count afterwards; a two-level tree holds the unique primitives' records only)
@@ -468,7 +489,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_sig_handle, sizeof(unsigned long long) * sigh.size()));
         HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_sig_visibility, sizeof(uint32_t) * std::max(n, 1u)));
         HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_sig_sbt, sizeof(uint32_t) * std::max(n, 1u)));
-        if (!t.d_blas_box) HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_blas_box, sizeof(float) * bbox.size()));
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_blas_box, sizeof(float) * bbox.size()));
         HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_update_flags, sizeof(uint32_t) * 2));
         if (!t.h_update_flags) HIP_TRY(ctx, hipHostMalloc((void **)&t.h_update_flags, sizeof(uint32_t) * 4, hipHostMallocDefault));
         t.h_update_flags[0] = t.h_update_flags[2] = 0x3f800000u; t.h_update_flags[1] = t.h_update_flags[3] = 0u;

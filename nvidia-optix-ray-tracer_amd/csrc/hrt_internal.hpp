@@ -41,6 +41,7 @@ struct Blas {
     std::mutex tmpl_mu; bool tmpl_built = false; Bvh8 tmpl;
     // ... and its device copy (topology, packed 80 / 48 byte records): what a two-level TLAS copies in behind its top level
     unsigned char *d_tmpl_nodes = nullptr, *d_tmpl_prims = nullptr;
+    float bsphere[4] = {0, 0, 0, -1.0f}; bool bsphere_ready = false;      // bounding sphere (centre of the box, largest vertex distance): the instances' tight bound
     ~Blas() { if (d_verts) (void)hipFree(d_verts); if (d_tmpl_nodes) (void)hipFree(d_tmpl_nodes); if (d_tmpl_prims) (void)hipFree(d_tmpl_prims); }
 };
 
@@ -76,6 +77,7 @@ struct Tlas {
     // trees' records only.  Memory and update cost: instances + unique primitives.
     bool two_level = false; uint32_t n_top_nodes = 0, n_unique_blas = 0;
     uint32_t *d_inst_root = nullptr;                     // per instance: node index of its BLAS's root
+    float *d_blas_bound = nullptr;                       // per instance, 10 floats: its BLAS's object-space box and bounding sphere (the top level's "geometry")
     float built_reach = 1.0f;                            // the largest object-space |coordinate| a ray origin was assumed to have when the BLAS trees were padded
     bool has_split_refs = false;                         // built with spatial splits (HRT_CTX_FAST_TRACE): a refit would recompute the leaf boxes from whole primitives, so the first update rebuilds instead
     const void **d_inst_src = nullptr;

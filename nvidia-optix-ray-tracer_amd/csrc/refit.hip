@@ -75,7 +75,7 @@ __device__ __forceinline__ void refit_slot(const RefitArgs &a, uint32_t node, ui
     uint32_t meta = 0;
     const float pad = a.scale_bits ? 4e-6f * fmaxf(1.0f, __uint_as_float(a.scale_bits[0])) : a.pad;
     // A transform node of a two-level tree (bvh8.h: word 3 == 0): its box is the instance's BLAS box under the instance's transform --
-    // lane k of the group transforms corner k, the butterfly below joins them -- and lane 0 writes what the traversal reads there:
+    // lane k of the group transforms corner k, the butterfly below joins them, lane 0 cuts the result down to the bounding sphere's box -- and writes what the traversal reads there:
     // the BLAS's root, the identity flag, world -> object.  Cost per instance: this, whatever the BLAS holds.
     const bool xform = live && ndw[3] == 0u;
     if (xform) {
@@ -121,6 +121,10 @@ __device__ __forceinline__ void refit_slot(const RefitArgs &a, uint32_t node, ui
     if (xform) {
         if (slot != 0u) return;
         const uint32_t inst = ndw[5];
+        {   // ... within the box of the BLAS's bounding sphere (bvh8_geom.h instance_world_bounds)
+            const float *b10 = reinterpret_cast<const float *>(a.inst_src[inst]);
+            clamp_to_sphere_bounds(b10 + 6, b10[9], a.inst_xf + 12 * (size_t)inst, a.inst_identity[inst] != 0u, nlo, nhi);
+        }
         const bool ok = finite_box(nlo, nhi) && nlo[0] <= nhi[0];
         float *b = a.node_box + 6 * (size_t)node;
         for (int k = 0; k < 3; ++k) { b[k] = ok ? nlo[k] - pad : INFINITY; b[3 + k] = ok ? nhi[k] + pad : -INFINITY; }
