@@ -144,6 +144,7 @@ struct FinalizeArgs {
     const float4 *accum; const uint32_t *rows;
     uint32_t n_tile_pixels, width, spp;
     float4 *color, *albedo, *normal, *linear;
+    uint32_t *reset_counters; uint32_t n_reset;      // when set: n_reset words (< the launch's threads) zeroed on the way
 };
 
 // one level of the bottom-up refit (refit.hip)
@@ -193,6 +194,10 @@ struct InstanceTableArgs {
     uint32_t *flags;               // [0]: scene scale (float bits, starts at 1.0f); [1]: bit 0 set when a handle or visibility bit differs (-> rebuild), bit 1 when an sbtOffset does (-> synchronous update)
 };
 void launch_instance_tables(const InstanceTableArgs &a, hipStream_t s);
+// the end of an asynchronous update, one launch instead of two copies to the host, one from it and a fill: the refit's area sum and the
+// tables kernel's verdict go to pinned host memory, the device words are set up for the next update
+struct UpdateEpilogueArgs { float *d_area; uint32_t *d_flags; float *h_area; uint32_t *h_flags; uint32_t flags_init0, flags_init1; };
+void launch_update_epilogue(const UpdateEpilogueArgs &a, hipStream_t s);
 void launch_refit_top(const RefitArgs &a, const RefitLevels &lv, hipStream_t s);
 
 // particle pose update (pose.hip)

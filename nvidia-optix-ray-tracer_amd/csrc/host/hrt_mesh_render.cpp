@@ -210,8 +210,9 @@ int main(int argc, char **argv) {
             hrtCheckError(ctx, hrt_pose_instances(ctx, fd.dev_instances, (uint32_t)addGeoCount, (uint32_t)fd.particleCount, fd.dev_states, fd.dev_states, &pose, nullptr));
             updateIAS(ctx, fd.ias, fd.dev_instances, fd.instanceCount);
             const HrtGlobalParams params{std::get<0>(fd.ias), dev_stateArray};
-            launch(ctx, params, raygen, 1);
+            hrtCheckError(ctx, hrt_render_launch(ctx, &params, &raygen, 1, nullptr, nullptr));      // (launch, conversion, then the frame's one synchronisation)
             hrtCheckError(ctx, hrt_to_rgba8(ctx, color, rgba, W, H, nullptr));
+            hrtCheckError(ctx, hrt_sync(ctx, nullptr));
         }
     }
     hipCheck(hipDeviceSynchronize());

@@ -146,10 +146,25 @@ int main(int argc, char **argv) {
     }
     long frames = 0;
     hrtCheckError(ctx, hrt_stats_reset(ctx));
+    // HRT_TIME_RENDER_BREAKDOWN=1: where a frame's time goes -- every step bracketed by device synchronisations (so the frames are slower
+    // than in a normal run, where the steps are only enqueued), summed separately for the first frame of a file (materials, the update
+    // that turns the identity-built IAS into the posed scene) and the others
+    const bool breakdown = std::getenv("HRT_TIME_RENDER_BREAKDOWN") != nullptr;
+    enum { kMaterials, kPose, kUpdate, kLaunch, kRgba, kSteps };
+    const char *stepName[kSteps] = {"hrt_materials_set", "hrt_pose_instances", "hrt_tlas_update", "hrt_render_launch", "hrt_to_rgba8 + sync"};
+    double stepMs[2][kSteps] = {{0}}; long stepFrames[2] = {0, 0};
+    auto timed = [&](int first, int step, auto &&fn) {
+        if (!breakdown) { fn(); return; }
+        hipCheck(hipDeviceSynchronize());
+        const auto a = std::chrono::steady_clock::now();
+        fn();
+        hipCheck(hipDeviceSynchronize());
+        stepMs[first][step] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
     const auto t0 = std::chrono::steady_clock::now();
     for (uint64_t f = 0; f < series.n && (maxFrames < 0 || frames < maxFrames); ++f) {
         FileData &fd = perFile[f];
-        hrtCheckError(ctx, hrt_materials_set(ctx, fd.records.data(), (uint32_t)fd.records.size()));
+        timed(1, kMaterials, [&] { hrtCheckError(ctx, hrt_materials_set(ctx, fd.records.data(), (uint32_t)fd.records.size())); });
         const uint64_t next = f + 1 < series.n ? f + 1 : f;                                   // :443-447
         const size_t frameCountThisFile = (size_t)(series.durations[f] * (float)(cfg.fps * cfg.render_speed_ratio));   // :427-428
         HrtPoseParams pose{};
@@ -157,12 +172,16 @@ int main(int argc, char **argv) {
         std::memcpy(&pose.particle_offset, cfg.particle_shift, 12); std::memcpy(&pose.particle_scale, cfg.particle_scale, 12);
         for (size_t frame = 0; frame < frameCountThisFile && (maxFrames < 0 || frames < maxFrames); ++frame, ++frames) {
             pose.frame = (uint32_t)frame;
-            hrtCheckError(ctx, hrt_pose_instances(ctx, fd.dev_instances, (uint32_t)addGeoCount, (uint32_t)files[f].n, fd.dev_states,
-                                                  perFile[next].dev_states, &pose, nullptr));
-            updateIAS(ctx, fd.ias, fd.dev_instances, fd.instanceCount);
+            const int first = frame == 0 ? 1 : 0;
+            ++stepFrames[first];
+            timed(first, kPose, [&] { hrtCheckError(ctx, hrt_pose_instances(ctx, fd.dev_instances, (uint32_t)addGeoCount, (uint32_t)files[f].n, fd.dev_states,
+                                                                            perFile[next].dev_states, &pose, nullptr)); });
+            timed(first, kUpdate, [&] { updateIAS(ctx, fd.ias, fd.dev_instances, fd.instanceCount); });
             const HrtGlobalParams params{std::get<0>(fd.ias), dev_stateArray};
-            launch(ctx, params, raygen, 1);
-            hrtCheckError(ctx, hrt_to_rgba8(ctx, color, rgba, W, H, nullptr));
+            // (launch, conversion, then the frame's one synchronisation -- the reference synchronises between the two, RendererTime.cu:497-515,
+            // because its denoiser runs on the host's schedule; nothing here needs the frame before the bytes exist)
+            timed(first, kLaunch, [&] { hrtCheckError(ctx, hrt_render_launch(ctx, &params, &raygen, 1, nullptr, nullptr)); });
+            timed(first, kRgba, [&] { hrtCheckError(ctx, hrt_to_rgba8(ctx, color, rgba, W, H, nullptr)); hrtCheckError(ctx, hrt_sync(ctx, nullptr)); });
         }
     }
     hipCheck(hipDeviceSynchronize());
@@ -173,6 +192,12 @@ int main(int argc, char **argv) {
         if (st.kernel_launches[k] && st.kernel_ms[k] > 0.0) std::printf("  kernel class %d: %.3f ms in %llu launches\n", k, st.kernel_ms[k], (unsigned long long)st.kernel_launches[k]);
     std::printf("%ld frames %ux%u: %.3f ms/frame (%.0f frames/s), %.1f Mrays/s, refits %llu rebuilds %llu\n", frames, W, H, ms / std::max(1l, frames),
                 frames / ms * 1e3, st.rays / ms * 1e-3, (unsigned long long)st.tlas_refits, (unsigned long long)st.tlas_rebuilds);
+
+    if (breakdown)
+        for (int first = 1; first >= 0; --first) {
+            std::printf("  %s (%ld): ", first ? "first frame of a file" : "other frames", stepFrames[first]);
+            for (int k = 0; k < kSteps; ++k) std::printf("%s %.3f ms%s", stepName[k], stepMs[first][k] / std::max(1l, stepFrames[first]), k + 1 < kSteps ? ", " : "\n");
+        }
 
     std::vector<HrtUchar4> host((size_t)W * H);
     hipCheck(hipMemcpy(host.data(), rgba, host.size() * sizeof(HrtUchar4), hipMemcpyDeviceToHost));

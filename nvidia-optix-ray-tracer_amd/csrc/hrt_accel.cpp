@@ -822,6 +822,7 @@ int refit_tlas(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, h
     HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_xf, t.h_xf.data(), sizeof(float) * t.h_xf.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_identity, t.h_ident.data(), sizeof(uint32_t) * t.h_ident.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(ctx, hipMemsetAsync(t.d_area, 0, sizeof(float), s));
+    t.async_words_ready = false;
     RefitArgs ra{};
     ra.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); ra.node_stride = t.node_stride;
     ra.prims = reinterpret_cast<unsigned char *>(t.d_prims); ra.prim_stride = t.prim_stride;
@@ -841,6 +842,38 @@ int refit_tlas(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, h
 }
 
 }  // namespace hrt
+
+// A rebuild in the middle of an animation.  Large scenes: the merged device build (3.1 ms for 2000 particles / 435 k triangles, 3.3 ms
+// for a million triangles: profiles/r03_device_split_build.txt) -- the better tree.  Small scenes and host-build contexts: the tree over
+// instances, whose top tree the host assembles in well under a millisecond.
+static bool rebuild_over_instances(const HrtContext *ctx, const Tlas &t) {
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < t.n_instances; ++i) total += t.blas_refs[i] ? t.blas_refs[i]->n_prims : 0u;
+    return ctx->tlas_instanced >= 0 && t.n_instances >= 2 && (!ctx->build_on_device || total < 100000ull || ctx->tlas_instanced > 0);
+}
+
+// The first update after a build, before anything is refitted: have the instances gone somewhere else altogether?  The reference
+// builds every file's IAS with identity transforms and poses it afterwards (RendererTime.cu:111-127): the tree was built over particles
+// lying on top of each other, a refit of it is a tree in name only, and the refit, the wait for its verdict and the rebuild that follows
+// are the rebuild alone when this says so.  Moved far = an instance's box centre is further from where it was than the box is wide.
+static bool instances_moved_far(const Tlas &t, const std::vector<HrtInstance> &inst) {
+    uint32_t valid = 0, far = 0;
+    for (uint32_t i = 0; i < t.n_instances; ++i) {
+        const Blas *b = t.blas_refs[i].get();
+        if (!b || (inst[i].visibilityMask & 1u) == 0 || !(b->lo[0] <= b->hi[0])) continue;
+        const float c[3] = {0.5f * (b->lo[0] + b->hi[0]), 0.5f * (b->lo[1] + b->hi[1]), 0.5f * (b->lo[2] + b->hi[2])};
+        const float e[3] = {b->hi[0] - b->lo[0], b->hi[1] - b->lo[1], b->hi[2] - b->lo[2]};
+        float was[3], now[3], ext[3];
+        xf_point(&t.h_xf[12 * (size_t)i], c, was); xf_point(inst[i].transform, c, now);
+        const float *m = &t.h_xf[12 * (size_t)i];
+        for (int k = 0; k < 3; ++k) ext[k] = std::fabs(m[4 * k]) * e[0] + std::fabs(m[4 * k + 1]) * e[1] + std::fabs(m[4 * k + 2]) * e[2];
+        const float d2 = (now[0] - was[0]) * (now[0] - was[0]) + (now[1] - was[1]) * (now[1] - was[1]) + (now[2] - was[2]) * (now[2] - was[2]);
+        const float w2 = ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2];
+        ++valid;
+        if (d2 > w2) ++far;
+    }
+    return valid >= 4 && 2 * far > valid;
+}
 
 extern "C" {
 
@@ -908,6 +941,15 @@ int hrt_tlas_build(HrtContext *ctx, const HrtInstance *d_instances, uint32_t n, 
     const int two_level_mode = (ctx->flags & HRT_CTX_TWO_LEVEL) != 0 ? 1 : ctx->two_level;
     if (rc == HRT_OK) rc = build_tlas_into(ctx, *t, inst, (hipStream_t)stream, ctx->tlas_instanced > 0 && two_level_mode <= 0, (ctx->flags & HRT_CTX_FAST_TRACE) != 0, two_level_mode);
     if (rc != HRT_OK) { free_tlas_device(ctx, *t); free_tlas_host(*t); return rc; }
+    // A rebuild in the middle of an animation builds a tree over instances when the scene is small (hrt_tlas_update): the per-BLAS
+    // template trees that needs are built now, while the scene is being loaded, not inside the first frame that rebuilds (the
+    // reference's shipped sample: 9 templates, 8.7 ms of its first frame)
+    if (!t->two_level && rebuild_over_instances(ctx, *t))
+        for (uint32_t i = 0; i < n && rc == HRT_OK; ++i) {
+            Blas &b = *t->blas_refs[i];
+            if ((inst[i].visibilityMask & 1u) != 0 && b.lo[0] <= b.hi[0]) rc = ensure_template(ctx, b, (hipStream_t)stream);
+        }
+    if (rc != HRT_OK) { free_tlas_device(ctx, *t); free_tlas_host(*t); return rc; }
     std::lock_guard<std::mutex> lk(ctx->mu);
     const uint64_t h = ctx->next_handle++;
     ctx->tlas[h] = std::move(t);
@@ -928,7 +970,7 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
     if (n && !d_instances) return fail(ctx, HRT_ERR_INVALID, "d_instances is NULL");
     bool force_rebuild = false, sbt_sync = false;
     // (the first update after a build takes the synchronous path below, which checks that refit on the spot: see there)
-    if ((ctx->flags & HRT_CTX_ASYNC_UPDATE) != 0 && ctx->refit != 0 && t->n_prims != 0u && n != 0u && t->refits_since_build != 0) {
+    if ((ctx->flags & HRT_CTX_ASYNC_UPDATE) != 0 && ctx->refit != 0 && t->n_prims != 0u && n != 0u && (t->refits_since_build != 0 || t->built_posed)) {
         // ---- asynchronous update: nothing is read back now.  First the verdict of the previous one (long complete). ----
         if (t->area_pending) {
             HIP_TRY(ctx, hipEventSynchronize(t->area_ready));
@@ -939,12 +981,17 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
             t->h_update_flags[1] = 0u;
         }
         if (!force_rebuild && !sbt_sync) {
-            HIP_TRY(ctx, hipMemcpyAsync(t->d_update_flags, t->h_update_flags + 2, sizeof(uint32_t) * 2, hipMemcpyHostToDevice, s));
+            // (the device words the tables kernel and the refit accumulate into -- scene scale, verdict bits, area sum -- are left in their
+            // initial state by the previous asynchronous update's epilogue; after a build or a synchronous update they are set here)
+            if (!t->async_words_ready) {
+                HIP_TRY(ctx, hipMemcpyAsync(t->d_update_flags, t->h_update_flags + 2, sizeof(uint32_t) * 2, hipMemcpyHostToDevice, s));
+                HIP_TRY(ctx, hipMemsetAsync(t->d_area, 0, sizeof(float), s));
+                t->async_words_ready = true;
+            }
             InstanceTableArgs ia{};
             ia.instances = d_instances; ia.n = n; ia.sig_handle = t->d_sig_handle; ia.sig_visibility = t->d_sig_visibility; ia.sig_sbt = t->d_sig_sbt; ia.blas_box = t->d_blas_box;
             ia.inst_xf = t->d_inst_xf; ia.inst_inv = t->d_inst_inv; ia.inst_identity = t->d_inst_identity; ia.flags = t->d_update_flags;
             launch_instance_tables(ia, s);
-            HIP_TRY(ctx, hipMemsetAsync(t->d_area, 0, sizeof(float), s));
             RefitArgs ra{};
             ra.nodes = reinterpret_cast<unsigned char *>(t->d_nodes); ra.node_stride = t->node_stride;
             ra.prims = reinterpret_cast<unsigned char *>(t->d_prims); ra.prim_stride = t->prim_stride;
@@ -953,9 +1000,10 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
             if (t->two_level) { ra.inst_inv = t->d_inst_inv; ra.inst_root = t->d_inst_root; }
             else attach_rec_box(ctx, *t, ra, t->n_prims);
             { Timer tm(ctx, s, HRT_K_REFIT); launch_refit_phases(ra, t->phases, s); }
+            // one launch where there were two copies to the host, one from it and a fill: results to pinned memory, device words reset
+            UpdateEpilogueArgs ue{t->d_area, t->d_update_flags, t->h_area, t->h_update_flags, t->h_update_flags[2], t->h_update_flags[3]};
+            launch_update_epilogue(ue, s);
             HIP_TRY(ctx, hipGetLastError());
-            HIP_TRY(ctx, hipMemcpyAsync(t->h_area, t->d_area, sizeof(float), hipMemcpyDeviceToHost, s));
-            HIP_TRY(ctx, hipMemcpyAsync(t->h_update_flags, t->d_update_flags, sizeof(uint32_t) * 2, hipMemcpyDeviceToHost, s));
             HIP_TRY(ctx, hipEventRecord(t->area_ready, s));
             t->area_pending = true;
             t->refits++; t->refits_since_build++; ctx->tlas_refits++;
@@ -970,6 +1018,8 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
     bool same = ctx->refit != 0 && t->n_prims != 0u && !force_rebuild && !t->has_split_refs;
     for (uint32_t i = 0; i < n && same; ++i)
         same = inst[i].traversableHandle == t->sig_handle[i] && (inst[i].visibilityMask & 1u) == t->sig_visibility[i];
+    bool moved_far = false;
+    if (same && t->refits_since_build == 0 && ctx->refit_moved_far_check && instances_moved_far(*t, inst)) { same = false; moved_far = true; }
     if (same && t->area_pending) {
         HIP_TRY(ctx, hipEventSynchronize(t->area_ready));
         t->area_pending = false;
@@ -999,18 +1049,13 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
     }
     if (std::getenv("HRT_BUILD_VERBOSE"))
         std::fprintf(stderr, "[hrt] update %llu of this tree rebuilds: %s (area ratio %.3f, %llu refits since the build)\n", (unsigned long long)(t->refits + t->rebuilds),
-                     force_rebuild ? "verdict of the previous asynchronous refit" : "handles / visibility changed or the refit just done degraded the tree", ctx->tlas_refit_ratio.load(),
+                     force_rebuild ? "verdict of the previous asynchronous refit" : moved_far ? "most instances are further from where the tree was built than they are wide" : "handles / visibility changed or the refit just done degraded the tree", ctx->tlas_refit_ratio.load(),
                      (unsigned long long)t->refits_since_build);
     HIP_TRY(ctx, hipDeviceSynchronize());                 // launches on other streams may still read the old tree
-    // A rebuild in the middle of an animation.  Large scenes: the merged device build (3.1 ms for 2000 particles / 435 k
-    // triangles, 3.3 ms for a million triangles: profiles/r03_device_split_build.txt) -- the better tree.  Small scenes and
-    // host-build contexts: the tree over instances, whose top tree the host assembles in well under a millisecond (the
-    // reference's 25-particle layout: 0.21 ms against 0.71 ms for the merged build).
-    uint64_t total = 0;
-    for (uint32_t i = 0; i < n; ++i) total += t->blas_refs[i] ? t->blas_refs[i]->n_prims : 0u;
-    if (t->two_level) return build_tlas_into(ctx, *t, inst, s, false, false, 1);      // a two-level tree stays one: its top level is rebuilt, the BLAS trees are copied in again
-    const bool over_instances = ctx->tlas_instanced >= 0 && n >= 2 && (!ctx->build_on_device || total < 100000ull || ctx->tlas_instanced > 0);
-    return build_tlas_into(ctx, *t, inst, s, over_instances);
+    // a two-level tree stays one: its top level is rebuilt, the BLAS trees are copied in again
+    const int rb = t->two_level ? build_tlas_into(ctx, *t, inst, s, false, false, 1) : build_tlas_into(ctx, *t, inst, s, rebuild_over_instances(ctx, *t));
+    if (rb == HRT_OK) t->built_posed = true;      // (built for the instances as they are now: the next update need not be checked on the spot)
+    return rb;
 }
 
 int hrt_pose_instances(HrtContext *ctx, HrtInstance *d_instances, uint32_t first_instance, uint32_t n_particles,

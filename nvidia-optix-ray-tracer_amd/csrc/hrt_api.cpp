@@ -95,7 +95,7 @@ int ensure_workspace(HrtContext *ctx, uint32_t n, uint32_t height) {
         w.rows_capacity = height;
     }
     for (SampleSet &st : w.set)
-        if (!st.stages) HIP_TRY(ctx, hipMalloc((void **)&st.stages, sizeof(StageCounters) * (kRayTraceDepth + 1) * kMaxSubTiles));
+        if (!st.stages) { HIP_TRY(ctx, hipMalloc((void **)&st.stages, sizeof(StageCounters) * (kRayTraceDepth + 1) * kMaxSubTiles)); ctx->fused_counters_clean = false; }
     return HRT_OK;
 }
 
@@ -165,6 +165,7 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
     if (const char *e = std::getenv("HRT_BVH_CPRIM")) ctx->build_c_prim = (float)std::atof(e);
     if (const char *e = std::getenv("HRT_BVH_CNODE")) ctx->build_c_node = (float)std::atof(e);
     if (const char *e = std::getenv("HRT_REFIT")) ctx->refit = std::atoi(e) != 0;
+    if (const char *e = std::getenv("HRT_REFIT_MOVED_FAR")) ctx->refit_moved_far_check = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_REFIT_REBUILD_RATIO")) { const double v = std::atof(e); if (v >= 1.0) ctx->refit_rebuild_ratio = (float)v; }
     if (const char *e = std::getenv("HRT_FUSED_LPT")) { const int v = std::atoi(e); if (v >= 0 && v <= 64) ctx->fused_lpt = v; }
     if (const char *e = std::getenv("HRT_FUSED_MAX_SPP")) { const int v = std::atoi(e); if (v >= 1) ctx->fused_max_spp = v; }
@@ -431,6 +432,7 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
             const uint32_t probe_spp = (uint32_t)std::min<int>(std::max(ctx->fused_lpt, 1), (int)spp / 4);
             pa.spp = probe_spp; pa.continue_sum = 0u; pa.slice_cost = w.slice_cost; pa.slice_order = nullptr;
             { Timer tm(ctx, s, HRT_K_PATHS); launch(); }
+            ctx->fused_counters_clean = false;
             ctx->h_slice_cost.resize(n_slices); ctx->h_slice_order.resize(n_slices);
             HIP_TRY(ctx, hipMemcpyAsync(ctx->h_slice_cost.data(), w.slice_cost, sizeof(uint32_t) * n_slices, hipMemcpyDeviceToHost, s));
             HIP_TRY(ctx, hipStreamSynchronize(s));
@@ -446,7 +448,9 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         while (done_spp < spp) {
             const uint32_t now = std::min<uint32_t>(spp - done_spp, (uint32_t)ctx->fused_max_spp);
             pa.spp = now; pa.continue_sum = done_spp > 0 ? 1u : 0u;
-            HIP_TRY(ctx, hipMemsetAsync(stg, 0, sizeof(StageCounters), s));
+            // (the slice counters: zeroed by the finalize kernel of the previous launch when that was a path-kernel launch too)
+            if (!ctx->fused_counters_clean) HIP_TRY(ctx, hipMemsetAsync(stg, 0, sizeof(StageCounters), s));
+            ctx->fused_counters_clean = false;
             { Timer tm(ctx, s, HRT_K_PATHS); launch(); }
             done_spp += now;
         }
@@ -454,13 +458,17 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
         fa.accum = w.accum; fa.rows = w.rows; fa.n_tile_pixels = n; fa.width = rg->width; fa.spp = spp;
         fa.color = reinterpret_cast<float4 *>(rg->colorBuffer); fa.albedo = reinterpret_cast<float4 *>(rg->albedoBuffer);
         fa.normal = reinterpret_cast<float4 *>(rg->normalBuffer); fa.linear = ctx->d_linear;
+        constexpr uint32_t kCounterWords = (uint32_t)(sizeof(StageCounters) / sizeof(uint32_t));
+        if (n >= kCounterWords) { fa.reset_counters = reinterpret_cast<uint32_t *>(stg); fa.n_reset = kCounterWords; }
         { Timer tm(ctx, s, HRT_K_FINALIZE); launch_finalize(fa, s); }
+        ctx->fused_counters_clean = fa.reset_counters != nullptr;
         HIP_TRY(ctx, hipGetLastError());
         ctx->paths += (uint64_t)n * spp;
         ctx->last_tlas = h_params->handle;
         return HRT_OK;
     }
 
+    ctx->fused_counters_clean = false;      // (the wavefront schedule below shares the counters' memory)
     // ---- sub-tiles: contiguous ranges of the tile's pixels, each on its own stream.  A traverse
     //      launch ends with a tail (the longest rays, ~0.3 ms) during which most CUs idle; with
     //      2-3 independent sub-tiles in flight one sub-tile's tail overlaps another's bulk. ----

@@ -69,6 +69,8 @@ struct Tlas {
     // asynchronous updates (HRT_CTX_ASYNC_UPDATE): what the tree was built with, for the device-side tables kernel, and its verdict
     unsigned long long *d_sig_handle = nullptr; uint32_t *d_sig_visibility = nullptr, *d_sig_sbt = nullptr; float *d_blas_box = nullptr;
     uint32_t *d_update_flags = nullptr;                  // [0] scene scale (float bits), [1] bit 0: handle / visibility changed, bit 1: an sbtOffset changed
+    bool built_posed = false;                            // built by an update, for the poses of that frame (not the reference's identity-posed load-time build): asynchronous updates may follow at once
+    bool async_words_ready = false;                      // d_update_flags / d_area are in their initial state (the asynchronous update's epilogue leaves them so)
     uint32_t *h_update_flags = nullptr;                  // pinned: [0..1] copy of the above after the last update, [2..3] their initial values
     std::vector<std::pair<uint32_t, uint32_t>> phases;   // (first, count) in processing order, children before parents
     bool instanced = false;
@@ -162,6 +164,7 @@ struct HrtContext {
     int fused_postpone_pct = 40;                // (r02_sweep_lanes_active.txt: same speed as 25, 65 % of the lanes active instead of 63.4 %)
     int fused_max_depth = kFusedMaxDepth;       // deeper trees take round 1's fused kernel (HRT_FUSED_MAX_DEPTH lowers it: tests)
     uint64_t fused_max_bytes = 1ull << 32;      // k_fused addresses nodes and records by 32-bit byte offsets: larger arrays take round 1's kernel (HRT_FUSED_MAX_BYTES lowers it: tests)
+    bool fused_counters_clean = false;          // the path kernel's slice counters are zero (the previous launch's finalize kernel left them so)
     uint64_t fused_fallback_launches = 0;       // launches that took round 1's path kernel because the tree did not fit k_fused
     int wavefront_lean = 1;                     // wavefront mode traverses with k_trace_queue (the loop of k_fused); 0: round 1's k_traverse (HRT_WAVEFRONT_LEAN)
     int wavefront_graph = 0;                    // wavefront mode: 1 = replay a captured pair of samples as a hipGraph; 0 (default) = enqueue every launch: the launches
@@ -200,6 +203,7 @@ struct HrtContext {
                                                 // on the soup scenes (C4: 24.1 node visits per ray, 16: 28.3, 64: 36.6 -- profiles/r02_build_bench.txt)
     float build_c_node = 1.0f, build_c_prim = 0.45f;   // collapse costs (bvh8_build.cpp has the same defaults)
     int refit = 1;                              // hrt_tlas_update: 1 = device refit when only transforms changed, 0 = always rebuild
+    int refit_moved_far_check = 1;              // the first update after a build rebuilds without refitting first when most instances have moved further than their size (HRT_REFIT_MOVED_FAR=0: always refit first)
     float refit_rebuild_ratio = 1.5f;           // rebuild when the refitted tree's weighted mean node area has grown by this factor
     std::atomic<uint64_t> tlas_refits{0}, tlas_rebuilds{0}; std::atomic<double> tlas_refit_ratio{1.0};   // (builds run on several loader threads)
     int substreams = 0;                         // sub-tiles rendered on their own HIP streams so that one's tail overlaps another's bulk

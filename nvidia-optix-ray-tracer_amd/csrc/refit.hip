@@ -249,6 +249,14 @@ __global__ __launch_bounds__(256) void k_instance_tables(InstanceTableArgs a) {
         atomicMax(&a.flags[0], __float_as_uint(smax));         // positive floats order like their bits
     }
 }
+__global__ void k_update_epilogue(UpdateEpilogueArgs a) {
+    if (threadIdx.x != 0u || blockIdx.x != 0u) return;
+    *a.h_area = *a.d_area; a.h_flags[0] = a.d_flags[0]; a.h_flags[1] = a.d_flags[1];
+    __threadfence_system();
+    *a.d_area = 0.0f; a.d_flags[0] = a.flags_init0; a.d_flags[1] = a.flags_init1;
+}
+void launch_update_epilogue(const UpdateEpilogueArgs &a, hipStream_t s) { hipLaunchKernelGGL(k_update_epilogue, dim3(1), dim3(64), 0, s, a); }
+
 void launch_instance_tables(const InstanceTableArgs &a, hipStream_t s) {
     if (a.n) hipLaunchKernelGGL(k_instance_tables, dim3((a.n + 255u) / 256u), dim3(256), 0, s, a);
 }

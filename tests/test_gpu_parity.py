@@ -778,31 +778,38 @@ def test_tree_over_instances_parity(hrt, oracle, gpu_available, monkeypatch):
 
 def test_rebuild_during_animation_uses_the_tree_over_instances(hrt, oracle, gpu_available, monkeypatch):
     """The reference builds each file's IAS with identity transforms and poses it afterwards (RendererTime.cu:111-127):
-    all particles start on top of each other and the first refit degrades the tree.  That refit is checked on the spot
-    and the tree rebuilt within the same update -- as a tree over instances (milliseconds) -- so no frame is traced
-    through the degraded tree.  Image parity after the rebuild and after a further refit."""
+    all particles start on top of each other.  The first update sees that most instances are further from where the tree
+    was built than they are wide and rebuilds at once -- as a tree over instances (milliseconds), without refitting the
+    useless tree first; with that check off (HRT_REFIT_MOVED_FAR=0) the refit is done, checked on the spot, and the tree
+    rebuilt within the same update.  Either way no frame is traced through the degraded tree.  Image parity after the
+    rebuild and after a further refit."""
     if not gpu_available:
         pytest.skip("no GPU")
-    r = hrt.Renderer(0, 0)
-    try:
-        n_p, w, h = 30, 72, 48
-        scene = hrt.scenes.particle_scene(n_p, w, h, 1, frame=0)
-        posed = [it["transform"].copy() for it in scene["instances"]]
-        for it in scene["instances"][1:]:
-            it["transform"] = hrt.scenes.IDENTITY.copy()
-        r.load_scene(scene)                                   # merged build over the overlapping particles
-        r.update_instances(posed)                             # refit: boxes explode -> checked on the spot -> rebuilt
-        s = r.stats()
-        assert s.tlas_refits == 1 and s.tlas_rebuilds == 2 and s.tlas_refit_ratio > 1.5
-        for it, m in zip(scene["instances"], posed):
-            it["transform"] = m
-        _moved_scene_matches_oracle(hrt, oracle, r, scene, w, h, 11)
-        r.update_instances(posed)                             # and the rebuilt tree refits
-        s = r.stats()
-        assert s.tlas_refits == 2 and s.tlas_rebuilds == 2 and s.tlas_refit_ratio < 1.01
-        _moved_scene_matches_oracle(hrt, oracle, r, scene, w, h, 12)
-    finally:
-        r.close()
+    for moved_far_check in (True, False):
+        monkeypatch.setenv("HRT_REFIT_MOVED_FAR", "1" if moved_far_check else "0")
+        r = hrt.Renderer(0, 0)
+        try:
+            n_p, w, h = 30, 72, 48
+            scene = hrt.scenes.particle_scene(n_p, w, h, 1, frame=0)
+            posed = [it["transform"].copy() for it in scene["instances"]]
+            for it in scene["instances"][1:]:
+                it["transform"] = hrt.scenes.IDENTITY.copy()
+            r.load_scene(scene)                                   # merged build over the overlapping particles
+            r.update_instances(posed)                             # rebuilt: at once, or after a refit whose boxes explode
+            s = r.stats()
+            if moved_far_check:
+                assert s.tlas_refits == 0 and s.tlas_rebuilds == 2
+            else:
+                assert s.tlas_refits == 1 and s.tlas_rebuilds == 2 and s.tlas_refit_ratio > 1.5
+            for it, m in zip(scene["instances"], posed):
+                it["transform"] = m
+            _moved_scene_matches_oracle(hrt, oracle, r, scene, w, h, 11)
+            r.update_instances(posed)                             # and the rebuilt tree refits
+            s = r.stats()
+            assert s.tlas_refits == (1 if moved_far_check else 2) and s.tlas_rebuilds == 2 and s.tlas_refit_ratio < 1.01
+            _moved_scene_matches_oracle(hrt, oracle, r, scene, w, h, 12)
+        finally:
+            r.close()
 
 
 def test_refit_quality_guard_rebuilds(hrt, oracle, monkeypatch):

@@ -123,9 +123,11 @@ def test_two_level_animation_refits_the_top_level_only(hrt, oracle, gpu_availabl
             r.close()
 
 
-def test_two_level_rebuild_when_the_particles_start_on_top_of_each_other(hrt, oracle, gpu_available):
+def test_two_level_rebuild_when_the_particles_start_on_top_of_each_other(hrt, oracle, gpu_available, monkeypatch):
     """The reference builds each file's IAS with identity transforms and poses it afterwards (RendererTime.cu:111-127): the first
-    update's refit degrades the top level, is checked on the spot and rebuilds -- as a two-level tree again."""
+    update rebuilds -- at once when it sees how far the instances have gone, else (HRT_REFIT_MOVED_FAR=0) after a refit that is
+    checked on the spot -- as a two-level tree again."""
+    monkeypatch.setenv("HRT_REFIT_MOVED_FAR", "0")
     r = _two_level(hrt, gpu_available)
     try:
         n_p, w, h = 30, 72, 48
