@@ -119,17 +119,62 @@ def profile_fields(profiles_dir, running):
 ISSUE_FLOOR_CYCLES = 2.4        # SIMD cycles per instruction with >= 2 waves issuing side by side (profiles/r02_valu_pipes_microbench.txt)
 
 
+def effective_cpus():
+    """How many CPUs this process may really use, and why: the OpenMP default is the machine's logical CPU count, which on a shared
+    box is far more than the affinity mask / the cgroup's quota gives (round 3: 128 threads on the GPU box ran 0.025 Mrays/s each
+    against 0.085 in the 8-CPU build container).  Returns (n, detail)."""
+    detail = {"os_cpu_count": os.cpu_count()}
+    n = os.cpu_count() or 1
+    try:
+        detail["sched_affinity"] = len(os.sched_getaffinity(0))
+        n = min(n, detail["sched_affinity"])
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                detail["cgroup_cpu_max"] = " ".join(txt)
+                if txt[0] != "max":
+                    n = min(n, max(1, int(np.ceil(int(txt[0]) / int(txt[1])))))
+            else:
+                quota = int(txt[0])
+                period = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                detail["cgroup_cfs_quota_us"], detail["cgroup_cfs_period_us"] = quota, period
+                if quota > 0:
+                    n = min(n, max(1, int(np.ceil(quota / period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n), detail
+
+
 def cpu_baseline(hrt, scene, target_seconds, renderer=None):
     """The CPU oracle (kind "port": the reference has no CPU path to build) on a bounded sample of
     the same workload: the same frame at a reduced number of samples per pixel (or a subset of its
-    rows when even 1 spp would take too long), all host threads, sized for ~target_seconds.
-    With a renderer, the GPU renders the very same sample afterwards and the two images are compared
-    (the metric's "image L-inf vs ref"): returns (cpu_baseline, parity)."""
+    rows when even 1 spp would take too long), sized for ~target_seconds, on as many threads as the process
+    really has CPUs (effective_cpus).  With a renderer the oracle walks THE PRODUCT'S TREE -- the packed BVH8 the
+    GPU has just been timed on, fetched with hrt_tlas_download ("same BVH bytes as the GPU
+    run"; the closest hit is canonical, so the image is the oracle's own) -- and the GPU renders the very same
+    sample afterwards; the two images are compared (the metric's "image L-inf vs ref"): returns (cpu_baseline, parity)."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle_py
     W, H = scene["width"], scene["height"]
-    threads = oracle_py.lib().oracle_num_threads()
+    omp_default = oracle_py.lib().oracle_num_threads()
+    threads, cpu_detail = effective_cpus()
+    threads = min(threads, omp_default) if os.environ.get("OMP_NUM_THREADS") else threads
+    oracle_py.lib().oracle_set_threads(threads)
     osc = oracle_py.OracleScene(scene)
+    tree = "oracle/oracle.c's own median-split BVH2"
+    if renderer is not None and os.environ.get("HRT_BENCH_CPU_OWN_TREE") != "1":
+        import ctypes as C
+        blob = hrt.BvhBlob()
+        if renderer.lib.hrt_tlas_download(renderer.ctx, renderer.tlas, C.byref(blob)) == 0:
+            nodes = np.ctypeslib.as_array(C.cast(blob.nodes, C.POINTER(C.c_uint8)), shape=(blob.n_nodes * 80,)).copy()
+            prims = np.ctypeslib.as_array(C.cast(blob.triangles, C.POINTER(C.c_uint8)), shape=(max(blob.n_triangles, 1) * 48,)).copy()
+            tree = f"the product's packed BVH8 as timed on the GPU (hrt_tlas_download: {blob.n_nodes} nodes, {blob.n_triangles} records, {len(nodes) + len(prims)} bytes)"
+            renderer.lib.hrt_host_free(C.byref(blob))
+            osc.attach_bvh8(nodes, prims)
     states = oracle_py.rng_init(W, H, hrt.scenes.SEED_SALT)
     probe_rows = np.arange(4, H, 16, dtype=np.uint32)                    # calibrate on 1/16 of the rows
     t0 = time.perf_counter()
@@ -148,8 +193,9 @@ def cpu_baseline(hrt, scene, target_seconds, renderer=None):
     osc.close()
     n_rows = H if rows is None else len(rows)
     base = {"value": round(r["rays"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": int(threads), "kind": "port",
-            "sample": f"{n_rows} of {H} rows x {W} px, {spp} spp, {r['rays']} rays in {dt:.1f} s, "
-                      f"oracle/oracle.c (own BVH2) OpenMP x{threads}"}
+            "sample": f"{n_rows} of {H} rows x {W} px, {spp} spp, {r['rays']} rays in {dt:.1f} s, oracle/oracle.c OpenMP x{threads} walking {tree}",
+            "per_thread": round(r["rays"] / dt / 1e6 / threads, 4), "node_visits_per_ray": round(r["node_visits"] / max(r["rays"], 1), 2),
+            "cpus": dict(cpu_detail, omp_default_threads=int(omp_default), threads_used=int(threads))}
     if renderer is None:
         return base, None
     # the same sample on the GPU, from the same seeded streams
@@ -248,19 +294,28 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    torch.cuda.synchronize(dev)
+    own_elapsed = time.perf_counter() - t0          # this rank's own work done (before it waits for the others at the barrier)
     fence()
     elapsed = time.perf_counter() - t0
     st = r.stats()
 
-    # max over ranks of the time, sum over ranks of the rays
+    # max over ranks of the time, sum over ranks of the rays; and every rank's own time up to the end of ITS work (N > 1: the tail
+    # imbalance of the tile split -- a rank whose stripes hold the long sample chains -- shows as min against max)
+    own = [0.0] * world
+    own[rank] = own_elapsed
+    per_rank = torch.tensor(own, dtype=torch.float64, device=dev)
     tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     rays = torch.tensor([float(st.rays), float(st.rays_closest), st.kernel_ms[hrt.K_TRAVERSE],
                          float(st.kernel_launches[hrt.K_TRAVERSE]), 1.0], dtype=torch.float64, device=dev)   # [4]: one per rank
     if world > 1:
         if backend != "nccl":
             tt, rays = tt.cpu(), rays.cpu()
+            per_rank = per_rank.cpu()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+    rank_elapsed = [float(x) for x in per_rank.tolist()]
     elapsed = float(tt.item())
     total_rays = float(rays[0].item())
     ranks_seen = int(round(float(rays[4].item())))
@@ -313,6 +368,8 @@ def main():
             "unit": "Mrays/s",
             "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
+            "rank_ms_per_step": {"min": round(min(rank_elapsed) / max(args.steps, 1) * 1e3, 3), "max": round(max(rank_elapsed) / max(args.steps, 1) * 1e3, 3),
+                                 "per_rank": [round(x / max(args.steps, 1) * 1e3, 3) for x in rank_elapsed]},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

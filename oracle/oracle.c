@@ -308,6 +308,9 @@ typedef struct {
     bnode *nodes; uint32_t n_nodes;
     int brute;
     int object_space;               /* 1: the INSTANCED canonical mode (below): triangles of transformed instances stay in object space */
+    /* optional: the PRODUCT's packed BVH8 (hrt_tlas_download), walked instead of the BVH2 above -- the closest hit is canonical, so the
+     * image is the same; bench.py's cpu_baseline times the CPU on the very bytes the GPU traverses */
+    const void *bvh8_nodes, *bvh8_prims;
 } oracle_scene;
 
 /* point / vector transform with a fixed operation order (shared definition with the product) */
@@ -404,10 +407,19 @@ static inline void test_ref(const oracle_scene *sc, uint32_t ref, f3 o, f3 d, fl
 
 typedef struct { uint64_t rays, node_visits, prim_tests; } trace_counters;
 
+static void bvh8_walk(const uint32_t *nodes, const void *prims_blob, const float *inst_inv, const uint32_t *inst_identity, f3 ow, f3 dw,
+                      float tmin, float tmax, int any_hit, hit_rec *out, uint64_t *n_nodes, uint64_t *n_prims, uint64_t *n_empty);
+
 static void closest_hit(const oracle_scene *sc, f3 o, f3 d, float tmin, float tmax, int any_hit,
                         hit_rec *best, trace_counters *cnt) {
     best->hit = 0; best->t = tmax; best->u = best->v = 0.0f; best->prim = best->inst = 0xffffffffu;
     if (cnt) cnt->rays++;
+    if (sc->bvh8_nodes) {
+        uint64_t nn = 0, np = 0, ne = 0;
+        bvh8_walk((const uint32_t *)sc->bvh8_nodes, sc->bvh8_prims, &sc->inv[0][0], (const uint32_t *)sc->identity, o, d, tmin, tmax, any_hit, best, &nn, &np, &ne);
+        if (cnt) { cnt->node_visits += nn; cnt->prim_tests += np; }
+        return;
+    }
     if (sc->brute || sc->n_nodes == 0) {
         for (uint32_t r = 0; r < sc->n_prim; ++r) {
             test_ref(sc, r, o, d, tmin, tmax, best);
@@ -591,6 +603,10 @@ oracle_scene *oracle_scene_create_mode(const oracle_instance *inst, int n_inst, 
 }
 oracle_scene *oracle_scene_create(const oracle_instance *inst, int n_inst, int force_brute) {
     return oracle_scene_create_mode(inst, n_inst, force_brute, 0);
+}
+/* closest_hit then walks this tree (the product's, for the same instances in the same order); NULL detaches.  The blobs stay the caller's. */
+void oracle_scene_attach_bvh8(oracle_scene *sc, const void *nodes, const void *prims) {
+    sc->bvh8_nodes = nodes; sc->bvh8_prims = nodes ? prims : NULL;
 }
 void oracle_scene_destroy(oracle_scene *sc) {
     if (!sc) return;
@@ -806,114 +822,121 @@ static inline float safe_rcp_dir(float d) {
     return 1.0f / dd;
 }
 
+/* one ray through a packed BVH8 (one- or two-level): the canonical closest hit (or any hit), and what the walk cost */
+static void bvh8_walk(const uint32_t *nodes, const void *prims_blob, const float *inst_inv, const uint32_t *inst_identity, f3 ow, f3 dw,
+                      float tmin, float tmax, int any_hit, hit_rec *out, uint64_t *n_nodes, uint64_t *n_prims, uint64_t *n_empty) {
+    const prim48 *prims = (const prim48 *)prims_blob;
+    uint64_t tot_nodes = 0, tot_prims = 0, tot_empty = 0;
+    /* the ray in the space being walked: world, or -- below a transform node of a two-level tree -- the instance's object space */
+    f3 o = ow, d = dw;
+    float idx = safe_rcp_dir(d.x), idy = safe_rcp_dir(d.y), idz = safe_rcp_dir(d.z);
+    uint32_t oct = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u);
+    uint32_t oct_inv = 7u - oct;
+    uint32_t cur_inst = 0xffffffffu;         /* the instance whose BLAS is being walked (two-level trees) */
+    hit_rec best; best.hit = 0; best.t = tmax; best.u = best.v = 0.0f; best.prim = best.inst = 0xffffffffu;
+    uint32_t stack_x[64], stack_y[64]; int sp = 0;
+    uint32_t cur_x = 0, cur_y = 0x80000000u;
+    int done = 0;
+    while (!done) {
+        uint32_t tri_x = 0, tri_y = 0;
+        if (cur_y > 0x00ffffffu) {
+            const uint32_t hits_imask = cur_y;
+            uint32_t bit = 31; while (!((hits_imask >> bit) & 1u)) --bit;
+            cur_y &= ~(1u << bit);
+            if (cur_y > 0x00ffffffu) { stack_x[sp] = cur_x; stack_y[sp] = cur_y; ++sp; }
+            const uint32_t slot_index = (bit - 24u) ^ oct_inv;
+            const uint32_t rel = (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot_index));
+            const uint32_t *nd = nodes + 20 * (size_t)(cur_x + rel);
+            ++tot_nodes;
+            const uint32_t e_imask = nd[3];
+            if (e_imask == 0u) {
+                /* a transform node (two-level trees, csrc/bvh8.h): word 4 = root of the instance's BLAS, word 5 = instance,
+                 * word 6 = identity flag, words 8..19 = world -> object.  The ray goes into object space; a marker on the stack
+                 * brings the world ray back when the BLAS has been walked. */
+                stack_x[sp] = 0xffffffffu; stack_y[sp] = 0u; ++sp;
+                cur_inst = nd[5];
+                if (!nd[6]) { const float *m = (const float *)(nd + 8); o = xf_point(m, ow); d = xf_vector(m, dw); }
+                idx = safe_rcp_dir(d.x); idy = safe_rcp_dir(d.y); idz = safe_rcp_dir(d.z);
+                oct = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u); oct_inv = 7u - oct;
+                cur_x = nd[4]; cur_y = 0x01000000u;          /* one child: the root (no inner-mask bits: index = base) */
+                continue;
+            }
+            float p[3]; memcpy(p, nd, 12);
+            uint32_t eb; float sx, sy, sz;
+            eb = (e_imask & 0xffu) << 23; memcpy(&sx, &eb, 4);
+            eb = ((e_imask >> 8) & 0xffu) << 23; memcpy(&sy, &eb, 4);
+            eb = ((e_imask >> 16) & 0xffu) << 23; memcpy(&sz, &eb, 4);
+            const float aix = sx * idx, aiy = sy * idy, aiz = sz * idz;
+            const float aox = (p[0] - o.x) * idx, aoy = (p[1] - o.y) * idy, aoz = (p[2] - o.z) * idz;
+            const uint8_t *meta = (const uint8_t *)(nd + 6);
+            const uint8_t *q = (const uint8_t *)(nd + 8);        /* qlo[3][8], qhi[3][8] */
+            uint32_t hitmask = 0;
+            const float bt = best.hit ? best.t : tmax;
+            for (int s = 0; s < 8; ++s) {
+                const uint32_t m = meta[s];
+                const int is_inner = ((m & (m << 1)) & 0x10u) != 0;
+                const uint32_t bit_index = (m ^ (is_inner ? oct_inv : 0u)) & 0x1fu;
+                const uint32_t child_bits = (m >> 5) & 7u;
+                const float qlx = q[0 * 8 + s], qly = q[1 * 8 + s], qlz = q[2 * 8 + s];
+                const float qhx = q[24 + 0 * 8 + s], qhy = q[24 + 1 * 8 + s], qhz = q[24 + 2 * 8 + s];
+                const float tnx = fmaf(d.x < 0.0f ? qhx : qlx, aix, aox), tfx = fmaf(d.x < 0.0f ? qlx : qhx, aix, aox);
+                const float tny = fmaf(d.y < 0.0f ? qhy : qly, aiy, aoy), tfy = fmaf(d.y < 0.0f ? qly : qhy, aiy, aoy);
+                const float tnz = fmaf(d.z < 0.0f ? qhz : qlz, aiz, aoz), tfz = fmaf(d.z < 0.0f ? qlz : qhz, aiz, aoz);
+                const float tlo = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+                const float thi = fminf(fminf(tfx, tfy), fminf(tfz, bt));
+                if (tlo <= thi) hitmask |= child_bits << bit_index;
+            }
+            cur_x = nd[4]; cur_y = (hitmask & 0xff000000u) | (e_imask >> 24);
+            tri_x = nd[5]; tri_y = hitmask & 0x00ffffffu;
+            if (hitmask == 0u) ++tot_empty;
+        }
+        while (tri_y) {
+            const uint32_t k = (uint32_t)__builtin_ctz(tri_y);
+            tri_y &= tri_y - 1u;
+            ++tot_prims;
+            const prim48 *pr = &prims[tri_x + k];
+            const uint32_t pinst = cur_inst != 0xffffffffu ? cur_inst : pr->inst;      /* a shared BLAS does not know who instances it */
+            float t, u = 0.0f, v = 0.0f; int h = 0;
+            if (pr->kind == 1u) {
+                wsph s; s.c = mk3(pr->a[0], pr->a[1], pr->a[2]); s.r = pr->b[0];
+                f3 oo = o, dd = d;
+                if (cur_inst == 0xffffffffu && inst_identity && !inst_identity[pr->inst]) { oo = xf_point(inst_inv + 12 * (size_t)pr->inst, o); dd = xf_vector(inst_inv + 12 * (size_t)pr->inst, d); }
+                h = isect_sph(&s, oo, dd, tmin, tmax, &t);
+            } else {
+                wtri tr; tr.v0 = mk3(pr->a[0], pr->a[1], pr->a[2]); tr.e1 = mk3(pr->b[0], pr->b[1], pr->b[2]); tr.e2 = mk3(pr->c[0], pr->c[1], pr->c[2]);
+                h = isect_tri(&tr, o, d, tmin, tmax, &t, &u, &v);
+            }
+            if (h) { consider(&best, t, u, v, pr->prim, pinst); if (any_hit) { done = 1; break; } }
+        }
+        while (!done && cur_y <= 0x00ffffffu) {
+            if (sp == 0) { done = 1; break; }
+            --sp; cur_x = stack_x[sp]; cur_y = stack_y[sp];
+            if (cur_x == 0xffffffffu && cur_y == 0u) {       /* the marker: back to world space */
+                o = ow; d = dw; cur_inst = 0xffffffffu;
+                idx = safe_rcp_dir(d.x); idy = safe_rcp_dir(d.y); idz = safe_rcp_dir(d.z);
+                oct = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u); oct_inv = 7u - oct;
+            }
+        }
+    }
+    *out = best; *n_nodes += tot_nodes; *n_prims += tot_prims; *n_empty += tot_empty;
+}
+
 void oracle_bvh8_trace(const void *nodes_blob, const void *prims_blob,
                        const float *inst_inv /* 12 per instance or NULL */, const uint32_t *inst_identity,
                        const float *origins, const float *dirs, uint32_t n_rays,
                        float tmin, float tmax, int any_hit,
                        float *t_out, float *u_out, float *v_out, uint32_t *prim_out, uint32_t *inst_out,
                        uint64_t *out_counters /* [4]: node visits, prim tests, node visits that found nothing to enter or test, 0 */, uint32_t *per_ray_nodes /* or NULL */) {
-    const uint32_t *nodes = (const uint32_t *)nodes_blob;          /* 20 words per node */
-    const prim48 *prims = (const prim48 *)prims_blob;
     uint64_t tot_nodes = 0, tot_prims = 0, tot_empty = 0;
     #pragma omp parallel for schedule(dynamic, 256) reduction(+:tot_nodes, tot_prims, tot_empty)
     for (long ri = 0; ri < (long)n_rays; ++ri) {
-        const f3 ow = mk3(origins[3 * ri], origins[3 * ri + 1], origins[3 * ri + 2]);
-        const f3 dw = mk3(dirs[3 * ri], dirs[3 * ri + 1], dirs[3 * ri + 2]);
-        /* the ray in the space being walked: world, or -- below a transform node of a two-level tree -- the instance's object space */
-        f3 o = ow, d = dw;
-        float idx = safe_rcp_dir(d.x), idy = safe_rcp_dir(d.y), idz = safe_rcp_dir(d.z);
-        uint32_t oct = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u);
-        uint32_t oct_inv = 7u - oct;
-        uint32_t cur_inst = 0xffffffffu;         /* the instance whose BLAS is being walked (two-level trees) */
-        hit_rec best; best.hit = 0; best.t = tmax; best.u = best.v = 0.0f; best.prim = best.inst = 0xffffffffu;
-        uint32_t stack_x[64], stack_y[64]; int sp = 0;
-        uint32_t cur_x = 0, cur_y = 0x80000000u;
-        int done = 0;
-        uint32_t my_nodes = 0;
-        while (!done) {
-            uint32_t tri_x = 0, tri_y = 0;
-            if (cur_y > 0x00ffffffu) {
-                const uint32_t hits_imask = cur_y;
-                uint32_t bit = 31; while (!((hits_imask >> bit) & 1u)) --bit;
-                cur_y &= ~(1u << bit);
-                if (cur_y > 0x00ffffffu) { stack_x[sp] = cur_x; stack_y[sp] = cur_y; ++sp; }
-                const uint32_t slot_index = (bit - 24u) ^ oct_inv;
-                const uint32_t rel = (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot_index));
-                const uint32_t *nd = nodes + 20 * (size_t)(cur_x + rel);
-                ++tot_nodes; ++my_nodes;
-                const uint32_t e_imask = nd[3];
-                if (e_imask == 0u) {
-                    /* a transform node (two-level trees, csrc/bvh8.h): word 4 = root of the instance's BLAS, word 5 = instance,
-                     * word 6 = identity flag, words 8..19 = world -> object.  The ray goes into object space; a marker on the stack
-                     * brings the world ray back when the BLAS has been walked. */
-                    stack_x[sp] = 0xffffffffu; stack_y[sp] = 0u; ++sp;
-                    cur_inst = nd[5];
-                    if (!nd[6]) { const float *m = (const float *)(nd + 8); o = xf_point(m, ow); d = xf_vector(m, dw); }
-                    idx = safe_rcp_dir(d.x); idy = safe_rcp_dir(d.y); idz = safe_rcp_dir(d.z);
-                    oct = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u); oct_inv = 7u - oct;
-                    cur_x = nd[4]; cur_y = 0x01000000u;          /* one child: the root (no inner-mask bits: index = base) */
-                    continue;
-                }
-                float p[3]; memcpy(p, nd, 12);
-                uint32_t eb; float sx, sy, sz;
-                eb = (e_imask & 0xffu) << 23; memcpy(&sx, &eb, 4);
-                eb = ((e_imask >> 8) & 0xffu) << 23; memcpy(&sy, &eb, 4);
-                eb = ((e_imask >> 16) & 0xffu) << 23; memcpy(&sz, &eb, 4);
-                const float aix = sx * idx, aiy = sy * idy, aiz = sz * idz;
-                const float aox = (p[0] - o.x) * idx, aoy = (p[1] - o.y) * idy, aoz = (p[2] - o.z) * idz;
-                const uint8_t *meta = (const uint8_t *)(nd + 6);
-                const uint8_t *q = (const uint8_t *)(nd + 8);        /* qlo[3][8], qhi[3][8] */
-                uint32_t hitmask = 0;
-                const float bt = best.hit ? best.t : tmax;
-                for (int s = 0; s < 8; ++s) {
-                    const uint32_t m = meta[s];
-                    const int is_inner = ((m & (m << 1)) & 0x10u) != 0;
-                    const uint32_t bit_index = (m ^ (is_inner ? oct_inv : 0u)) & 0x1fu;
-                    const uint32_t child_bits = (m >> 5) & 7u;
-                    const float qlx = q[0 * 8 + s], qly = q[1 * 8 + s], qlz = q[2 * 8 + s];
-                    const float qhx = q[24 + 0 * 8 + s], qhy = q[24 + 1 * 8 + s], qhz = q[24 + 2 * 8 + s];
-                    const float tnx = fmaf(d.x < 0.0f ? qhx : qlx, aix, aox), tfx = fmaf(d.x < 0.0f ? qlx : qhx, aix, aox);
-                    const float tny = fmaf(d.y < 0.0f ? qhy : qly, aiy, aoy), tfy = fmaf(d.y < 0.0f ? qly : qhy, aiy, aoy);
-                    const float tnz = fmaf(d.z < 0.0f ? qhz : qlz, aiz, aoz), tfz = fmaf(d.z < 0.0f ? qlz : qhz, aiz, aoz);
-                    const float tlo = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
-                    const float thi = fminf(fminf(tfx, tfy), fminf(tfz, bt));
-                    if (tlo <= thi) hitmask |= child_bits << bit_index;
-                }
-                cur_x = nd[4]; cur_y = (hitmask & 0xff000000u) | (e_imask >> 24);
-                tri_x = nd[5]; tri_y = hitmask & 0x00ffffffu;
-                if (hitmask == 0u) ++tot_empty;
-            }
-            while (tri_y) {
-                const uint32_t k = (uint32_t)__builtin_ctz(tri_y);
-                tri_y &= tri_y - 1u;
-                ++tot_prims;
-                const prim48 *pr = &prims[tri_x + k];
-                const uint32_t pinst = cur_inst != 0xffffffffu ? cur_inst : pr->inst;      /* a shared BLAS does not know who instances it */
-                float t, u = 0.0f, v = 0.0f; int h = 0;
-                if (pr->kind == 1u) {
-                    wsph s; s.c = mk3(pr->a[0], pr->a[1], pr->a[2]); s.r = pr->b[0];
-                    f3 oo = o, dd = d;
-                    if (cur_inst == 0xffffffffu && inst_identity && !inst_identity[pr->inst]) { oo = xf_point(inst_inv + 12 * (size_t)pr->inst, o); dd = xf_vector(inst_inv + 12 * (size_t)pr->inst, d); }
-                    h = isect_sph(&s, oo, dd, tmin, tmax, &t);
-                } else {
-                    wtri tr; tr.v0 = mk3(pr->a[0], pr->a[1], pr->a[2]); tr.e1 = mk3(pr->b[0], pr->b[1], pr->b[2]); tr.e2 = mk3(pr->c[0], pr->c[1], pr->c[2]);
-                    h = isect_tri(&tr, o, d, tmin, tmax, &t, &u, &v);
-                }
-                if (h) { consider(&best, t, u, v, pr->prim, pinst); if (any_hit) { done = 1; break; } }
-            }
-            while (!done && cur_y <= 0x00ffffffu) {
-                if (sp == 0) { done = 1; break; }
-                --sp; cur_x = stack_x[sp]; cur_y = stack_y[sp];
-                if (cur_x == 0xffffffffu && cur_y == 0u) {       /* the marker: back to world space */
-                    o = ow; d = dw; cur_inst = 0xffffffffu;
-                    idx = safe_rcp_dir(d.x); idy = safe_rcp_dir(d.y); idz = safe_rcp_dir(d.z);
-                    oct = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u); oct_inv = 7u - oct;
-                }
-            }
-        }
+        hit_rec best; uint64_t nn = 0, np = 0, ne = 0;
+        bvh8_walk((const uint32_t *)nodes_blob, prims_blob, inst_inv, inst_identity, mk3(origins[3 * ri], origins[3 * ri + 1], origins[3 * ri + 2]),
+                  mk3(dirs[3 * ri], dirs[3 * ri + 1], dirs[3 * ri + 2]), tmin, tmax, any_hit, &best, &nn, &np, &ne);
+        tot_nodes += nn; tot_prims += np; tot_empty += ne;
         t_out[ri] = best.hit ? best.t : tmax; u_out[ri] = best.u; v_out[ri] = best.v;
         prim_out[ri] = best.hit ? best.prim : 0xffffffffu; inst_out[ri] = best.hit ? best.inst : 0xffffffffu;
-        if (per_ray_nodes) per_ray_nodes[ri] = my_nodes;
+        if (per_ray_nodes) per_ray_nodes[ri] = (uint32_t)nn;
     }
     if (out_counters) { out_counters[0] = tot_nodes; out_counters[1] = tot_prims; out_counters[2] = tot_empty; out_counters[3] = 0; }
 }

@@ -36,6 +36,7 @@ def lib():
     L.oracle_scene_create_mode.restype = C.c_void_p
     L.oracle_scene_create_mode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.oracle_scene_destroy.argtypes = [C.c_void_p]
+    L.oracle_scene_attach_bvh8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.oracle_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
                                 C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.oracle_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_int,
@@ -156,6 +157,16 @@ class OracleScene:
         prim, inst = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
         L.oracle_trace_rays(self.handle, _p(o), _p(d), n, tmin, tmax, int(any_hit), _p(t), _p(u), _p(v), _p(prim), _p(inst))
         return t, u, v, prim, inst
+
+    def attach_bvh8(self, nodes, prims):
+        """Walk the PRODUCT's packed BVH8 (uint8 arrays as hrt_tlas_download / hrt_host_build_bvh8 return them, for these very
+        instances) instead of the oracle's own BVH2: same image (the closest hit is canonical), the product's bytes.  None detaches."""
+        if nodes is None:
+            lib().oracle_scene_attach_bvh8(self.handle, None, None)
+            self._bvh8 = None
+            return
+        self._bvh8 = (np.ascontiguousarray(nodes, dtype=np.uint8), np.ascontiguousarray(prims, dtype=np.uint8))
+        lib().oracle_scene_attach_bvh8(self.handle, self._bvh8[0].ctypes.data, self._bvh8[1].ctypes.data)
 
     def close(self):
         if self.handle:

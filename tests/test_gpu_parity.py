@@ -131,10 +131,11 @@ def test_render_cornell_c1(hrt, oracle, renderer):
 
 
 def test_render_sphere_in_box_c2_spp(hrt, oracle, renderer):
-    """BASELINE configs[1] at reduced size (the oracle is scalar): sphere + walls, 16 spp."""
-    scene = hrt.scenes.sphere_in_box(128, 128, 16)
+    """BASELINE configs[1] at its own size: sphere + walls, 512 x 512, 16 spp (4.2 M paths: a few seconds of oracle)."""
+    scene = hrt.scenes.sphere_in_box()
+    assert (scene["width"], scene["height"], scene["spp"]) == (512, 512, 16)
     renderer.reset_stats()
-    ref, states = _render_both(hrt, oracle, renderer, scene, 128, 128, 16)
+    ref, states = _render_both(hrt, oracle, renderer, scene, 512, 512, 16)
     _check_image(renderer, ref)
     assert np.array_equal(renderer.rng_states_numpy(), states)
     assert renderer.stats().rays == ref["rays"]
@@ -193,6 +194,48 @@ def test_tile_union_equals_full_frame(hrt, oracle, renderer):
     assert np.array_equal(acc, full_color)
     assert np.array_equal(renderer.linear.cpu().numpy()[[y for y in range(50) if (y // 4) % 3 == 2]],
                           full_linear[[y for y in range(50) if (y // 4) % 3 == 2]])
+
+
+def test_two_ranks_as_two_contexts_on_one_device(hrt, oracle, gpu_available):
+    """The N = 2 device path without a second GPU: two contexts on device 0 -- each with its own scene copy, tree, RNG states and
+    frame, as two ranks have -- render their stripes of the same frame at 16 spp (small tiles: the cost-ordered probe launch runs
+    too); the reduce is a plain add.  The sum is the one-context frame bit for bit, the oracle's too, and the rays add up."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    scene = hrt.scenes.mixed_test_scene(3000, 40, 11, 192, 128, 16)
+    w, h, spp, salt = 192, 128, 16, hrt.scenes.SEED_SALT
+    ranks = [hrt.Renderer(0, 0) for _ in range(2)]
+    try:
+        for r in ranks:
+            r.load_scene(scene)
+            r.set_frame(w, h, salt, linear=True)
+        for k, r in enumerate(ranks):                      # enqueue both before waiting for either: two contexts in flight on one card
+            r.color.zero_(); r.linear.zero_()
+            r.render(spp, tile=hrt.tile_for_rank(h, k, 2), sync=False)
+        for r in ranks:
+            r._torch.cuda.synchronize()
+        total = ranks[0].color + ranks[1].color            # ncclReduce(sum) / torch.distributed.reduce stand-in: x + 0 is exact
+        total_lin = ranks[0].linear + ranks[1].linear
+        rays = sum(r.stats().rays for r in ranks)
+        one = hrt.Renderer(0, 0)
+        try:
+            one.load_scene(scene)
+            one.set_frame(w, h, salt, linear=True)
+            one.render(spp)
+            assert np.array_equal(total.cpu().numpy().view(np.uint32), one.color.cpu().numpy().view(np.uint32))
+            assert rays == one.stats().rays
+        finally:
+            one.close()
+        ref = oracle.OracleScene(scene).render(w, h, oracle.rng_init(w, h, salt), spp)
+        lin = total_lin.cpu().numpy()
+        lin[..., 3] = 1.0                                   # (each rank writes alpha 1 in its own rows only)
+        assert np.array_equal(lin.view(np.uint32), ref["linear"].view(np.uint32)) and rays == ref["rays"]
+        for k, r in enumerate(ranks):                      # a rank's rows outside its stripes stayed zero
+            others = [y for y in range(h) if (y // 8) % 2 != k]
+            assert not r.color.cpu().numpy()[others].any()
+    finally:
+        for r in ranks:
+            r.close()
 
 
 def test_tile_then_empty_tile_then_same_tile(hrt, renderer):

@@ -94,6 +94,27 @@ def test_host_bvh8_build_and_cpu_walk(hrt, oracle, n):
     assert not blob.nodes
 
 
+def test_oracle_renders_the_same_image_through_the_products_bvh8(hrt, oracle):
+    """bench.py's cpu_baseline walks the product's BVH8 bytes ("same BVH bytes as the GPU run"): an oracle scene
+    with the product's tree attached renders the very image it renders through its own BVH2, rays counted alike -- the closest hit is
+    canonical -- and reports the product tree's node visits."""
+    scene = hrt.scenes.random_soup(3000, 0.15, 5, 96, 64, 2)
+    lib, blob = _build(hrt, scene["instances"][0]["vertices"])
+    nodes = np.ctypeslib.as_array(C.cast(blob.nodes, C.POINTER(C.c_uint8)), shape=(blob.n_nodes * 80,)).copy()
+    prims = np.ctypeslib.as_array(C.cast(blob.triangles, C.POINTER(C.c_uint8)), shape=(blob.n_triangles * 48,)).copy()
+    lib.hrt_host_free(C.byref(blob))
+    osc = oracle.OracleScene(scene)
+    s1, s2 = oracle.rng_init(96, 64, 3), oracle.rng_init(96, 64, 3)
+    a = osc.render(96, 64, s1, 2)
+    osc.attach_bvh8(nodes, prims)
+    b = osc.render(96, 64, s2, 2)
+    assert np.array_equal(a["linear"].view(np.uint32), b["linear"].view(np.uint32)) and a["rays"] == b["rays"] and np.array_equal(s1, s2)
+    assert 0 < b["node_visits"] < a["node_visits"]           # an 8-wide SAH tree against a median-split BVH2
+    osc.attach_bvh8(None, None)
+    s3 = oracle.rng_init(96, 64, 3)
+    assert osc.render(96, 64, s3, 2)["node_visits"] == a["node_visits"]
+
+
 def test_host_bvh8_degenerate_inputs(hrt, oracle):
     """Duplicates, zero-area triangles, identical centroids, huge coordinate range."""
     rng = np.random.default_rng(3)
