@@ -29,10 +29,6 @@ $(LIBDIR)/fused_queue.o: $(CSRC)/fused_queue.hip $(CSRC)/device_types.h $(CSRC)/
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/paths.o: $(CSRC)/paths.hip $(CSRC)/device_types.h $(CSRC)/trav_common.h
-	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-
 $(LIBDIR)/build.o: $(CSRC)/build.hip $(CSRC)/build.h $(CSRC)/build_dev.h $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -49,7 +45,7 @@ $(LIBDIR)/pose.o: $(CSRC)/pose.hip $(CSRC)/device_types.h $(CSRC)/cr_trig.h $(CS
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-API_DEPS := $(CSRC)/build.h $(CSRC)/hrt_internal.hpp $(CSRC)/device_types.h $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.h include/hrt.h include/hrt_params.h
+API_DEPS := $(CSRC)/knobs.def $(CSRC)/build.h $(CSRC)/hrt_internal.hpp $(CSRC)/device_types.h $(CSRC)/bvh8.h $(CSRC)/bvh8_geom.h include/hrt.h include/hrt_params.h
 
 $(LIBDIR)/hrt_accel.o: $(CSRC)/hrt_accel.cpp $(API_DEPS)
 	@mkdir -p $(LIBDIR)
@@ -67,7 +63,7 @@ $(LIBDIR)/bvh8_host_api.o: $(CSRC)/bvh8_host_api.cpp $(CSRC)/bvh8.h include/hrt.
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
-$(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/fused_queue.o $(LIBDIR)/paths.o $(LIBDIR)/build.o $(LIBDIR)/build_split.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o $(LIBDIR)/bvh8_host_api.o
+$(LIBDIR)/libhrt.so: $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/fused_queue.o $(LIBDIR)/build.o $(LIBDIR)/build_split.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o $(LIBDIR)/bvh8_host_api.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -pthread
 	@cat $(sort $(wildcard $(CSRC)/*.hip $(CSRC)/*.h $(CSRC)/*.hpp $(CSRC)/*.cpp include/*.h)) | sha256sum | cut -c1-16 > $(LIBDIR)/BUILD_ID
 
@@ -108,20 +104,10 @@ clean:
 
 # instrumented build for tools/lane_stats.py: lane-utilisation counters compiled into the path kernels
 stats: $(LIBDIR)/libhrt_stats.so
-$(LIBDIR)/libhrt_stats.so: $(LIBDIR)/fused_queue.o $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/paths.hip $(CSRC)/trav_common.h $(CSRC)/trav_lean.h $(LIBDIR)/libhrt.so
+$(LIBDIR)/libhrt_stats.so: $(LIBDIR)/fused_queue.o $(CSRC)/kernels.hip $(CSRC)/fused.hip $(CSRC)/trav_common.h $(CSRC)/trav_lean.h $(LIBDIR)/libhrt.so
 	$(HIPCC) $(HIPFLAGS) -DHRT_LANE_STATS -c $(CSRC)/kernels.hip -o $(LIBDIR)/kernels_stats.o
 	$(HIPCC) $(HIPFLAGS) -DHRT_LANE_STATS -c $(CSRC)/fused.hip -o $(LIBDIR)/fused_stats.o
-	$(HIPCC) $(HIPFLAGS) -DHRT_LANE_STATS -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_stats.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LIBDIR)/kernels_stats.o $(LIBDIR)/fused_stats.o $(LIBDIR)/fused_queue.o $(LIBDIR)/paths_stats.o $(LIBDIR)/build.o $(LIBDIR)/build_split.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o $(LIBDIR)/bvh8_host_api.o -pthread
-
-# bound-finding experiments on k_paths (tools only, never shipped): twice the slab arithmetic / twice the node loads
-exp: $(LIBDIR)/libhrt.so
-	$(HIPCC) $(HIPFLAGS) -DHRT_EXP_VALU2 -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_valu2.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_valu2.so $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/fused_queue.o $(LIBDIR)/paths_valu2.o $(LIBDIR)/build.o $(LIBDIR)/build_split.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o $(LIBDIR)/bvh8_host_api.o -pthread
-	$(HIPCC) $(HIPFLAGS) -DHRT_EXP_LOAD2 -DHRT_EXP_LOAD2_SAME -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_load2s.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_load2s.so $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/fused_queue.o $(LIBDIR)/paths_load2s.o $(LIBDIR)/build.o $(LIBDIR)/build_split.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o $(LIBDIR)/bvh8_host_api.o -pthread
-	$(HIPCC) $(HIPFLAGS) -DHRT_EXP_LOAD2 -c $(CSRC)/paths.hip -o $(LIBDIR)/paths_load2.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(LIBDIR)/libhrt_load2.so $(LIBDIR)/kernels.o $(LIBDIR)/fused.o $(LIBDIR)/fused_queue.o $(LIBDIR)/paths_load2.o $(LIBDIR)/build.o $(LIBDIR)/build_split.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o $(LIBDIR)/bvh8_host_api.o -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(LIBDIR)/kernels_stats.o $(LIBDIR)/fused_stats.o $(LIBDIR)/fused_queue.o $(LIBDIR)/build.o $(LIBDIR)/build_split.o $(LIBDIR)/refit.o $(LIBDIR)/pose.o $(LIBDIR)/hrt_api.o $(LIBDIR)/hrt_accel.o $(LIBDIR)/bvh8_build.o $(LIBDIR)/bvh8_host_api.o -pthread
 
 # ---- sanitizer build (CPU only; GPU AddressSanitizer is not available and is never attempted): the host-side code that takes
 # untrusted files or builds trees on the host -- the format readers, the host BVH8 builder, the test oracle -- compiled with

@@ -344,7 +344,7 @@ def main():
             b_closest = NODE_BYTES * nodes_per_ray + PRIM_BYTES * prims_per_ray
             b_any = NODE_BYTES * any_nodes + PRIM_BYTES * any_prims
             which = os.environ.get("HRT_FUSED", "1")
-            kernel_name = {"2": "k_traverse<FUSED> (round 1's persistent path kernel)", "3": "k_paths (slot pipeline)"}.get(
+            kernel_name = {"2": "k_traverse<FUSED> (round 1's persistent path kernel)"}.get(
                 which, "k_fused (persistent path kernel: generate + traverse + shade + accumulate)")
         else:
             # wavefront mode: every traverse launch of the timed region (closest-hit rays and the depth-5 any-hit rays)

@@ -303,19 +303,15 @@ void build_bvh8(const std::vector<BuildPrim> &prims, Bvh8 &out, int threads, flo
         scene_box.grow(prims[i].lo, prims[i].hi);
     }
     // spatial splits: the caller's choice (hrt_tlas_build under HRT_CTX_FAST_TRACE), HRT_SBVH = 0 / 1 overrides; at most
-    // HRT_SBVH_BUDGET x n extra references (default 2.0; C4 uses 0.47), tried where the object split's children overlap by more than
+    // HRT_SBVH_BUDGET x n extra references (default 1.0, the device builder's; C4 uses 0.47), tried where the object split's children overlap by more than
     // HRT_SBVH_ALPHA of the scene's area (default 1e-5, the paper's)
     B.spatial = spatial_splits && max_leaf_prims == kMaxLeafPrims;
     if (const char *e = std::getenv("HRT_SBVH")) B.spatial = std::atoi(e) != 0 && max_leaf_prims == kMaxLeafPrims;
-    double budget_frac = 2.0;
+    double budget_frac = 1.0;
     if (const char *e = std::getenv("HRT_SBVH_BUDGET")) budget_frac = std::max(0.0, std::atof(e));
     if (const char *e = std::getenv("HRT_SBVH_ALPHA")) B.alpha = (float)std::atof(e);
-    if (const char *e = std::getenv("HRT_SBVH_FAST_BINNING")) B.fast_binning = std::atoi(e) != 0;
     if (const char *e = std::getenv("HRT_SBVH_BIAS")) B.spatial_bias = (float)std::atof(e);
-    if (const char *e = std::getenv("HRT_SBVH_MIN_REFS")) B.spatial_min_refs = (uint32_t)std::strtoul(e, nullptr, 10);
-    if (const char *e = std::getenv("HRT_SBVH_MAX_REFS")) B.spatial_max_refs = (uint32_t)std::strtoul(e, nullptr, 10);
     const int64_t extra = B.spatial ? (int64_t)std::min<double>(budget_frac * (double)n, 3.0e9 - 2.0 * (double)n) : 0;
-    if (const char *e = std::getenv("HRT_BVH_BINS")) B.n_bins = std::min(std::max(std::atoi(e), 2), 64);
     B.root_area = scene_box.area();
     B.nodes.resize(2 * ((size_t)n + (size_t)std::max<int64_t>(extra, 0)) + 2);
     B.n_nodes = 1;

@@ -55,24 +55,7 @@ struct TraverseSeg {
     uint64_t *count_nodes, *count_prims;   // COUNT builds
 };
 
-// Slot pipeline (k_paths): the state of one pixel in flight.  A wave keeps kPipeSlots pixels going at once -- 64 of them
-// have their current ray in a lane, the others wait in the wave's LDS queues for a free lane or for the next shading batch --
-// so a lane carries traversal state only.  What a pixel has to remember from bounce to bounce lives here, in global memory
-// (a wave's slots are 6 KB, contiguous, L2 resident), touched once per bounce by the shading batch; the ray itself and
-// its hit record travel through LDS.
-constexpr int kMaxPipeSlots = 128;      // stride of a workgroup's slots in the slot buffer (k_paths runs with 80, 96, 112 or 128 of them)
-struct alignas(16) PathSlot {
-    uint32_t rng[6];               // XORWOW d, v0..v4 (the live words of the pixel's curandState)
-    uint32_t packed;               // samples finished (bits 0-15) | depth of the ray in flight (16-19) | 1 << 20 until the first sample is stored
-    uint32_t px_local;             // tile-local pixel index (index into the running sums)
-    uint32_t chain[4];             // instance hit at each bounce of the current path (albedo product on the way back, Shader.cu:236-238)
-    uint32_t px_tid;               // global pixel index y*W+x = RNG stream (Shader.cu:97)
-    uint32_t t0;                   // probe launches: clock at the pixel's start
-    uint32_t pad[2];
-};
-static_assert(sizeof(PathSlot) == 64, "four 16-byte pieces");
-
-// fused path modes (k_paths, k_traverse<..., FUSED>): what generate / shade / accumulate need, in one launch
+// fused path modes (k_fused, k_traverse<..., FUSED>): what generate / shade / accumulate need, in one launch
 struct PathArgs {
     const uint32_t *rows; uint32_t first_pixel, n_tile_pixels, width, height;
     uint32_t spp;                  // samples taken by THIS launch
@@ -86,9 +69,6 @@ struct PathArgs {
     uint64_t *rays_closest, *rays_any;
     const RayRec *trace_rays;      // fused kernel as hrt_trace_rays: the "pixels" are these rays, traced once; results below (else NULL)
     float4 *trace_tuvp; uint32_t *trace_inst; uint32_t trace_any;
-    PathSlot *slots;               // k_paths: kMaxPipeSlots per workgroup
-    int shade_threshold;           // k_paths: with the ray queue empty, a shading batch starts once this many lanes are idle
-    int low_water, min_batch;      // k_paths: ... or earlier: the ray queue is down to low_water rays beyond what the idle lanes take and min_batch hits wait
 };
 
 struct TraverseArgs {
@@ -216,8 +196,6 @@ void launch_debug_trig(int which, const float *a, const float *b, uint32_t first
 void launch_rng_init(RngState *states, uint32_t n, uint64_t salt, const uint32_t *d_jump, hipStream_t s);
 void launch_generate(const GenerateArgs &a, hipStream_t s);
 void launch_traverse(const TraverseArgs &a, bool count, bool has_spheres, bool dma, uint32_t grid_blocks, hipStream_t s);
-void launch_paths(const TraverseArgs &a, bool has_spheres, int slots, uint32_t grid_blocks, hipStream_t s);
-uint32_t paths_blocks_that_fit(int slots);
 void launch_paths_v1(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s);   // round 1's fused kernel k_traverse<.., FUSED> (HRT_FUSED=2)
 constexpr int kFusedBlocksPerCu = 16;  // k_fused is compiled for 4 waves per SIMD (125 VGPRs, nothing spilled): more workgroups per CU would only queue
 constexpr int kFusedMaxDepth = 12;     // deepest tree (levels below the root) k_fused takes: its per-lane node stack in LDS (trav_lean.h: kNodeStackLds)

@@ -536,7 +536,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         in.d_inst_xf = t.d_inst_xf; in.d_inst_identity = t.d_inst_identity;
         in.max_leaf_prims = 1; in.instance_leaves = true; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius; in.quant_guard = ctx->quant_guard;
         in.split.enabled = ctx->build_topdown != 0; in.split.budget_frac = 0.0f; in.split.alpha = ctx->split_alpha; in.split.bias = ctx->split_bias; in.split.cut_bias = ctx->split_cut_bias;
-        in.split.cell_refs = (uint32_t)ctx->split_cell_refs; in.split.pad = ra.pad; in.split.verbose = std::getenv("HRT_BUILD_VERBOSE") != nullptr;
+        in.split.cell_refs = (uint32_t)ctx->split_cell_refs; in.split.pad = ra.pad; in.split.verbose = ctx->build_verbose;
         // worst case: a transform node per instance and fewer box nodes than instances
         const size_t max_nodes = 2 * (size_t)n2 + 2;
         const size_t stage_nodes = ((size_t)t.node_stride * max_nodes + 255u) & ~(size_t)255u, stage_ref = (sizeof(float) * 2 * max_nodes + 255u) & ~(size_t)255u;
@@ -629,7 +629,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         launch_refit_phases(ra, t.phases, s);
         HIP_TRY(ctx, hipGetLastError());
         HIP_TRY(ctx, hipStreamSynchronize(s));
-        if (std::getenv("HRT_BUILD_VERBOSE"))
+        if (ctx->build_verbose)
             std::fprintf(stderr, "[hrt] two-level build: %u instances over %u BLASes -> %u top nodes (depth %u, %u split levels), %u BLAS nodes (depth <= %u), %u records (flattened: %u)\n",
                          n2, nu, n_top, r.max_depth, r.split_levels, node_off[nu], blas_depth, n_rec, first[n]);
         t.bvh = Bvh8();
@@ -652,7 +652,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         // the top-down phase always (object splits: what gives the tree its shape above the cells PLOC builds -- on the reference's kind of
         // scene, separate bodies over a huge ground sphere, PLOC alone costs seven times the node visits); spatial splits under HRT_CTX_FAST_TRACE
         in.split.enabled = device_split || ctx->build_topdown != 0; in.split.budget_frac = device_split ? ctx->split_budget : 0.0f; in.split.alpha = ctx->split_alpha; in.split.bias = ctx->split_bias; in.split.cut_bias = ctx->split_cut_bias;
-        in.split.cell_refs = (uint32_t)ctx->split_cell_refs; in.split.pad = ra.pad; in.split.verbose = std::getenv("HRT_BUILD_VERBOSE") != nullptr;
+        in.split.cell_refs = (uint32_t)ctx->split_cell_refs; in.split.pad = ra.pad; in.split.verbose = ctx->build_verbose;
         // worst-case node output (one node and two reference floats per leaf: primitive, or reference of a spatial split) at the front of the
         // working memory; a split build's records and their clip boxes too (their number is known afterwards)
         const size_t max_leaves = gpu_build_max_refs(in.n_prims, &in.split);
@@ -711,7 +711,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
             HIP_TRY(ctx, hipGetLastError());
             if (device_split && r.split_levels) HIP_TRY(ctx, hipStreamSynchronize(s));      // (the clip boxes live in the working memory)
             ra.clip = nullptr;
-            if (std::getenv("HRT_BUILD_VERBOSE"))
+            if (ctx->build_verbose)
                 std::fprintf(stderr, "[hrt] device build: %u primitives -> %u records, %u nodes, depth %u, %u PLOC rounds (radius %d), %u split levels, %u cells\n",
                              r.n_prims, r.n_records, r.n_nodes, r.max_depth, r.ploc_rounds, ctx->ploc_radius, r.split_levels, r.n_cells);
             const uint32_t dropped = first[n] - r.n_prims;      // non-finite primitives (counted against the triangles unless there are none)
@@ -1047,7 +1047,7 @@ int hrt_tlas_update(HrtContext *ctx, HrtTraversable tlas, const HrtInstance *d_i
         ctx->tlas_refit_ratio = (double)*t->h_area;
         if (ctx->tlas_refit_ratio <= (double)ctx->refit_rebuild_ratio) return HRT_OK;
     }
-    if (std::getenv("HRT_BUILD_VERBOSE"))
+    if (ctx->build_verbose)
         std::fprintf(stderr, "[hrt] update %llu of this tree rebuilds: %s (area ratio %.3f, %llu refits since the build)\n", (unsigned long long)(t->refits + t->rebuilds),
                      force_rebuild ? "verdict of the previous asynchronous refit" : moved_far ? "most instances are further from where the tree was built than they are wide" : "handles / visibility changed or the refit just done degraded the tree", ctx->tlas_refit_ratio.load(),
                      (unsigned long long)t->refits_since_build);

@@ -138,50 +138,12 @@ int hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx) {
         hipMalloc((void **)&ctx->d_stats, sizeof(DeviceStats)) != hipSuccess ||
         hipMemset(ctx->d_stats, 0, sizeof(DeviceStats)) != hipSuccess)
         return fail(nullptr, HRT_ERR_HIP, "context allocation failed: %s", hipGetErrorString(hipGetLastError()));
-    if (const char *e = std::getenv("HRT_TRAVERSE_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) { ctx->traverse_blocks_per_cu = v; ctx->fused_blocks_per_cu = v; ctx->traverse_blocks_auto = false; } }
-    if (const char *e = std::getenv("HRT_FETCH_CHUNK")) { const int v = std::atoi(e); if (v >= 8 && v <= 4096) { ctx->fetch_chunk = v; ctx->fused_fetch_chunk = v; } }
-    if (const char *e = std::getenv("HRT_NODE_STRIDE")) { const int v = std::atoi(e); if (v >= 80 && v <= 256 && v % 16 == 0) { ctx->node_stride = v; ctx->node_stride_auto = false; } }
-    if (const char *e = std::getenv("HRT_PRIM_STRIDE")) { const int v = std::atoi(e); if (v >= 48 && v <= 256 && v % 16 == 0) ctx->prim_stride = v; }
-    if (const char *e = std::getenv("HRT_FUSED")) ctx->fused = std::atoi(e);
-    if (const char *e = std::getenv("HRT_PATHS_BLOCKS_PER_CU")) { const int v = std::atoi(e); if (v >= 1 && v <= 20) ctx->paths_blocks_per_cu = v; }
-    if (const char *e = std::getenv("HRT_PATHS_SLOTS")) { const int v = std::atoi(e); if (v >= 65 && v <= 128) ctx->paths_slots = v; }
-    if (const char *e = std::getenv("HRT_PATHS_EXCHANGE")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->paths_exchange_threshold = v; }
-    if (const char *e = std::getenv("HRT_PATHS_LOW_WATER")) { const int v = std::atoi(e); if (v >= 0 && v <= 64) ctx->paths_low_water = v; }
-    if (const char *e = std::getenv("HRT_PATHS_MIN_BATCH")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->paths_min_batch = v; }
-    if (const char *e = std::getenv("HRT_PATHS_SHADE")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->paths_shade_threshold = v; }
-    if (const char *e = std::getenv("HRT_TLAS_INSTANCED")) ctx->tlas_instanced = std::atoi(e);
-    if (const char *e = std::getenv("HRT_TWO_LEVEL")) ctx->two_level = std::atoi(e);
-    if (const char *e = std::getenv("HRT_TWO_LEVEL_MIN_PRIMS")) { const unsigned long long v = std::strtoull(e, nullptr, 0); if (v >= 1) ctx->two_level_min_prims = v; }
-    if (const char *e = std::getenv("HRT_BUILD")) ctx->build_on_device = std::strcmp(e, "host") != 0;
-    if (const char *e = std::getenv("HRT_QUANT_GUARD")) { const double q = std::atof(e); if (q >= 0.0) ctx->quant_guard = (float)q; }
-    if (const char *e = std::getenv("HRT_BUILD_TOPDOWN")) ctx->build_topdown = std::atoi(e) != 0;
-    if (const char *e = std::getenv("HRT_FAST_TRACE_BUILD")) ctx->fast_trace_on_device = std::strcmp(e, "device") == 0;
-    if (const char *e = std::getenv("HRT_SBVH_BUDGET")) { const double v = std::atof(e); if (v >= 0.0 && v <= 8.0) ctx->split_budget = (float)v; }
-    if (const char *e = std::getenv("HRT_SBVH_ALPHA")) ctx->split_alpha = (float)std::atof(e);
-    if (const char *e = std::getenv("HRT_SBVH_BIAS")) ctx->split_bias = (float)std::atof(e);
-    if (const char *e = std::getenv("HRT_SBVH_CUT_BIAS")) { const double w = std::atof(e); if (w > 0.0) ctx->split_cut_bias = (float)w; }
-    if (const char *e = std::getenv("HRT_SBVH_CELL_REFS")) { const int v = std::atoi(e); if (v >= 2 && v <= (1 << 20)) ctx->split_cell_refs = v; }
-    if (const char *e = std::getenv("HRT_PLOC_RADIUS")) { const int v = std::atoi(e); if (v >= 1 && v <= 128) ctx->ploc_radius = v; }
-    if (const char *e = std::getenv("HRT_BVH_CPRIM")) ctx->build_c_prim = (float)std::atof(e);
-    if (const char *e = std::getenv("HRT_BVH_CNODE")) ctx->build_c_node = (float)std::atof(e);
-    if (const char *e = std::getenv("HRT_REFIT")) ctx->refit = std::atoi(e) != 0;
-    if (const char *e = std::getenv("HRT_REFIT_MOVED_FAR")) ctx->refit_moved_far_check = std::atoi(e) != 0;
-    if (const char *e = std::getenv("HRT_REFIT_REBUILD_RATIO")) { const double v = std::atof(e); if (v >= 1.0) ctx->refit_rebuild_ratio = (float)v; }
-    if (const char *e = std::getenv("HRT_FUSED_LPT")) { const int v = std::atoi(e); if (v >= 0 && v <= 64) ctx->fused_lpt = v; }
-    if (const char *e = std::getenv("HRT_FUSED_MAX_SPP")) { const int v = std::atoi(e); if (v >= 1) ctx->fused_max_spp = v; }
-    if (const char *e = std::getenv("HRT_FUSED_MAX_PIXELS")) { const int v = std::atoi(e); if (v > 0) ctx->fused_max_pixels = v; }
-    if (const char *e = std::getenv("HRT_LDS_GATHER")) ctx->lds_gather = std::atoi(e) != 0;
-    if (const char *e = std::getenv("HRT_TAIL_SPLIT")) ctx->tail_split = std::atoi(e) != 0;
-    if (const char *e = std::getenv("HRT_SUBSTREAM_MIN_PIXELS")) { const int v = std::atoi(e); if (v >= 1024) ctx->substream_min_pixels = v; }
-    if (const char *e = std::getenv("HRT_SUBSTREAMS")) { const int v = std::atoi(e); if (v >= 0 && v <= 8) ctx->substreams = v; }
-    if (const char *e = std::getenv("HRT_FUSED_MAX_DEPTH")) { const int v = std::atoi(e); if (v >= 0 && v <= kFusedMaxDepth) ctx->fused_max_depth = v; }
-    if (const char *e = std::getenv("HRT_WAVEFRONT_GRAPH")) ctx->wavefront_graph = std::atoi(e);
-    if (const char *e = std::getenv("HRT_WAVEFRONT_LEAN")) ctx->wavefront_lean = std::atoi(e) != 0;
-    if (const char *e = std::getenv("HRT_FUSED_MAX_BYTES")) { const unsigned long long v = std::strtoull(e, nullptr, 0); if (v >= 1 && v <= (1ull << 32)) ctx->fused_max_bytes = v; }
-    if (const char *e = std::getenv("HRT_TAIL_REGEN")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->fused_tail_regen = v; }
-    if (const char *e = std::getenv("HRT_LEAF_QUORUM")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) ctx->leaf_quorum = v; }
-    if (const char *e = std::getenv("HRT_POSTPONE_PCT")) { const int v = std::atoi(e); if (v >= 0 && v <= 100) { ctx->postpone_pct = v; ctx->fused_postpone_pct = v; } }
-    if (const char *e = std::getenv("HRT_REFILL_THRESHOLD")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) { ctx->refill_threshold = v; ctx->fused_refill_threshold = v; } }
+    // the tuning knobs: one list (knobs.def), parsed here, documented from there (tools/knob_table.py)
+#define HRT_KNOB(NAME, DEFAULT, DOC, ...) if (const char *e = std::getenv(NAME)) { __VA_ARGS__; }
+#define HRT_HOST_KNOB(NAME, DEFAULT, DOC)
+#include "knobs.def"
+#undef HRT_KNOB
+#undef HRT_HOST_KNOB
     *out_ctx = ctx.release();
     return HRT_OK;
 }
@@ -206,7 +168,7 @@ int hrt_ctx_destroy(HrtContext *ctx) {
         void *sp[] = {st.rays[0], st.rays[1], st.hit_tuvp, st.hit_inst, st.bin_items, st.chain, st.result, st.stages};
         for (void *p : sp) if (p) (void)hipFree(p);
     }
-    void *ptrs[] = {w.accum, w.slice_cost, w.slice_order, w.slots, w.rows, ctx->d_jump, ctx->d_stats, ctx->d_hitgroups, ctx->d_inst_program};
+    void *ptrs[] = {w.accum, w.slice_cost, w.slice_order, w.rows, ctx->d_jump, ctx->d_stats, ctx->d_hitgroups, ctx->d_inst_program};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (const ScratchArena &a : ctx->scratch_free) (void)hipFree(a.p);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -310,163 +272,123 @@ static int refresh_tables(HrtContext *ctx, uint64_t handle, Tlas *t, hipStream_t
     return HRT_OK;
 }
 
-int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const HrtRayGenParams *rg, uint32_t spp,
-                      const HrtTile *tile, void *stream) {
-    if (!ctx || !h_params || !rg) return HRT_ERR_INVALID;
-    hipStream_t s = (hipStream_t)stream;
-    (void)hipSetDevice(ctx->device);
-    if (spp == 0) return fail(ctx, HRT_ERR_INVALID, "spp must be >= 1");
-    if (rg->width == 0 || rg->height == 0 || (uint64_t)rg->width * rg->height > 0xffffffffull) return fail(ctx, HRT_ERR_INVALID, "bad frame size %ux%u", rg->width, rg->height);
-    if (!rg->colorBuffer) return fail(ctx, HRT_ERR_INVALID, "RayGenParams.colorBuffer is NULL");
-    if (!h_params->stateArray) return fail(ctx, HRT_ERR_INVALID, "GlobalParams.stateArray is NULL");
-    if (!ctx->have_records) return fail(ctx, HRT_ERR_STATE, "hrt_materials_set has not been called");
-    Tlas *t;
-    { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->tlas.find(h_params->handle);
-      if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "GlobalParams.handle 0x%llx is not a TLAS", (unsigned long long)h_params->handle);
-      t = it->second.get(); }
-    int rc = refresh_tables(ctx, h_params->handle, t, s);
-    if (rc != HRT_OK) return rc;
+// What both execution modes of a launch work from (hrt_render_launch has checked the arguments, found the tree, refreshed the material
+// tables and uploaded the tile's row list).
+struct LaunchFrame {
+    HrtContext *ctx; Tlas *t; const HrtGlobalParams *h_params; const HrtRayGenParams *rg;
+    uint32_t spp, n;               // samples per pixel, pixels of the tile
+    hipStream_t s;
+};
 
-    // ---- tile rows ----
-    HrtTile tl = tile ? *tile : HrtTile{0, rg->height, 1, 1, 0};
-    if (tl.stripe_rows == 0 || tl.stripe_period == 0 || tl.stripe_phase >= tl.stripe_period || tl.y_begin > tl.y_end || tl.y_end > rg->height)
-        return fail(ctx, HRT_ERR_INVALID, "bad tile");
-    const bool same_rows = ctx->rows_w == rg->width && ctx->rows_h == rg->height && std::memcmp(&ctx->rows_tile, &tl, sizeof tl) == 0 && ctx->ws.rows;
-    if (!same_rows) {
-        ctx->rows_w = ctx->rows_h = 0;       // the cached row list is being replaced: its key is valid again only once the upload below has succeeded
-        ctx->h_rows.clear();
-        for (uint32_t y = tl.y_begin; y < tl.y_end; ++y)
-            if ((y / tl.stripe_rows) % tl.stripe_period == tl.stripe_phase) ctx->h_rows.push_back(y);
-    }
-    const uint32_t n_rows = (uint32_t)ctx->h_rows.size();
-    const uint64_t n64 = (uint64_t)n_rows * rg->width;
-    if (n64 == 0) return HRT_OK;
-    const uint32_t n = (uint32_t)n64;
-    rc = ensure_workspace(ctx, n, rg->height);
-    if (rc != HRT_OK) return rc;
+// ---- fused path mode: ONE launch, every lane owns a pixel and runs all its samples (generate, traverse, shade, accumulate in place).
+//      No stage barriers.  The default (HRT_FUSED=1); HRT_FUSED=2 and trees outside k_fused's limits: round 1's path kernel. ----
+static int render_fused(const LaunchFrame &f) {
+    HrtContext *ctx = f.ctx; Tlas *t = f.t; const HrtGlobalParams *h_params = f.h_params; const HrtRayGenParams *rg = f.rg;
+    const uint32_t spp = f.spp, n = f.n; hipStream_t s = f.s;
     Workspace &w = ctx->ws;
-    if (!same_rows) {
-        HIP_TRY(ctx, hipMemcpyAsync(w.rows, ctx->h_rows.data(), sizeof(uint32_t) * n_rows, hipMemcpyHostToDevice, s));
+    StageCounters *stg = w.set[0].stages;
+    TraverseArgs ta{};
+    ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.node_stride = t->node_stride; ta.prim_stride = t->prim_stride;
+    ta.fetch_counter = stg[0].fetch;
+    ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
+    ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;
+    ta.refill_threshold = ctx->fused_refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.leaf_quorum = ctx->leaf_quorum; ta.tail_regen = ctx->fused_tail_regen; ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fused_fetch_chunk;
+    PathArgs &pa = ta.path;
+    pa.rows = w.rows; pa.first_pixel = 0; pa.n_tile_pixels = n; pa.width = rg->width; pa.height = rg->height; pa.spp = spp;
+    std::memcpy(pa.center, &rg->cameraCenter, 12); std::memcpy(pa.U, &rg->cameraU, 12);
+    std::memcpy(pa.V, &rg->cameraV, 12); std::memcpy(pa.W, &rg->cameraW, 12);
+    pa.bg[0] = ctx->miss.backgroundColor.x; pa.bg[1] = ctx->miss.backgroundColor.y; pa.bg[2] = ctx->miss.backgroundColor.z;
+    pa.states = reinterpret_cast<RngState *>(h_params->stateArray);
+    pa.hitgroups = ctx->d_hitgroups; pa.inst_program = ctx->d_inst_program; pa.accum = w.accum;
+    pa.rays_closest = &ctx->d_stats->rays_closest; pa.rays_any = &ctx->d_stats->rays_any;
+    // Waves per CU: a lane runs its pixel's samples one after the other, so a small tile (the multi-GPU split) ends
+    // with its slowest pixels; about 1.4 pixels per lane lets the lanes that drew cheap pixels take a second one
+    // while fewer waves share each SIMD (measured, profiles/r01_sweep_tile_waves.txt: 1/8 of the C4 frame takes
+    // 172 ms on 12 waves per CU, 210 ms on 16).  A full frame has many pixels per lane and keeps the maximum: 16 waves
+    // per CU = 4 per SIMD for k_fused (122 VGPRs, nothing spilled: 3120 Mrays/s on C4; compiled for 5 waves it spills 95
+    // registers around the shading: 2560), 20 = 5 per SIMD for round 1's kernel (96 VGPRs, a few spills: 2905).
+    // k_fused (fused.hip) keeps one sibling group per tree level in LDS and has no overflow path: deeper trees, and HRT_FUSED=2, take round 1's kernel
+    const bool lean = ctx->fused != 2 && fits_fused_kernel(ctx, *t);
+    if (t->two_level && !lean) return fail(ctx, HRT_ERR_STATE, "a two-level TLAS needs the default path kernel (HRT_FUSED=1)");
+    if (lean) ta.postpone_pct = ctx->fused_postpone_pct;
+    else if (ctx->fused != 2) ctx->fused_fallback_launches++;        // the tree does not fit k_fused
+    uint32_t blocks_per_cu = lean ? std::min<uint32_t>((uint32_t)ctx->fused_blocks_per_cu, (uint32_t)kFusedBlocksPerCu) : (uint32_t)ctx->fused_blocks_per_cu;
+    if (ctx->traverse_blocks_auto) {
+        const uint32_t fit = (uint32_t)((10ull * n + 14ull * 64ull * (uint64_t)ctx->n_cu - 1ull) / (14ull * 64ull * (uint64_t)ctx->n_cu));
+        blocks_per_cu = std::min(blocks_per_cu, std::max(fit, 4u));
+    }
+    const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * blocks_per_cu, (n + 63u) / 64u);
+    if (t->two_level) ta.tail_split = 0;        // (the pieces of a split ray would have to carry the instance they are in)
+    auto launch = [&]() {
+        if (lean && t->two_level) launch_fused_instanced(ta, t->has_spheres, grid, s);
+        else if (lean) launch_fused(ta, t->has_spheres, grid, s);
+        else launch_paths_v1(ta, t->has_spheres, grid, s);
+    };
+    // Longest-processing-time-first: a pixel's samples run one after the other in one lane, so a render ends with
+    // whatever pixels were started last.  For renders of many samples the first sample is a probe launch of its own
+    // that records how long each slice's pixels took over their sample; the slices are then handed out slowest first,
+    // and the render ends on pixels whose paths leave the scene at once.  (The image does not depend on the order.)
+    uint32_t done_spp = 0;
+    const uint32_t n_slices = (n + ta.fetch_chunk - 1u) / ta.fetch_chunk;
+    // Worth it when a lane gets only a few pixels (the tiles of the multi-GPU split: 1/4 of the C4 frame 238 -> 219 ms);
+    // a full frame has ~6 pixels per lane, a tail of a few percent, and keeps its single launch.
+    if (ctx->fused_lpt && spp >= 16u && n_slices >= 4096u && (uint64_t)n < 4ull * 64ull * (uint64_t)grid) {
+        if (n_slices > w.slice_capacity) {
+            for (uint32_t *p : {w.slice_cost, w.slice_order}) if (p) (void)hipFree(p);
+            w.slice_cost = w.slice_order = nullptr; w.slice_capacity = 0;
+            HIP_TRY(ctx, hipMalloc((void **)&w.slice_cost, sizeof(uint32_t) * n_slices));
+            HIP_TRY(ctx, hipMalloc((void **)&w.slice_order, sizeof(uint32_t) * n_slices));
+            w.slice_capacity = n_slices;
+        }
+        HIP_TRY(ctx, hipMemsetAsync(w.slice_cost, 0, sizeof(uint32_t) * n_slices, s));
+        HIP_TRY(ctx, hipMemsetAsync(stg, 0, sizeof(StageCounters), s));
+        const uint32_t probe_spp = (uint32_t)std::min<int>(std::max(ctx->fused_lpt, 1), (int)spp / 4);
+        pa.spp = probe_spp; pa.continue_sum = 0u; pa.slice_cost = w.slice_cost; pa.slice_order = nullptr;
+        { Timer tm(ctx, s, HRT_K_PATHS); launch(); }
+        ctx->fused_counters_clean = false;
+        ctx->h_slice_cost.resize(n_slices); ctx->h_slice_order.resize(n_slices);
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_slice_cost.data(), w.slice_cost, sizeof(uint32_t) * n_slices, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
-        ctx->rows_tile = tl; ctx->rows_w = rg->width; ctx->rows_h = rg->height;
+        for (uint32_t i = 0; i < n_slices; ++i) ctx->h_slice_order[i] = i;
+        std::stable_sort(ctx->h_slice_order.begin(), ctx->h_slice_order.end(),
+                         [&](uint32_t x, uint32_t y) { return ctx->h_slice_cost[x] > ctx->h_slice_cost[y]; });
+        HIP_TRY(ctx, hipMemcpyAsync(w.slice_order, ctx->h_slice_order.data(), sizeof(uint32_t) * n_slices, hipMemcpyHostToDevice, s));
+        pa.slice_cost = nullptr; pa.slice_order = w.slice_order;
+        done_spp = probe_spp;
     }
-
-    const bool count = (ctx->flags & HRT_CTX_COUNT) != 0;
-
-    // ---- fused path mode: ONE launch, every lane owns a pixel and runs all its samples (generate,
-    //      traverse, shade, accumulate in place).  No stage barriers.  The default (HRT_FUSED=1). ----
-    if (t->two_level && (count || ctx->fused != 1)) return fail(ctx, HRT_ERR_STATE, "a two-level TLAS is traced by the default path kernel only (not under HRT_CTX_COUNT / HRT_FUSED != 1)");
-    const bool use_fused = !count && (ctx->fused > 0 || (ctx->fused < 0 && n <= (uint32_t)ctx->fused_max_pixels));
-    if (use_fused) {
-        StageCounters *stg = w.set[0].stages;
-        TraverseArgs ta{};
-        ta.nodes = t->d_nodes; ta.prims = t->d_prims; ta.node_stride = t->node_stride; ta.prim_stride = t->prim_stride;
-        ta.fetch_counter = stg[0].fetch;
-        ta.inst_inv = t->d_inst_inv; ta.inst_identity = t->d_inst_identity;
-        ta.tmin = kFloatZero; ta.tmax = kFloatInfinity;
-        ta.refill_threshold = ctx->fused_refill_threshold; ta.postpone_pct = ctx->postpone_pct; ta.leaf_quorum = ctx->leaf_quorum; ta.tail_regen = ctx->fused_tail_regen; ta.tail_split = ctx->tail_split; ta.fetch_chunk = (uint32_t)ctx->fused_fetch_chunk;
-        PathArgs &pa = ta.path;
-        pa.rows = w.rows; pa.first_pixel = 0; pa.n_tile_pixels = n; pa.width = rg->width; pa.height = rg->height; pa.spp = spp;
-        std::memcpy(pa.center, &rg->cameraCenter, 12); std::memcpy(pa.U, &rg->cameraU, 12);
-        std::memcpy(pa.V, &rg->cameraV, 12); std::memcpy(pa.W, &rg->cameraW, 12);
-        pa.bg[0] = ctx->miss.backgroundColor.x; pa.bg[1] = ctx->miss.backgroundColor.y; pa.bg[2] = ctx->miss.backgroundColor.z;
-        pa.states = reinterpret_cast<RngState *>(h_params->stateArray);
-        pa.hitgroups = ctx->d_hitgroups; pa.inst_program = ctx->d_inst_program; pa.accum = w.accum;
-        pa.rays_closest = &ctx->d_stats->rays_closest; pa.rays_any = &ctx->d_stats->rays_any;
-        // Waves per CU: a lane runs its pixel's samples one after the other, so a small tile (the multi-GPU split) ends
-        // with its slowest pixels; about 1.4 pixels per lane lets the lanes that drew cheap pixels take a second one
-        // while fewer waves share each SIMD (measured, profiles/r01_sweep_tile_waves.txt: 1/8 of the C4 frame takes
-        // 172 ms on 12 waves per CU, 210 ms on 16).  A full frame has many pixels per lane and keeps the maximum: 16 waves
-        // per CU = 4 per SIMD for k_fused (122 VGPRs, nothing spilled: 3120 Mrays/s on C4; compiled for 5 waves it spills 95
-        // registers around the shading: 2560), 20 = 5 per SIMD for round 1's kernel (96 VGPRs, a few spills: 2905).
-        const bool v1 = ctx->fused != 3;            // 3: the slot pipeline k_paths (paths.hip); otherwise a fused kernel: k_fused (fused.hip), 2: round 1's (kernels.hip)
-        // k_fused keeps one sibling group per tree level in LDS and has no overflow path: deeper trees take round 1's kernel
-        if (t->two_level && (!v1 || ctx->fused == 2 || !fits_fused_kernel(ctx, *t)))
-            return fail(ctx, HRT_ERR_STATE, "a two-level TLAS needs the default path kernel (HRT_FUSED=1)");
-        const bool lean = v1 && ctx->fused != 2 && fits_fused_kernel(ctx, *t);
-        if (lean) ta.postpone_pct = ctx->fused_postpone_pct;
-        else if (v1 && ctx->fused != 2) ctx->fused_fallback_launches++;        // the tree does not fit k_fused
-        uint32_t blocks_per_cu = lean ? std::min<uint32_t>((uint32_t)ctx->fused_blocks_per_cu, (uint32_t)kFusedBlocksPerCu)
-                               : v1 ? (uint32_t)ctx->fused_blocks_per_cu : std::min<uint32_t>((uint32_t)ctx->paths_blocks_per_cu, paths_blocks_that_fit(ctx->paths_slots));
-        if (!v1) { ta.refill_threshold = ctx->paths_exchange_threshold; pa.shade_threshold = ctx->paths_shade_threshold; pa.low_water = ctx->paths_low_water; pa.min_batch = ctx->paths_min_batch; }
-        if (ctx->traverse_blocks_auto && v1) {
-            const uint32_t fit = (uint32_t)((10ull * n + 14ull * 64ull * (uint64_t)ctx->n_cu - 1ull) / (14ull * 64ull * (uint64_t)ctx->n_cu));
-            blocks_per_cu = std::min(blocks_per_cu, std::max(fit, 4u));
-        }
-        const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * blocks_per_cu, (n + 63u) / 64u);
-        if (!v1) {
-            const uint32_t need = grid * (uint32_t)kMaxPipeSlots;
-            if (need > w.slots_capacity) {
-                if (w.slots) (void)hipFree(w.slots);
-                w.slots = nullptr; w.slots_capacity = 0;
-                HIP_TRY(ctx, hipMalloc((void **)&w.slots, sizeof(PathSlot) * (size_t)need));
-                w.slots_capacity = need;
-            }
-            pa.slots = w.slots;
-        }
-        if (t->two_level) ta.tail_split = 0;        // (the pieces of a split ray would have to carry the instance they are in)
-        auto launch = [&]() {
-            if (lean && t->two_level) launch_fused_instanced(ta, t->has_spheres, grid, s);
-            else if (lean) launch_fused(ta, t->has_spheres, grid, s);
-            else if (v1) launch_paths_v1(ta, t->has_spheres, grid, s);
-            else launch_paths(ta, t->has_spheres, ctx->paths_slots, grid, s);
-        };
-        // Longest-processing-time-first: a pixel's samples run one after the other in one lane, so a render ends with
-        // whatever pixels were started last.  For renders of many samples the first sample is a probe launch of its own
-        // that records how long each slice's pixels took over their sample; the slices are then handed out slowest first,
-        // and the render ends on pixels whose paths leave the scene at once.  (The image does not depend on the order.)
-        uint32_t done_spp = 0;
-        const uint32_t n_slices = (n + ta.fetch_chunk - 1u) / ta.fetch_chunk;
-        // Worth it when a lane gets only a few pixels (the tiles of the multi-GPU split: 1/4 of the C4 frame 238 -> 219 ms);
-        // a full frame has ~6 pixels per lane, a tail of a few percent, and keeps its single launch.
-        if (ctx->fused_lpt && spp >= 16u && n_slices >= 4096u && (uint64_t)n < 4ull * 64ull * (uint64_t)grid) {
-            if (n_slices > w.slice_capacity) {
-                for (uint32_t *p : {w.slice_cost, w.slice_order}) if (p) (void)hipFree(p);
-                w.slice_cost = w.slice_order = nullptr; w.slice_capacity = 0;
-                HIP_TRY(ctx, hipMalloc((void **)&w.slice_cost, sizeof(uint32_t) * n_slices));
-                HIP_TRY(ctx, hipMalloc((void **)&w.slice_order, sizeof(uint32_t) * n_slices));
-                w.slice_capacity = n_slices;
-            }
-            HIP_TRY(ctx, hipMemsetAsync(w.slice_cost, 0, sizeof(uint32_t) * n_slices, s));
-            HIP_TRY(ctx, hipMemsetAsync(stg, 0, sizeof(StageCounters), s));
-            const uint32_t probe_spp = (uint32_t)std::min<int>(std::max(ctx->fused_lpt, 1), (int)spp / 4);
-            pa.spp = probe_spp; pa.continue_sum = 0u; pa.slice_cost = w.slice_cost; pa.slice_order = nullptr;
-            { Timer tm(ctx, s, HRT_K_PATHS); launch(); }
-            ctx->fused_counters_clean = false;
-            ctx->h_slice_cost.resize(n_slices); ctx->h_slice_order.resize(n_slices);
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_slice_cost.data(), w.slice_cost, sizeof(uint32_t) * n_slices, hipMemcpyDeviceToHost, s));
-            HIP_TRY(ctx, hipStreamSynchronize(s));
-            for (uint32_t i = 0; i < n_slices; ++i) ctx->h_slice_order[i] = i;
-            std::stable_sort(ctx->h_slice_order.begin(), ctx->h_slice_order.end(),
-                             [&](uint32_t x, uint32_t y) { return ctx->h_slice_cost[x] > ctx->h_slice_cost[y]; });
-            HIP_TRY(ctx, hipMemcpyAsync(w.slice_order, ctx->h_slice_order.data(), sizeof(uint32_t) * n_slices, hipMemcpyHostToDevice, s));
-            pa.slice_cost = nullptr; pa.slice_order = w.slice_order;
-            done_spp = probe_spp;
-        }
-        // very long renders are cut into launches of at most fused_max_spp samples (a launch should stay in the
-        // range of seconds); the RNG states and the running sums carry over, so the result is the same bits
-        while (done_spp < spp) {
-            const uint32_t now = std::min<uint32_t>(spp - done_spp, (uint32_t)ctx->fused_max_spp);
-            pa.spp = now; pa.continue_sum = done_spp > 0 ? 1u : 0u;
-            // (the slice counters: zeroed by the finalize kernel of the previous launch when that was a path-kernel launch too)
-            if (!ctx->fused_counters_clean) HIP_TRY(ctx, hipMemsetAsync(stg, 0, sizeof(StageCounters), s));
-            ctx->fused_counters_clean = false;
-            { Timer tm(ctx, s, HRT_K_PATHS); launch(); }
-            done_spp += now;
-        }
-        FinalizeArgs fa{};
-        fa.accum = w.accum; fa.rows = w.rows; fa.n_tile_pixels = n; fa.width = rg->width; fa.spp = spp;
-        fa.color = reinterpret_cast<float4 *>(rg->colorBuffer); fa.albedo = reinterpret_cast<float4 *>(rg->albedoBuffer);
-        fa.normal = reinterpret_cast<float4 *>(rg->normalBuffer); fa.linear = ctx->d_linear;
-        constexpr uint32_t kCounterWords = (uint32_t)(sizeof(StageCounters) / sizeof(uint32_t));
-        if (n >= kCounterWords) { fa.reset_counters = reinterpret_cast<uint32_t *>(stg); fa.n_reset = kCounterWords; }
-        { Timer tm(ctx, s, HRT_K_FINALIZE); launch_finalize(fa, s); }
-        ctx->fused_counters_clean = fa.reset_counters != nullptr;
-        HIP_TRY(ctx, hipGetLastError());
-        ctx->paths += (uint64_t)n * spp;
-        ctx->last_tlas = h_params->handle;
-        return HRT_OK;
+    // very long renders are cut into launches of at most fused_max_spp samples (a launch should stay in the
+    // range of seconds); the RNG states and the running sums carry over, so the result is the same bits
+    while (done_spp < spp) {
+        const uint32_t now = std::min<uint32_t>(spp - done_spp, (uint32_t)ctx->fused_max_spp);
+        pa.spp = now; pa.continue_sum = done_spp > 0 ? 1u : 0u;
+        // (the slice counters: zeroed by the finalize kernel of the previous launch when that was a path-kernel launch too)
+        if (!ctx->fused_counters_clean) HIP_TRY(ctx, hipMemsetAsync(stg, 0, sizeof(StageCounters), s));
+        ctx->fused_counters_clean = false;
+        { Timer tm(ctx, s, HRT_K_PATHS); launch(); }
+        done_spp += now;
     }
+    FinalizeArgs fa{};
+    fa.accum = w.accum; fa.rows = w.rows; fa.n_tile_pixels = n; fa.width = rg->width; fa.spp = spp;
+    fa.color = reinterpret_cast<float4 *>(rg->colorBuffer); fa.albedo = reinterpret_cast<float4 *>(rg->albedoBuffer);
+    fa.normal = reinterpret_cast<float4 *>(rg->normalBuffer); fa.linear = ctx->d_linear;
+    constexpr uint32_t kCounterWords = (uint32_t)(sizeof(StageCounters) / sizeof(uint32_t));
+    if (n >= kCounterWords) { fa.reset_counters = reinterpret_cast<uint32_t *>(stg); fa.n_reset = kCounterWords; }
+    { Timer tm(ctx, s, HRT_K_FINALIZE); launch_finalize(fa, s); }
+    ctx->fused_counters_clean = fa.reset_counters != nullptr;
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->paths += (uint64_t)n * spp;
+    ctx->last_tlas = h_params->handle;
+    return HRT_OK;
+}
+
+// ---- wavefront mode (HRT_FUSED=0, and always under HRT_CTX_COUNT): the north-star pipeline with separate kernels -- generate, traverse,
+//      bin by material, shade per program, accumulate -- every kernel reading its input count from device memory, so a launch is a
+//      fixed sequence of enqueues with no host synchronisation ----
+static int render_wavefront(const LaunchFrame &f, bool count) {
+    HrtContext *ctx = f.ctx; Tlas *t = f.t; const HrtGlobalParams *h_params = f.h_params; const HrtRayGenParams *rg = f.rg;
+    const uint32_t spp = f.spp, n = f.n; hipStream_t s = f.s;
+    Workspace &w = ctx->ws;
+    int rc = HRT_OK;
 
     ctx->fused_counters_clean = false;      // (the wavefront schedule below shares the counters' memory)
     // ---- sub-tiles: contiguous ranges of the tile's pixels, each on its own stream.  A traverse
@@ -660,6 +582,55 @@ int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const Hr
     ctx->last_tlas = h_params->handle;
     return HRT_OK;
 }
+
+int hrt_render_launch(HrtContext *ctx, const HrtGlobalParams *h_params, const HrtRayGenParams *rg, uint32_t spp,
+                      const HrtTile *tile, void *stream) {
+    if (!ctx || !h_params || !rg) return HRT_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipSetDevice(ctx->device);
+    if (spp == 0) return fail(ctx, HRT_ERR_INVALID, "spp must be >= 1");
+    if (rg->width == 0 || rg->height == 0 || (uint64_t)rg->width * rg->height > 0xffffffffull) return fail(ctx, HRT_ERR_INVALID, "bad frame size %ux%u", rg->width, rg->height);
+    if (!rg->colorBuffer) return fail(ctx, HRT_ERR_INVALID, "RayGenParams.colorBuffer is NULL");
+    if (!h_params->stateArray) return fail(ctx, HRT_ERR_INVALID, "GlobalParams.stateArray is NULL");
+    if (!ctx->have_records) return fail(ctx, HRT_ERR_STATE, "hrt_materials_set has not been called");
+    Tlas *t;
+    { std::lock_guard<std::mutex> lk(ctx->mu); auto it = ctx->tlas.find(h_params->handle);
+      if (it == ctx->tlas.end()) return fail(ctx, HRT_ERR_INVALID, "GlobalParams.handle 0x%llx is not a TLAS", (unsigned long long)h_params->handle);
+      t = it->second.get(); }
+    int rc = refresh_tables(ctx, h_params->handle, t, s);
+    if (rc != HRT_OK) return rc;
+
+    // ---- tile rows ----
+    HrtTile tl = tile ? *tile : HrtTile{0, rg->height, 1, 1, 0};
+    if (tl.stripe_rows == 0 || tl.stripe_period == 0 || tl.stripe_phase >= tl.stripe_period || tl.y_begin > tl.y_end || tl.y_end > rg->height)
+        return fail(ctx, HRT_ERR_INVALID, "bad tile");
+    const bool same_rows = ctx->rows_w == rg->width && ctx->rows_h == rg->height && std::memcmp(&ctx->rows_tile, &tl, sizeof tl) == 0 && ctx->ws.rows;
+    if (!same_rows) {
+        ctx->rows_w = ctx->rows_h = 0;       // the cached row list is being replaced: its key is valid again only once the upload below has succeeded
+        ctx->h_rows.clear();
+        for (uint32_t y = tl.y_begin; y < tl.y_end; ++y)
+            if ((y / tl.stripe_rows) % tl.stripe_period == tl.stripe_phase) ctx->h_rows.push_back(y);
+    }
+    const uint32_t n_rows = (uint32_t)ctx->h_rows.size();
+    const uint64_t n64 = (uint64_t)n_rows * rg->width;
+    if (n64 == 0) return HRT_OK;
+    const uint32_t n = (uint32_t)n64;
+    rc = ensure_workspace(ctx, n, rg->height);
+    if (rc != HRT_OK) return rc;
+    Workspace &w = ctx->ws;
+    if (!same_rows) {
+        HIP_TRY(ctx, hipMemcpyAsync(w.rows, ctx->h_rows.data(), sizeof(uint32_t) * n_rows, hipMemcpyHostToDevice, s));
+        HIP_TRY(ctx, hipStreamSynchronize(s));
+        ctx->rows_tile = tl; ctx->rows_w = rg->width; ctx->rows_h = rg->height;
+    }
+
+    const bool count = (ctx->flags & HRT_CTX_COUNT) != 0;
+    if (t->two_level && (count || ctx->fused != 1)) return fail(ctx, HRT_ERR_STATE, "a two-level TLAS is traced by the default path kernel only (not under HRT_CTX_COUNT / HRT_FUSED != 1)");
+    const LaunchFrame frame{ctx, t, h_params, rg, spp, n, s};
+    const bool use_fused = !count && (ctx->fused > 0 || (ctx->fused < 0 && n <= (uint32_t)ctx->fused_max_pixels));
+    return use_fused ? render_fused(frame) : render_wavefront(frame, count);
+}
+
 
 int hrt_sync(HrtContext *ctx, void *stream) {
     if (!ctx) return HRT_ERR_INVALID;

@@ -111,7 +111,6 @@ struct Workspace {
     float4 *accum = nullptr;
     uint32_t *rows = nullptr;
     uint32_t *slice_cost = nullptr, *slice_order = nullptr; uint32_t slice_capacity = 0;   // fused mode: cost-ordered slices
-    PathSlot *slots = nullptr; uint32_t slots_capacity = 0;                                // k_paths: kMaxPipeSlots per workgroup
 };
 
 struct TimedSpan { int kind; hipEvent_t a, b; };
@@ -177,12 +176,7 @@ struct HrtContext {
     bool node_stride_auto = true;               // no HRT_NODE_STRIDE given: trees beyond the Infinity Cache (> 3.5 M primitives) get 128-byte nodes -- a packed
                                                 // 80-byte node straddles two 128-byte lines two times in five, which only costs once the lines come from HBM
                                                 // (32 M triangles: +3.4 %, 8 M: +1 %, C4: -3 %; profiles/r03_large_scenes_node_stride.txt)
-    int fused = 1;                              // 1: fused persistent path kernel k_fused (default), 2: round 1's fused kernel, 3: slot-pipeline path kernel k_paths, 0: wavefront kernels, -1: fused only for small tiles
-    int paths_slots = 112;                      // k_paths: pixels in flight per wave (80 / 96 / 112 / 128): 64 in lanes, the rest queued in LDS
-    int paths_blocks_per_cu = 20;               // k_paths: one-wave workgroups per CU, at most what the LDS holds (20 / 18 / 16 / 15 for the slot counts above)
-    int paths_exchange_threshold = 8;           // k_paths: lanes that have finished before the wave stops to exchange rays with its queues
-    int paths_low_water = 8, paths_min_batch = 24;   // k_paths: shade ahead of starvation: ray queue down to this, at least that many hits waiting
-    int paths_shade_threshold = 8;              // k_paths: idle lanes the ray queue cannot serve before a (partial) shading batch starts
+    int fused = 1;                              // 1: fused persistent path kernel k_fused (default), 2: round 1's fused kernel, 0: wavefront kernels, -1: fused only for small tiles
     int fused_max_pixels = 700000;
     int fused_lpt = 2;                          // samples of the probe launch that orders the slices by cost for the rest of the render (0: off)
     int fused_max_spp = 512;                    // samples per fused launch
@@ -202,6 +196,7 @@ struct HrtContext {
     int ploc_radius = 2;                        // device build: nearest-neighbour search radius of the PLOC rounds (positions in Morton order); 2 traces fastest
                                                 // on the soup scenes (C4: 24.1 node visits per ray, 16: 28.3, 64: 36.6 -- profiles/r02_build_bench.txt)
     float build_c_node = 1.0f, build_c_prim = 0.45f;   // collapse costs (bvh8_build.cpp has the same defaults)
+    bool build_verbose = false;                 // HRT_BUILD_VERBOSE: builds and updates report on stderr
     int refit = 1;                              // hrt_tlas_update: 1 = device refit when only transforms changed, 0 = always rebuild
     int refit_moved_far_check = 1;              // the first update after a build rebuilds without refitting first when most instances have moved further than their size (HRT_REFIT_MOVED_FAR=0: always refit first)
     float refit_rebuild_ratio = 1.5f;           // rebuild when the refitted tree's weighted mean node area has grown by this factor

@@ -1,5 +1,5 @@
 // trav_common.h -- device code shared by the kernels of kernels.hip (wavefront pipeline, counting build, round-1 fused
-// kernel) and paths.hip (the slot pipeline k_paths): vector helpers, XORWOW, the shading arithmetic of shader/Shader.cu,
+// kernel), fused.hip and fused_queue.hip (the production path kernel and its queue form): vector helpers, XORWOW, the shading arithmetic of shader/Shader.cu,
 // the canonical primitive test and the load / wait primitives of the traversal step.  One definition each, hence one
 // rounding behaviour everywhere.  Device-only: include from .hip files compiled with -ffp-contract=off.
 #pragma once

@@ -1154,10 +1154,6 @@ MODES = {
     "wavefront-lds-dma-gather": {"HRT_FUSED": "0", "HRT_LDS_GATHER": "1"},
     "wavefront-substreams": {"HRT_FUSED": "0", "HRT_SUBSTREAMS": "3", "HRT_SUBSTREAM_MIN_PIXELS": "1024"},
     "wavefront-no-tail-split-small-slices": {"HRT_FUSED": "0", "HRT_TAIL_SPLIT": "0", "HRT_FETCH_CHUNK": "16", "HRT_REFILL_THRESHOLD": "4"},
-    "slot-pipeline": {"HRT_FUSED": "3"},
-    "slot-pipeline-80-slots-eager-exchange": {"HRT_FUSED": "3", "HRT_PATHS_SLOTS": "80", "HRT_PATHS_EXCHANGE": "1", "HRT_PATHS_SHADE": "1", "HRT_PATHS_LOW_WATER": "0", "HRT_PATHS_MIN_BATCH": "1"},
-    "slot-pipeline-128-slots-lazy-exchange-few-waves": {"HRT_FUSED": "3", "HRT_PATHS_SLOTS": "128", "HRT_PATHS_EXCHANGE": "32", "HRT_PATHS_SHADE": "48", "HRT_PATHS_BLOCKS_PER_CU": "2", "HRT_PATHS_MIN_BATCH": "64"},
-    "slot-pipeline-two-samples-per-launch": {"HRT_FUSED": "3", "HRT_FUSED_MAX_SPP": "2", "HRT_PATHS_SLOTS": "96"},
     "fused-two-samples-per-launch": {"HRT_FUSED_MAX_SPP": "2"},
     "fused-round-1-kernel": {"HRT_FUSED": "2"},
     "fused-no-tail-splitting": {"HRT_TAIL_SPLIT": "0"},

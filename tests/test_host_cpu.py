@@ -44,6 +44,26 @@ def test_no_cpu_fallback(hrt, gpu_available):
         hrt.Renderer(0)
 
 
+def test_tuning_knobs_come_from_one_list():
+    """csrc/knobs.def is THE list of environment knobs: hrt_ctx_create parses it, INTEGRATION.md's table is generated from it
+    (tools/knob_table.py --write), and no library source reads an HRT_* variable that is not in it."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import knob_table
+    names = {k[0] for k in knob_table.knobs() if k[0]}
+    assert len(names) >= 30 and len(names) == sum(1 for k in knob_table.knobs() if k[0]), "duplicate knob"
+    assert knob_table.current((ROOT / "INTEGRATION.md").read_text()) == knob_table.table(), "run tools/knob_table.py --write"
+    csrc = ROOT / "nvidia-optix-ray-tracer_amd" / "csrc"
+    read = set()
+    sites = 0
+    for f in list(csrc.glob("*.cpp")) + list(csrc.glob("*.hip")) + list(csrc.glob("*.h")) + list(csrc.glob("*.hpp")):
+        text = f.read_text()
+        sites += text.count("getenv(")
+        read |= set(re.findall(r'getenv\("(HRT_[A-Z0-9_]+)"\)', text))
+    assert read <= names, sorted(read - names)
+    assert sites <= 12, sites                        # (round 3: 59 getenv sites; the list is parsed by one of them)
+
+
 def test_sbt_header_packing(hrt):
     lib = hrt.load_library()
     rec = hrt.SbtRecord()
@@ -241,7 +261,7 @@ def test_tiles_partition_the_frame(hrt):
 def test_hand_issued_loads_are_not_touched_before_their_wait():
     """The traversal kernels issue their node / primitive loads from inline asm and retire them with hand-counted
     s_waitcnt: between the two the compiler must not read, copy or spill the destination registers (it does not know they
-    are in flight).  tools/audit_asm_loads.py compiles kernels.hip and paths.hip to assembly with the Makefile's own flags
+    are in flight).  tools/audit_asm_loads.py compiles kernels.hip, fused.hip and fused_queue.hip to assembly with the Makefile's own flags
     and checks every instantiation; any compiler or flag change that breaks the invariant fails here."""
     import subprocess
     import sys

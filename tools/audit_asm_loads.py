@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Audit of the hand-issued loads of the traversal kernels (k_traverse in kernels.hip, k_paths in paths.hip): between an asm
+"""Audit of the hand-issued loads of the traversal kernels (k_traverse in kernels.hip, k_fused in fused.hip, k_trace_queue in fused_queue.hip): between an asm
 block that issues global_load_dwordx4 into VGPRs and the asm wait that retires them, the compiler must not read, copy or spill
 those registers -- it does not know the loads are in flight, and the hardware does not interlock.  Compiles both files to
 assembly with the Makefile's own flags (`make -pn`), then prints, per kernel instantiation, the instructions that touch the
@@ -73,7 +73,7 @@ def audit(source, kernel_prefix, verbose=False):
 if __name__ == "__main__":
     v = "-v" in sys.argv
     total_groups = total_bad = 0
-    for src, prefix in (("nvidia-optix-ray-tracer_amd/csrc/kernels.hip", "_ZN3hrt10k_traverse"), ("nvidia-optix-ray-tracer_amd/csrc/fused.hip", "_ZN3hrt7k_fused"), ("nvidia-optix-ray-tracer_amd/csrc/fused_queue.hip", "_ZN3hrt13k_trace_queue"), ("nvidia-optix-ray-tracer_amd/csrc/paths.hip", "_ZN3hrt7k_paths")):
+    for src, prefix in (("nvidia-optix-ray-tracer_amd/csrc/kernels.hip", "_ZN3hrt10k_traverse"), ("nvidia-optix-ray-tracer_amd/csrc/fused.hip", "_ZN3hrt7k_fused"), ("nvidia-optix-ray-tracer_amd/csrc/fused_queue.hip", "_ZN3hrt13k_trace_queue")):
         g, b = audit(src, prefix, v)
         print(f"{src}: {g} groups of in-flight loads checked, {b} hazardous instructions")
         total_groups += g; total_bad += b

@@ -20,7 +20,3 @@ print("rays", s.rays, "wave iterations", it, "iters/ray-lane", it*64/s.rays)
 print("alive lanes/iter %.1f  node lanes/iter %.1f  prim lanes/iter %.1f" % (alive/it, node/it, prim/it))
 print("prim passes per iteration %.3f  lanes per prim pass %.1f  regens per iteration %.4f (every %.1f iterations)" % (ppass/it, prim/max(ppass,1), regen/it, it/max(regen,1)))
 print("node steps per ray %.2f  prim tests per ray %.2f" % (node/s.rays, prim/s.rays))
-if s.prim_tests_closest and s.node_visits - s.node_visits_closest >= 0:
-    # k_paths: regen = shading batches, and d[4] (nodes_any) = hits shaded in them
-    lanes = s.node_visits - s.node_visits_closest
-    print("k_paths: shading batches %d, hits per batch %.1f, iterations between batches %.1f" % (regen, lanes / max(regen, 1), it / max(regen, 1)))

@@ -55,7 +55,7 @@ def loops(source, prefix):
 
 if __name__ == "__main__":
     want = sys.argv[1:]
-    for src, prefix in (("nvidia-optix-ray-tracer_amd/csrc/kernels.hip", "_ZN3hrt10k_traverse"), ("nvidia-optix-ray-tracer_amd/csrc/fused.hip", "_ZN3hrt7k_fused"), ("nvidia-optix-ray-tracer_amd/csrc/paths.hip", "_ZN3hrt7k_paths")):
+    for src, prefix in (("nvidia-optix-ray-tracer_amd/csrc/kernels.hip", "_ZN3hrt10k_traverse"), ("nvidia-optix-ray-tracer_amd/csrc/fused.hip", "_ZN3hrt7k_fused")):
         for name, cs, ops in loops(src, prefix):
             if want and not any(w in name for w in want):
                 continue

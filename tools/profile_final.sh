@@ -27,7 +27,7 @@ tag, build = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(list); kernel_names = set()
 for path in glob.glob("gpurun_out/final/*/*/*counter_collection.csv"):
     for row in csv.DictReader(open(path)):
-        if "k_fused<" in row["Kernel_Name"] or "k_traverse<false, false, false, true>" in row["Kernel_Name"] or "k_paths<" in row["Kernel_Name"]:
+        if "k_fused<" in row["Kernel_Name"] or "k_traverse<false, false, false, true>" in row["Kernel_Name"]:
             kernel_names.add(row["Kernel_Name"])
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in acc.items()}

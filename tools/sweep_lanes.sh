@@ -27,11 +27,11 @@ import csv, glob, sys, collections
 acc = collections.defaultdict(float); n = 0; dur = []
 for path in glob.glob(sys.argv[1] + "/*/*counter_collection.csv"):
     for row in csv.DictReader(open(path)):
-        if any(k in row["Kernel_Name"] for k in ("k_fused<", "k_traverse<false, false, false, true>", "k_paths<")):
+        if any(k in row["Kernel_Name"] for k in ("k_fused<", "k_traverse<false, false, false, true>")):
             acc[row["Counter_Name"]] += float(row["Counter_Value"])
 for path in glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"):
     for row in csv.DictReader(open(path)):
-        if any(k in row["Kernel_Name"] for k in ("k_fused<", "k_traverse<false, false, false, true>", "k_paths<")):
+        if any(k in row["Kernel_Name"] for k in ("k_fused<", "k_traverse<false, false, false, true>")):
             dur.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
 la = acc["SQ_THREAD_CYCLES_VALU"] / (64 * acc["SQ_ACTIVE_INST_VALU"]) if acc["SQ_ACTIVE_INST_VALU"] else float("nan")
 print("%.2f ms | lanes-active %.3f | VALU %.3e SALU %.3e" % (sum(dur), la, acc["SQ_INSTS_VALU"], acc["SQ_INSTS_SALU"]))
