@@ -102,6 +102,7 @@ struct GpuBuildResult {
     uint32_t n_nodes = 0, n_prims = 0, max_depth = 0, ploc_rounds = 0;      // n_prims: valid primitives
     uint32_t n_records = 0;                              // primitive records emitted (= n_prims without spatial splits)
     uint32_t split_levels = 0, n_cells = 0;
+    bool fell_back = false;                              // the top-down phase gave up and PLOC alone built the tree
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     std::vector<uint32_t> level_begin;                   // nodes of level l: [level_begin[l], level_begin[l + 1])
 };

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
+#include <cstdio>
 #include <vector>
 #include "build_dev.h"
 
@@ -789,8 +790,21 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
         if (nv < std::max(in.split.cell_refs, 2u)) split = false;
     }
     if (split) {
+        const size_t arena_mark = arena.used;
         sp = gpu_split_phase(a, nv, in.split, arena, s);
-        if (sp.error != hipSuccess) { res.error = sp.error; res.where = sp.where; goto done; }
+        if (sp.error != hipSuccess) {
+            // The top-down phase is an improvement, not a necessity: when it gives up (its tables outgrown twice, its ~120 bytes per
+            // reference of temporaries not to be had, counts that do not add up) and the stream is healthy, PLOC alone builds the tree --
+            // inside an update of a running animation that is a slower frame, not a failed one.
+            if (hipStreamSynchronize(s) != hipSuccess) { res.error = sp.error; res.where = sp.where; goto done; }
+            (void)hipGetLastError();
+            if (in.split.verbose) std::fprintf(stderr, "[hrt] device build: the top-down phase gave up (%s: %s); PLOC alone\n", sp.where, hipGetErrorString(sp.error));
+            arena.used = arena_mark;
+            split = false; sp = SplitPhaseResult{};
+            res.fell_back = true;
+        }
+    }
+    if (split) {
         a.ref_lo = sp.ref_lo; a.ref_hi = sp.ref_hi; a.out_clip = in.out_clip;
         n_cells = sp.n_cells; res.split_levels = sp.levels; res.n_cells = sp.n_cells;
     }

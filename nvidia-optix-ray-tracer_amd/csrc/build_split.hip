@@ -57,7 +57,7 @@ constexpr int kObjCnt = kBinMinMax, kSpEnter = kObjCnt + 3 * kObjBins, kSpLeave 
 constexpr int kBinWords = kSpLeave + 3 * kSpBins;                                      // 1104 words per segment
 constexpr uint32_t kChunk = 512u, kMaxLevels = 64u, kWave = 64u;
 
-struct SplitCounters { uint32_t n_act, n_chunks, src_total, n_cells, n_top, n_out, n_segs, gave_up, n_big, retry, n_cut; float bulk_area, bulk_area_next; };
+struct SplitCounters { uint32_t n_act, n_chunks, src_total, n_cells, n_top, n_out, n_segs, gave_up, n_big, retry, n_cut; float bulk_area; uint32_t bulk_area_next; };      // bulk_area_next: float bits (a positive float orders like its bits), 0 = no candidate this level
 
 struct SplitArgs {
     GpuBuildArgs b;                                  // instance tables (the scatter clips triangles), primitive bounds, scene counters
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void k_split_first_level(SplitArgs a, uint32_t
     {
         float lo[3], hi[3];
         seg_bounds(sg.nb, lo, hi);
-        sc.bulk_area = sc.bulk_area_next = half_area3(lo, hi);
+        sc.bulk_area = half_area3(lo, hi); sc.bulk_area_next = 0u;
     }
     *a.counters = sc;
 }
@@ -212,8 +212,9 @@ __device__ __forceinline__ void select_split(const SplitArgs &a, SplitSeg &sg, c
     // outlier -- the reference's: a ground sphere of radius 1000 beside particles of size 0.1 -- has a root box that says nothing about
     // the geometry, and no overlap would ever pass.  The yardstick is therefore the box of the BULK: the segment that still holds nine
     // tenths of all references, followed down from the root (it takes effect a level later: plan_apply moves it, so that every segment
-    // of a level is judged by the same number whatever the order of the waves).
-    if (lane == 0u && (uint64_t)cnt * 10u >= (uint64_t)a.n_total * 9u) a.counters->bulk_area_next = half_area3(nlo, nhi);
+    // of a level is judged by the same number whatever the order of the waves).  After heavy spatial splitting two segments of a level
+    // can both hold nine tenths of the ORIGINAL count: the larger box wins, whichever wave comes last (atomicMax on the float's bits).
+    if (lane == 0u && (uint64_t)cnt * 10u >= (uint64_t)a.n_total * 9u) atomicMax(&a.counters->bulk_area_next, __float_as_uint(fmaxf(half_area3(nlo, nhi), 0.0f)));
     // ---- object split: candidate c = (axis, k): bins 0..k of the axis go left ----
     float o_cost = INFINITY, o_l[6], o_r[6]; uint32_t o_idx = 0xffffffffu, o_nl = 0u, o_nr = 0u;
     for (uint32_t c = lane; c < 3u * (uint32_t)(kObjBins - 1); c += kWave) {
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256) void k_split_plan_apply(SplitArgs a) {
     if (ai == 0u) {
         cn->n_act = 2u * tot_split; cn->n_chunks = (uint32_t)(t2 >> 32); cn->src_total = tot_dst; cn->n_big = (uint32_t)t2;
         cn->n_cells = cell_base + tot_cells; cn->n_top = top_base + tot_split; cn->n_out = out_base + tot_out;
-        cn->n_segs = seg_base + 2u * tot_split; cn->retry = 0u; cn->n_cut = 0u; cn->bulk_area = cn->bulk_area_next;
+        cn->n_segs = seg_base + 2u * tot_split; cn->retry = 0u; cn->n_cut = 0u; if (cn->bulk_area_next != 0u) cn->bulk_area = __uint_as_float(cn->bulk_area_next); cn->bulk_area_next = 0u;
     }
 }
 
@@ -582,7 +583,11 @@ SplitPhaseResult gpu_split_phase(const GpuBuildArgs &b, uint32_t n_valid, const 
     SplitCounters h{};
     h.n_segs = 1u;
     uint32_t seg_cap_now = seg_cap;
-    if (const char *e = std::getenv("HRT_SBVH_SEG_CAP")) { const unsigned long v = std::strtoul(e, nullptr, 10); if (v >= 1 && v < seg_cap) seg_cap_now = (uint32_t)v; }      // (tests: the tables-are-full path)
+    if (const char *e = std::getenv("HRT_SBVH_SEG_CAP")) {      // (tests: the tables-are-full path; 0: the phase gives up at once, the build falls back to PLOC alone)
+        const unsigned long v = std::strtoul(e, nullptr, 10);
+        if (v == 0) { res.error = hipErrorUnknown; res.where = "split phase: gave up on request (HRT_SBVH_SEG_CAP=0)"; return res; }
+        if (v < seg_cap) seg_cap_now = (uint32_t)v;
+    }
     a.seg_cap = seg_cap_now;
     res.top_level_begin.push_back(0u);
     for (;;) {

@@ -160,14 +160,25 @@ std::vector<uint8_t> orient_triangles(const std::vector<uint64_t> &tri_points, c
         const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
         return len > 0.0 ? n[0] / len : 0.0;
     };
-    // the triangles other than t that use both p and q
+    // the triangles other than t that use both p and q: from a table of the edges (unordered point pairs; reversing a triangle does not
+    // change them) sorted once -- scanning the triangles around p instead is quadratic in the valence, and a fan of 10^5 triangles
+    // around one merged point (untrusted files are parsed here) took minutes
+    struct Edge { uint64_t a, b; uint32_t t; };
+    std::vector<Edge> edges;
+    edges.reserve(3 * nt);
+    for (size_t t = 0; t < nt; ++t)
+        for (int j = 0; j < 3; ++j) {
+            const uint64_t p = tri_points[3 * t + j], q = tri_points[3 * t + (j + 1) % 3];
+            if (p != q) edges.push_back({std::min(p, q), std::max(p, q), (uint32_t)t});
+        }
+    std::sort(edges.begin(), edges.end(), [](const Edge &x, const Edge &y) { return x.a != y.a ? x.a < y.a : x.b != y.b ? x.b < y.b : x.t < y.t; });
     auto edge_neighbours = [&](uint32_t t, uint64_t p, uint64_t q, std::vector<uint32_t> &out) {
         out.clear();
         if (p == q) return;
-        for (uint32_t c : cells_of[p]) {
-            if (c == t) continue;
-            if (cur[3 * (size_t)c] == q || cur[3 * (size_t)c + 1] == q || cur[3 * (size_t)c + 2] == q) out.push_back(c);
-        }
+        const Edge key{std::min(p, q), std::max(p, q), 0u};
+        auto it = std::lower_bound(edges.begin(), edges.end(), key, [](const Edge &x, const Edge &y) { return x.a != y.a ? x.a < y.a : x.b < y.b; });
+        for (; it != edges.end() && it->a == key.a && it->b == key.b; ++it)
+            if (it->t != t && (out.empty() || out.back() != it->t)) out.push_back(it->t);      // (a triangle with a repeated edge counts once)
     };
     std::vector<uint32_t> order(np);
     for (size_t i = 0; i < np; ++i) order[i] = (uint32_t)i;

@@ -39,8 +39,13 @@ ScratchArena scratch_acquire(HrtContext *ctx, size_t bytes) {
     ScratchArena a;
     a.bytes = bytes + bytes / 4 + 4096;
     if (hipMalloc(&a.p, a.bytes) != hipSuccess) {
+        // out of memory: what the context keeps for later -- the trees' cached blocks AND the other arenas (up to eight, each too small
+        // for this request or it would have been taken above) -- goes back to the runtime first, then exactly what was asked for
         (void)hipGetLastError();
-        pool_drain(ctx);                                   // (the trees' cached blocks first, then exactly what was asked for)
+        pool_drain(ctx);
+        std::vector<ScratchArena> arenas;
+        { std::lock_guard<std::mutex> lk(ctx->scratch_mu); arenas.swap(ctx->scratch_free); }
+        for (const ScratchArena &x : arenas) (void)hipFree(x.p);
         a.bytes = bytes;
         if (hipMalloc(&a.p, a.bytes) != hipSuccess) { (void)hipGetLastError(); a = ScratchArena(); }
     }
@@ -259,7 +264,8 @@ int ensure_template(HrtContext *ctx, Blas &b, hipStream_t s, bool keep_device = 
     const size_t o_scratch = o_ref + up(sizeof(float) * 2 * (size_t)n);
     const ScratchArena arena = scratch_acquire(ctx, o_scratch + gpu_build_scratch_bytes(n));
     if (!arena.p) return fail(ctx, HRT_ERR_OOM, "device build of a BLAS template: no working memory");
-    struct Release { HrtContext *c; ScratchArena a; ~Release() { scratch_release(c, a); } } release{ctx, arena};
+    // (on an error path kernels may still be writing to the arena: another loader thread must not be handed it before they are done)
+    struct Release { HrtContext *c; ScratchArena a; hipStream_t st; ~Release() { (void)hipStreamSynchronize(st); scratch_release(c, a); } } release{ctx, arena, s};
     unsigned char *base = static_cast<unsigned char *>(arena.p);
     unsigned char *d_nodes = base + o_nodes, *d_prims = base + o_prims;
     HIP_TRY(ctx, hipMemcpyAsync(base + o_first, h_first, sizeof h_first, hipMemcpyHostToDevice, s)); HIP_TRY(ctx, hipMemcpyAsync(base + o_kind, &h_kind, 4, hipMemcpyHostToDevice, s));
@@ -357,8 +363,10 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         SplitParams probe; probe.enabled = true; probe.budget_frac = ctx->split_budget; probe.cell_refs = (uint32_t)ctx->split_cell_refs;
         const size_t leaves = gpu_build_max_refs(first[n], &probe);
         const size_t want = gpu_build_scratch_bytes(first[n], &probe) + leaves * (size_t)(128 + 8 + ctx->prim_stride + 24);
-        size_t free_b = 0, total_b = 0;
-        if (leaves > (1u << 30) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || want > free_b / 10 * 9) device_split = false;
+        size_t free_b = 0, total_b = 0, kept = 0;      // (what the context keeps for later counts as free: an allocation that fails gives it back first)
+        { std::lock_guard<std::mutex> lk(ctx->scratch_mu); for (const ScratchArena &x : ctx->scratch_free) kept += x.bytes; }
+        { std::lock_guard<std::mutex> lk(ctx->pool_mu); kept += ctx->pool_bytes; }
+        if (leaves > (1u << 30) || hipMemGetInfo(&free_b, &total_b) != hipSuccess || want > (free_b + kept) / 10 * 9) device_split = false;
     }
     if (instanced) {
         std::vector<const Bvh8 *> tmpl(n, nullptr);
@@ -665,7 +673,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
             arena = scratch_acquire(ctx, gpu_build_scratch_bytes(in.n_prims, nullptr) + stage_all);
         }
         if (!arena.p) return fail(ctx, HRT_ERR_OOM, "device build: no working memory (%zu bytes)", want);
-        struct Release { HrtContext *c; ScratchArena a; ~Release() { scratch_release(c, a); } } release{ctx, arena};
+        struct Release { HrtContext *c; ScratchArena a; hipStream_t st; ~Release() { (void)hipStreamSynchronize(st); scratch_release(c, a); } } release{ctx, arena, s};      // (see ensure_template)
         unsigned char *stage = static_cast<unsigned char *>(arena.p);
         in.out_nodes = stage; in.node_stride = t.node_stride; in.out_node_ref = reinterpret_cast<float *>(stage + stage_nodes);
         in.out_prims = device_split ? stage + stage_nodes + stage_ref : ra.prims; in.prim_stride = t.prim_stride;

@@ -62,6 +62,29 @@ def test_stl_reader_survives_garbage(io, tmp_path):
     assert ok >= 1                                      # (the empty prefix parses as an empty solid)
 
 
+def test_stl_reader_takes_a_fan_of_many_triangles_around_one_point(io, tmp_path):
+    """A cone apex / triangle fan: 60 000 triangles share one merged point.  The orientation pass (vtkPolyDataNormals' consistency walk,
+    scene_io.cpp orient_triangles) looks its edge neighbours up in a sorted edge table; scanning the triangles around the point instead
+    was quadratic in the valence and took minutes on such a file.  The fan comes back consistently oriented, in seconds."""
+    import time
+    n = 60000
+    ang = np.linspace(0.0, 2.0 * np.pi, n + 1)
+    rim = np.stack([np.cos(ang), np.sin(ang), np.zeros(n + 1)], axis=1)
+    lines = ["solid fan"]
+    for k in range(n):
+        a, b = (rim[k], rim[k + 1]) if k % 3 else (rim[k + 1], rim[k])          # every third facet wound the other way
+        lines += ["facet normal 0 0 0", "outer loop", "vertex 0 0 1", "vertex %.9g %.9g 0" % (a[0], a[1]), "vertex %.9g %.9g 0" % (b[0], b[1]), "endloop", "endfacet"]
+    lines.append("endsolid fan")
+    path = tmp_path / "fan.stl"
+    path.write_text("\n".join(lines))
+    t0 = time.perf_counter()
+    m = io.read_stl(str(path))
+    dt = time.perf_counter() - t0
+    assert len(m["vertices"]) == n and dt < 20.0, dt
+    nz = m["normals"][:, 0, 2]
+    assert (nz > 0).all() or (nz < 0).all()               # one consistent side, whatever the winding in the file
+
+
 def test_particle_vtk_reader_survives_garbage(io, tmp_path):
     rng = np.random.default_rng(2)
     src = (FILES / "particle" / "particle_000000000000000.vtk").read_bytes()

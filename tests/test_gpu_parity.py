@@ -1343,6 +1343,34 @@ def test_device_split_build_with_full_segment_tables(hrt, oracle, gpu_available,
         r.close()
 
 
+def test_device_build_falls_back_to_ploc_when_the_top_down_phase_gives_up(hrt, oracle, gpu_available, monkeypatch):
+    """The top-down phase runs in every default build above 4096 primitives, rebuilds inside hrt_tlas_update included.  When it gives
+    up (here: on request, HRT_SBVH_SEG_CAP=0; in the field: tables outgrown twice, no room for its temporaries) the build goes on with
+    PLOC alone instead of failing: the very tree HRT_BUILD_TOPDOWN=0 builds, same hits, same image -- also under HRT_CTX_FAST_TRACE."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    w, h, spp = 128, 80, 2
+    scene = hrt.scenes.random_soup(30000, 0.08, 12, w, h, spp)
+    trees = {}
+    for name, env, flags in (("ploc", {"HRT_BUILD_TOPDOWN": "0"}, 0), ("gave-up", {"HRT_SBVH_SEG_CAP": "0"}, 0), ("gave-up-fast-trace", {"HRT_SBVH_SEG_CAP": "0"}, hrt.CTX_FAST_TRACE)):
+        for k in ("HRT_BUILD_TOPDOWN", "HRT_SBVH_SEG_CAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = hrt.Renderer(0, flags)
+        try:
+            r.load_scene(scene)
+            _moved_scene_matches_oracle(hrt, oracle, r, scene, w, h, 6, spp)
+            trees[name] = _download_tree(hrt, r)
+            moved = scene["instances"][0]["transform"].copy()
+            r.update_instances([moved])                          # and an update refits such a tree (it has no split references)
+            assert r.stats().tlas_refits == 1
+        finally:
+            r.close()
+    assert np.array_equal(trees["ploc"][0], trees["gave-up"][0]) and np.array_equal(trees["ploc"][1], trees["gave-up"][1])
+    assert np.array_equal(trees["ploc"][0], trees["gave-up-fast-trace"][0])
+
+
 def test_device_split_build_is_deterministic_and_fast(hrt, gpu_available):
     """The device build with spatial splits takes its positions from prefix sums and its bounds from ordered-integer min / max: two
     builds of the same scene give the same tree (the same nodes and records, up to the order of the blocks they are stored in).  1 M triangles build in well under a second (measured: ~45 ms
