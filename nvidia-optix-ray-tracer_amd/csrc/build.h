@@ -27,6 +27,7 @@ struct GpuBuildArgs {
     const float *inst_xf; const uint32_t *inst_identity;
     uint32_t max_leaf_prims; float c_node, c_prim; int ploc_radius;
     float quant_guard;                // emission: a node whose children's stored (8-bit) boxes would have more than this times their true area keeps its two BVH2 children (0: off)
+    uint32_t width;                   // children per node at most (8; HRT_BVH_WIDTH: fewer, to measure what a narrower node would cost in visits)
     uint32_t instance_leaves;         // 1: the top level of a two-level tree -- every primitive is an instance (kPrimKindInstance) and is emitted as a
                                       // TRANSFORM NODE in its parent's child block (bvh8.h), not as a record
     BuildCounters *counters;
@@ -86,6 +87,7 @@ struct GpuBuildInput {
     const float *d_inst_xf; const uint32_t *d_inst_identity;
     uint32_t max_leaf_prims; float c_node, c_prim; int ploc_radius;
     float quant_guard = 1.25f;
+    uint32_t width = 8;                                  // children per node at most
     bool instance_leaves = false;                        // the top level of a two-level tree (GpuBuildArgs); max_leaf_prims must be 1
     unsigned char *out_nodes; uint32_t node_stride;      // room for n_prims nodes (worst case; instance_leaves: 2 * n_prims + 1)
     unsigned char *out_prims; uint32_t prim_stride;      // room for n_prims records

@@ -134,7 +134,7 @@ __device__ void cost_of_node(const GpuBuildArgs &a, uint32_t nd, bool leaf, Cost
         }
         dist[j] = best; bits |= (uint32_t)bk << (8 + 3 * (j - 2));
     }
-    const float c_internal = dist[8] + area * a.c_node;
+    const float c_internal = dist[a.width] + area * a.c_node;      // (a.width children at most: 8, or fewer as an experiment -- HRT_BVH_WIDTH)
     if (c_leaf <= c_internal) bits |= 1u;
     out.c[1] = fminf(c_leaf, c_internal);
     for (int i = 2; i <= 7; ++i) {
@@ -379,7 +379,7 @@ __device__ void collect_forest(const GpuBuildArgs &a, uint32_t root, Forest &out
     // Collector::distribute(root, 8) of bvh8_build.cpp, iteratively: (node, budget) pairs on a small stack; right pushed first
     uint32_t st_node[16]; int st_budget[16]; bool st_open[16]; int sp = 0;
     out.n = 0;
-    st_node[sp] = root; st_budget[sp] = 8; st_open[sp] = true; ++sp;
+    st_node[sp] = root; st_budget[sp] = (int)a.width; st_open[sp] = true; ++sp;
     while (sp > 0) {
         --sp;
         const uint32_t x = st_node[sp]; int i = st_budget[sp]; const bool open = st_open[sp];
@@ -770,6 +770,7 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     a.inst_xf = in.d_inst_xf; a.inst_identity = in.d_inst_identity;
     a.max_leaf_prims = in.max_leaf_prims; a.c_node = in.c_node; a.c_prim = in.c_prim; a.quant_guard = in.quant_guard;
     a.instance_leaves = in.instance_leaves ? 1u : 0u;
+    a.width = in.width >= 2u && in.width <= 8u ? in.width : 8u;
     a.ploc_radius = in.ploc_radius < 1 ? 1 : (in.ploc_radius > kPlocMaxRadius ? kPlocMaxRadius : in.ploc_radius);
     a.out_nodes = in.out_nodes; a.node_stride = in.node_stride; a.out_prims = in.out_prims; a.prim_stride = in.prim_stride; a.out_node_ref = in.out_node_ref;
 

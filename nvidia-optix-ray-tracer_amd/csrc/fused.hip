@@ -48,7 +48,11 @@ template <bool HAS_SPHERES, bool INSTANCED>
 #ifndef HRT_FUSED_WAVES_PER_SIMD
 #define HRT_FUSED_WAVES_PER_SIMD 4      // 128 VGPRs, a dozen kernel constants spilled; 5 waves (96 VGPRs, 95 spilled around the shading): 2560 against 3122 Mrays/s
 #endif
-__global__ __launch_bounds__(kTraverseBlock, HRT_FUSED_WAVES_PER_SIMD) void k_fused(TraverseArgs a) {
+#ifndef HRT_INST_WAVES_PER_SIMD
+#define HRT_INST_WAVES_PER_SIMD 3       // the INSTANCED instantiation: 160 VGPRs, nothing spilled, 12 waves per CU (at 4 waves per SIMD it spills 47 registers around
+                                        // the shading: 2 % slower on both particle clouds, profiles/r04_two_level_sweep.txt)
+#endif
+__global__ __launch_bounds__(kTraverseBlock, INSTANCED ? HRT_INST_WAVES_PER_SIMD : HRT_FUSED_WAVES_PER_SIMD) void k_fused(TraverseArgs a) {
     static_assert(kTraverseBlock == 64, "one wave per workgroup: the stacks are per wave");
     __shared__ uint2 s_nodes[kNodeStackLds][kTraverseBlock];     // sibling groups: one per tree level (hrt_api.cpp sends deeper trees to k_traverse)
     __shared__ uint2 s_leaves[kLeafStackLds][kTraverseBlock];    // leaf groups

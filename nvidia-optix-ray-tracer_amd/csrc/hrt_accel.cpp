@@ -276,7 +276,7 @@ int ensure_template(HrtContext *ctx, Blas &b, hipStream_t s, bool keep_device = 
     in.d_inst_first = reinterpret_cast<const uint32_t *>(base + o_first); in.d_inst_kind = reinterpret_cast<const uint32_t *>(base + o_kind);
     in.d_inst_src = reinterpret_cast<const void *const *>(base + o_src); in.d_inst_xf = reinterpret_cast<const float *>(base + o_xf);
     in.d_inst_identity = reinterpret_cast<const uint32_t *>(base + o_ident);
-    in.max_leaf_prims = kMaxLeafPrims; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius; in.quant_guard = ctx->quant_guard;
+    in.max_leaf_prims = kMaxLeafPrims; in.width = (uint32_t)ctx->build_width; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius; in.quant_guard = ctx->quant_guard;
     in.out_nodes = d_nodes; in.node_stride = sizeof(Bvh8Node); in.out_prims = d_prims; in.prim_stride = sizeof(PrimRecord); in.out_node_ref = reinterpret_cast<float *>(base + o_ref);
     in.scratch = base + o_scratch; in.scratch_bytes = arena.bytes - o_scratch;
     const GpuBuildResult r = gpu_build_bvh8(in, s);      // (synchronises the stream before it returns)
@@ -656,7 +656,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         GpuBuildInput in{};
         in.n_prims = first[n]; in.n_inst = n; in.d_inst_first = t.d_inst_first; in.d_inst_kind = t.d_inst_kind; in.d_inst_src = t.d_inst_src;
         in.d_inst_xf = t.d_inst_xf; in.d_inst_identity = t.d_inst_identity;
-        in.max_leaf_prims = kMaxLeafPrims; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius; in.quant_guard = ctx->quant_guard;
+        in.max_leaf_prims = kMaxLeafPrims; in.width = (uint32_t)ctx->build_width; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius; in.quant_guard = ctx->quant_guard;
         // the top-down phase always (object splits: what gives the tree its shape above the cells PLOC builds -- on the reference's kind of
         // scene, separate bodies over a huge ground sphere, PLOC alone costs seven times the node visits); spatial splits under HRT_CTX_FAST_TRACE
         in.split.enabled = device_split || ctx->build_topdown != 0; in.split.budget_frac = device_split ? ctx->split_budget : 0.0f; in.split.alpha = ctx->split_alpha; in.split.bias = ctx->split_bias; in.split.cut_bias = ctx->split_cut_bias;

@@ -312,7 +312,7 @@ static int render_fused(const LaunchFrame &f) {
     if (t->two_level && !lean) return fail(ctx, HRT_ERR_STATE, "a two-level TLAS needs the default path kernel (HRT_FUSED=1)");
     if (lean) ta.postpone_pct = ctx->fused_postpone_pct;
     else if (ctx->fused != 2) ctx->fused_fallback_launches++;        // the tree does not fit k_fused
-    uint32_t blocks_per_cu = lean ? std::min<uint32_t>((uint32_t)ctx->fused_blocks_per_cu, (uint32_t)kFusedBlocksPerCu) : (uint32_t)ctx->fused_blocks_per_cu;
+    uint32_t blocks_per_cu = lean ? std::min<uint32_t>((uint32_t)ctx->fused_blocks_per_cu, (uint32_t)(t->two_level ? kFusedInstancedBlocksPerCu : kFusedBlocksPerCu)) : (uint32_t)ctx->fused_blocks_per_cu;
     if (ctx->traverse_blocks_auto) {
         const uint32_t fit = (uint32_t)((10ull * n + 14ull * 64ull * (uint64_t)ctx->n_cu - 1ull) / (14ull * 64ull * (uint64_t)ctx->n_cu));
         blocks_per_cu = std::min(blocks_per_cu, std::max(fit, 4u));
@@ -730,7 +730,7 @@ int hrt_trace_rays(HrtContext *ctx, HrtTraversable tlas, const HrtFloat3 *d_orig
         const bool lean = ctx->fused != 2 && fits_fused_kernel(ctx, *t);
         if (lean) ta.postpone_pct = ctx->fused_postpone_pct;
         else if (ctx->fused != 2) ctx->fused_fallback_launches++;
-        const uint32_t blocks_per_cu = lean ? std::min<uint32_t>((uint32_t)ctx->fused_blocks_per_cu, (uint32_t)kFusedBlocksPerCu) : (uint32_t)ctx->fused_blocks_per_cu;
+        const uint32_t blocks_per_cu = lean ? std::min<uint32_t>((uint32_t)ctx->fused_blocks_per_cu, (uint32_t)(t->two_level ? kFusedInstancedBlocksPerCu : kFusedBlocksPerCu)) : (uint32_t)ctx->fused_blocks_per_cu;
         const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * blocks_per_cu, (n_rays + 63u) / 64u);
         Timer tm(ctx, s, HRT_K_PATHS);
         if (t->two_level) { ta.tail_split = 0; launch_fused_instanced(ta, t->has_spheres, grid, s); }

@@ -195,6 +195,7 @@ struct HrtContext {
     float split_budget = 1.0f, split_alpha = 1e-5f, split_bias = 0.95f, split_cut_bias = 1.0f; int split_cell_refs = 16;      // the device's spatial splits (HRT_SBVH_BUDGET / _ALPHA / _BIAS / _CELL_REFS)
     int ploc_radius = 2;                        // device build: nearest-neighbour search radius of the PLOC rounds (positions in Morton order); 2 traces fastest
                                                 // on the soup scenes (C4: 24.1 node visits per ray, 16: 28.3, 64: 36.6 -- profiles/r02_build_bench.txt)
+    int build_width = 8;                        // children per node at most (HRT_BVH_WIDTH)
     float build_c_node = 1.0f, build_c_prim = 0.45f;   // collapse costs (bvh8_build.cpp has the same defaults)
     bool build_verbose = false;                 // HRT_BUILD_VERBOSE: builds and updates report on stderr
     int refit = 1;                              // hrt_tlas_update: 1 = device refit when only transforms changed, 0 = always rebuild

@@ -1346,7 +1346,7 @@ def test_device_split_build_with_full_segment_tables(hrt, oracle, gpu_available,
 def test_device_build_falls_back_to_ploc_when_the_top_down_phase_gives_up(hrt, oracle, gpu_available, monkeypatch):
     """The top-down phase runs in every default build above 4096 primitives, rebuilds inside hrt_tlas_update included.  When it gives
     up (here: on request, HRT_SBVH_SEG_CAP=0; in the field: tables outgrown twice, no room for its temporaries) the build goes on with
-    PLOC alone instead of failing: the very tree HRT_BUILD_TOPDOWN=0 builds, same hits, same image -- also under HRT_CTX_FAST_TRACE."""
+    PLOC alone instead of failing: the tree HRT_BUILD_TOPDOWN=0 builds (as many nodes, the same records), same hits, same image -- also under HRT_CTX_FAST_TRACE."""
     if not gpu_available:
         pytest.skip("no GPU")
     w, h, spp = 128, 80, 2
@@ -1367,8 +1367,14 @@ def test_device_build_falls_back_to_ploc_when_the_top_down_phase_gives_up(hrt, o
             assert r.stats().tlas_refits == 1
         finally:
             r.close()
-    assert np.array_equal(trees["ploc"][0], trees["gave-up"][0]) and np.array_equal(trees["ploc"][1], trees["gave-up"][1])
-    assert np.array_equal(trees["ploc"][0], trees["gave-up-fast-trace"][0])
+    # the tree PLOC alone builds: as many nodes, the same records (the emission hands out node and record blocks from atomic cursors,
+    # so their ORDER within a level may differ from build to build)
+    def records(t):
+        rec = t[1].reshape(-1, 48)
+        return rec[np.lexsort(rec.T[::-1])]
+    for name in ("gave-up", "gave-up-fast-trace"):
+        assert trees[name][0].size == trees["ploc"][0].size, name
+        assert np.array_equal(records(trees[name]), records(trees["ploc"])), name
 
 
 def test_device_split_build_is_deterministic_and_fast(hrt, gpu_available):

@@ -291,4 +291,6 @@ def test_path_kernel_hot_loop_keeps_its_instruction_budget():
     assert cs["valu_complex"] <= 175 and cs["salu"] <= 110, dict(cs)
     assert not any(op.startswith("scratch_") or op.startswith("buffer_") for op in ops), sorted(ops)
     text = Path("/tmp/hrt_loops_fused.s").read_text()
-    assert all(int(v) <= 128 for v in re.findall(r"\.vgpr_count:\s+(\d+)", text))
+    # 4 waves per SIMD (<= 128 VGPRs) for the one-level kernels; the INSTANCED instantiations are compiled for 3 (<= 168)
+    counts = sorted(int(v) for v in re.findall(r"\.vgpr_count:\s+(\d+)", text))
+    assert len(counts) == 4 and counts[1] <= 128 and counts[3] <= 168, counts
