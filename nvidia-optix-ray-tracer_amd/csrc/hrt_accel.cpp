@@ -276,7 +276,7 @@ int ensure_template(HrtContext *ctx, Blas &b, hipStream_t s, bool keep_device = 
     in.d_inst_first = reinterpret_cast<const uint32_t *>(base + o_first); in.d_inst_kind = reinterpret_cast<const uint32_t *>(base + o_kind);
     in.d_inst_src = reinterpret_cast<const void *const *>(base + o_src); in.d_inst_xf = reinterpret_cast<const float *>(base + o_xf);
     in.d_inst_identity = reinterpret_cast<const uint32_t *>(base + o_ident);
-    in.max_leaf_prims = kMaxLeafPrims; in.width = (uint32_t)ctx->build_width; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius; in.quant_guard = ctx->quant_guard;
+    in.max_leaf_prims = kMaxLeafPrims; in.width = (uint32_t)ctx->build_width; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim_bodies; in.ploc_radius = ctx->ploc_radius; in.quant_guard = ctx->quant_guard;
     in.out_nodes = d_nodes; in.node_stride = sizeof(Bvh8Node); in.out_prims = d_prims; in.prim_stride = sizeof(PrimRecord); in.out_node_ref = reinterpret_cast<float *>(base + o_ref);
     in.scratch = base + o_scratch; in.scratch_bytes = arena.bytes - o_scratch;
     const GpuBuildResult r = gpu_build_bvh8(in, s);      // (synchronises the stream before it returns)
@@ -338,6 +338,10 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         if (refs[i]->kind == kPrimKindTriangle) n_tri_in += cnt; else n_sph_in += cnt;
         (void)n_sph_in;
     }
+    // a scene of bodies (the reference's kind: particles instancing a few shapes) or a soup?  (the collapse's primitive cost: hrt_internal.hpp)
+    uint32_t n_vis = 0;
+    for (uint32_t i = 0; i < n; ++i) n_vis += first[i + 1] > first[i] ? 1u : 0u;
+    const bool scene_of_bodies = n_vis >= 4u && (uint64_t)first[n] < 20000ull * n_vis;
     // ---- two levels or one?  Flattening costs memory, build and refit time in proportion to instances x primitives; a two-level tree
     //      (transform nodes over one shared tree per BLAS) in proportion to instances + unique primitives, at the price of a ray
     //      transform per instance entered.  Asked for (two_level_mode > 0), or chosen when the flattened tree would leave the caches
@@ -656,7 +660,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
         GpuBuildInput in{};
         in.n_prims = first[n]; in.n_inst = n; in.d_inst_first = t.d_inst_first; in.d_inst_kind = t.d_inst_kind; in.d_inst_src = t.d_inst_src;
         in.d_inst_xf = t.d_inst_xf; in.d_inst_identity = t.d_inst_identity;
-        in.max_leaf_prims = kMaxLeafPrims; in.width = (uint32_t)ctx->build_width; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius; in.quant_guard = ctx->quant_guard;
+        in.max_leaf_prims = kMaxLeafPrims; in.width = (uint32_t)ctx->build_width; in.c_node = ctx->build_c_node; in.c_prim = scene_of_bodies ? ctx->build_c_prim_bodies : ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius; in.quant_guard = ctx->quant_guard;
         // the top-down phase always (object splits: what gives the tree its shape above the cells PLOC builds -- on the reference's kind of
         // scene, separate bodies over a huge ground sphere, PLOC alone costs seven times the node visits); spatial splits under HRT_CTX_FAST_TRACE
         in.split.enabled = device_split || ctx->build_topdown != 0; in.split.budget_frac = device_split ? ctx->split_budget : 0.0f; in.split.alpha = ctx->split_alpha; in.split.bias = ctx->split_bias; in.split.cut_bias = ctx->split_cut_bias;

@@ -197,6 +197,11 @@ struct HrtContext {
                                                 // on the soup scenes (C4: 24.1 node visits per ray, 16: 28.3, 64: 36.6 -- profiles/r02_build_bench.txt)
     int build_width = 8;                        // children per node at most (HRT_BVH_WIDTH)
     float build_c_node = 1.0f, build_c_prim = 0.45f;   // collapse costs (bvh8_build.cpp has the same defaults)
+    // ... and the primitive's cost for scenes of BODIES (several instances of small meshes: the reference's kind): their rays test as many primitives as they
+    // visit nodes, a lane tests one primitive per iteration, and the collapse's 0.45 -- right for a soup, whose rays visit three nodes per test -- makes leaves too
+    // fat: 2.0 is 10-12 % faster on 2000 particles, 5-10 % on 25, 3 % on the shipped sample's loop, 8 % on two-level trees, and 1 % SLOWER on C4
+    // (profiles/r04_cprim_sweep.txt).  HRT_BVH_CPRIM sets both.
+    float build_c_prim_bodies = 2.0f;
     bool build_verbose = false;                 // HRT_BUILD_VERBOSE: builds and updates report on stderr
     int refit = 1;                              // hrt_tlas_update: 1 = device refit when only transforms changed, 0 = always rebuild
     int refit_moved_far_check = 1;              // the first update after a build rebuilds without refitting first when most instances have moved further than their size (HRT_REFIT_MOVED_FAR=0: always refit first)
