@@ -230,13 +230,14 @@ __device__ __forceinline__ float safe_rcp_dir(float d) {
 // canonical primitive test (DESIGN.md "canonical intersector"); updates the best hit.
 // INSTANCED (two-level trees, fused.hip): the record is a shared BLAS's, in object space, and so is the ray in `s` by now (the transform
 // node did that for triangles and spheres alike); the record does not know who instances it: `inst_cur` does.
+// (test_prim_ray: the ray given explicitly -- a lane of the instanced kernel that has left an instance with leaf tests still to make keeps that
+// instance's object-space ray in LDS while its registers hold the world ray again)
 template <bool HAS_SPHERES, bool INSTANCED = false>
-__device__ __forceinline__ bool test_prim(const float4 A, const float4 B, const float4 C, TravState &s,
-                                          float tmin, float tmax_ray,
-                                          const float *__restrict__ inst_inv, const uint32_t *__restrict__ inst_identity, uint32_t inst_cur = 0u) {
+__device__ __forceinline__ bool test_prim_ray(const float4 A, const float4 B, const float4 C, TravState &s, const V3 o, const V3 d,
+                                              float tmin, float tmax_ray,
+                                              const float *__restrict__ inst_inv, const uint32_t *__restrict__ inst_identity, uint32_t inst_cur = 0u) {
     float t, u = 0.0f, v = 0.0f;
     uint32_t prim = __float_as_uint(A.w), inst;
-    const V3 o = mk3(s.ox, s.oy, s.oz), d = mk3(s.dx, s.dy, s.dz);
     if (HAS_SPHERES && __float_as_uint(C.w) == 1u) {
         inst = INSTANCED ? inst_cur : __float_as_uint(B.w);
         V3 oo = o, dd = d;
@@ -297,6 +298,13 @@ __device__ __forceinline__ bool test_prim(const float4 A, const float4 B, const 
     }
     if (better) { s.bt = t; s.bu = u; s.bv = v; s.bprim = prim; s.binst = inst; }
     return better;
+}
+
+template <bool HAS_SPHERES, bool INSTANCED = false>
+__device__ __forceinline__ bool test_prim(const float4 A, const float4 B, const float4 C, TravState &s,
+                                          float tmin, float tmax_ray,
+                                          const float *__restrict__ inst_inv, const uint32_t *__restrict__ inst_identity, uint32_t inst_cur = 0u) {
+    return test_prim_ray<HAS_SPHERES, INSTANCED>(A, B, C, s, mk3(s.ox, s.oy, s.oz), mk3(s.dx, s.dy, s.dz), tmin, tmax_ray, inst_inv, inst_identity, inst_cur);
 }
 
 #define HRT_BYTE_F(w, k) ((float)(((w) >> (8 * (k))) & 0xffu))
