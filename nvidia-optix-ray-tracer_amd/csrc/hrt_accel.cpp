@@ -302,6 +302,235 @@ int ensure_template(HrtContext *ctx, Blas &b, hipStream_t s, bool keep_device = 
 // Either way the result is one world-space BVH8: the traversal kernels do not know the difference.
 constexpr int kRetryFlattened = 1;      // build_tlas_fresh: the two-level tree asked for cannot be had (too deep for the path kernel's stack): build the flattened one
 
+// ---- the merged device build (the body of build_tlas_fresh for it): every visible instance's primitives in ONE world-space tree -- topology and
+//      primitive ids from build.hip (the top-down SAH phase, with spatial splits under HRT_CTX_FAST_TRACE, then PLOC in the cells, the optimal
+//      collapse, the emission); the refit computes every record, box and quantised child, exactly as after an instance update ----
+static int build_merged_on_device(HrtContext *ctx, Tlas &t, const std::vector<uint32_t> &first, bool device_split, bool scene_of_bodies, uint32_t n_tri_in,
+                                  float scene_scale, size_t pb, RefitArgs ra, hipStream_t s) {
+    const uint32_t n = t.n_instances;
+    HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_first, sizeof(uint32_t) * first.size()));
+    HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_kind, sizeof(uint32_t) * std::max(n, 1u)));
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_first, first.data(), sizeof(uint32_t) * first.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_kind, t.kind.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
+    GpuBuildInput in{};
+    in.n_prims = first[n]; in.n_inst = n; in.d_inst_first = t.d_inst_first; in.d_inst_kind = t.d_inst_kind; in.d_inst_src = t.d_inst_src;
+    in.d_inst_xf = t.d_inst_xf; in.d_inst_identity = t.d_inst_identity;
+    in.max_leaf_prims = kMaxLeafPrims; in.width = (uint32_t)ctx->build_width; in.c_node = ctx->build_c_node; in.c_prim = scene_of_bodies ? ctx->build_c_prim_bodies : ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius; in.quant_guard = ctx->quant_guard;
+    // the top-down phase always (object splits: what gives the tree its shape above the cells PLOC builds -- on the reference's kind of
+    // scene, separate bodies over a huge ground sphere, PLOC alone costs seven times the node visits); spatial splits under HRT_CTX_FAST_TRACE
+    in.split.enabled = device_split || ctx->build_topdown != 0; in.split.budget_frac = device_split ? ctx->split_budget : 0.0f; in.split.alpha = ctx->split_alpha; in.split.bias = ctx->split_bias; in.split.cut_bias = ctx->split_cut_bias;
+    in.split.cell_refs = (uint32_t)ctx->split_cell_refs; in.split.pad = ra.pad; in.split.verbose = ctx->build_verbose;
+    // worst-case node output (one node and two reference floats per leaf: primitive, or reference of a spatial split) at the front of the
+    // working memory; a split build's records and their clip boxes too (their number is known afterwards)
+    const size_t max_leaves = gpu_build_max_refs(in.n_prims, &in.split);
+    const size_t stage_nodes = ((size_t)t.node_stride * max_leaves + 255u) & ~(size_t)255u, stage_ref = (sizeof(float) * 2 * max_leaves + 255u) & ~(size_t)255u;
+    const size_t stage_prims = device_split ? ((size_t)t.prim_stride * max_leaves + 255u) & ~(size_t)255u : 0u, stage_clip = device_split ? (sizeof(float) * 6 * max_leaves + 255u) & ~(size_t)255u : 0u;
+    const size_t stage_all = stage_nodes + stage_ref + stage_prims + stage_clip, want = gpu_build_scratch_bytes(in.n_prims, &in.split) + stage_all;
+    ScratchArena arena = scratch_acquire(ctx, want);
+    if (!arena.p && in.split.enabled && !device_split) {      // no room for the top-down phase's buffers: PLOC alone
+        in.split.enabled = false;
+        arena = scratch_acquire(ctx, gpu_build_scratch_bytes(in.n_prims, nullptr) + stage_all);
+    }
+    if (!arena.p) return fail(ctx, HRT_ERR_OOM, "device build: no working memory (%zu bytes)", want);
+    struct Release { HrtContext *c; ScratchArena a; hipStream_t st; ~Release() { (void)hipStreamSynchronize(st); scratch_release(c, a); } } release{ctx, arena, s};      // (see ensure_template)
+    unsigned char *stage = static_cast<unsigned char *>(arena.p);
+    in.out_nodes = stage; in.node_stride = t.node_stride; in.out_node_ref = reinterpret_cast<float *>(stage + stage_nodes);
+    in.out_prims = device_split ? stage + stage_nodes + stage_ref : ra.prims; in.prim_stride = t.prim_stride;
+    in.out_clip = device_split ? reinterpret_cast<float *>(stage + stage_nodes + stage_ref + stage_prims) : nullptr;
+    in.scratch = stage + stage_all; in.scratch_bytes = arena.bytes - stage_all;
+    const GpuBuildResult r = gpu_build_bvh8(in, s);      // (synchronises the stream before it returns)
+    if (r.error != hipSuccess) return fail(ctx, r.error == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, "device build failed: %s (%s)", hipGetErrorString(r.error), r.where);
+    {   // the tree's own buffers, as large as the build turned out to need
+        const size_t nn = std::max<size_t>(r.n_prims ? r.n_nodes : 1u, 1u);
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_nodes, (size_t)t.node_stride * nn));
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_node_box, sizeof(float) * 6 * nn));
+        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_node_ref, sizeof(float) * 2 * nn));
+        size_t rec_bytes = pb;
+        if (device_split) {
+            rec_bytes = (size_t)t.prim_stride * std::max<size_t>(r.n_records, 1);
+            HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_prims, rec_bytes));
+            ra.prims = reinterpret_cast<unsigned char *>(t.d_prims);
+            if (r.n_records) HIP_TRY(ctx, hipMemcpyAsync(t.d_prims, in.out_prims, (size_t)t.prim_stride * r.n_records, hipMemcpyDeviceToDevice, s));
+        }
+        if (r.n_prims) {
+            HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, stage, (size_t)t.node_stride * nn, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(ctx, hipMemcpyAsync(t.d_node_ref, in.out_node_ref, sizeof(float) * 2 * nn, hipMemcpyDeviceToDevice, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));         // the working memory goes back to the context when this scope ends
+        }
+        ra.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); ra.node_box = t.d_node_box; ra.node_ref = t.d_node_ref;
+        t.alloc_bytes = (uint64_t)t.node_stride * nn + sizeof(float) * 8 * nn + rec_bytes;
+    }
+    t.bvh = Bvh8();
+    if (r.n_prims == 0u) {
+        // every primitive had non-finite bounds: the empty root (every ray misses)
+        build_bvh8({}, t.bvh, 1, scene_scale);
+        HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, t.bvh.nodes.data(), sizeof(Bvh8Node), hipMemcpyHostToDevice, s));
+        t.phases.clear();
+        t.n_nodes = 1; t.n_prims = 0; t.n_triangles = t.n_spheres = 0; t.max_depth = 0;
+    } else {
+        if (2 * r.max_depth + 2 > (uint32_t)(8 + 56)) return fail(ctx, HRT_ERR_INVALID, "BVH depth %u exceeds the traversal stack", r.max_depth);
+        for (size_t l = r.level_begin.size() - 1; l-- > 0;) t.phases.emplace_back(r.level_begin[l], r.level_begin[l + 1] - r.level_begin[l]);
+        // (a split build: every record's box is the one its cell is responsible for, not the primitive's -- this once; a later
+        // update would recompute the boxes from whole primitives, so the first update rebuilds instead: has_split_refs)
+        if (device_split && r.split_levels) { ra.clip = in.out_clip; t.has_split_refs = true; }
+        attach_rec_box(ctx, t, ra, r.n_records);
+        launch_refit_phases(ra, t.phases, s);
+        HIP_TRY(ctx, hipGetLastError());
+        if (device_split && r.split_levels) HIP_TRY(ctx, hipStreamSynchronize(s));      // (the clip boxes live in the working memory)
+        ra.clip = nullptr;
+        if (ctx->build_verbose)
+            std::fprintf(stderr, "[hrt] device build: %u primitives -> %u records, %u nodes, depth %u, %u PLOC rounds (radius %d), %u split levels, %u cells\n",
+                         r.n_prims, r.n_records, r.n_nodes, r.max_depth, r.ploc_rounds, ctx->ploc_radius, r.split_levels, r.n_cells);
+        const uint32_t dropped = first[n] - r.n_prims;      // non-finite primitives (counted against the triangles unless there are none)
+        t.n_nodes = r.n_nodes; t.n_prims = r.n_records; t.max_depth = r.max_depth;
+        t.n_triangles = n_tri_in >= dropped ? n_tri_in - dropped : 0u; t.n_spheres = r.n_prims - t.n_triangles;
+        for (int a = 0; a < 3; ++a) { t.lo[a] = r.lo[a]; t.hi[a] = r.hi[a]; }
+    }
+    return HRT_OK;
+}
+
+// ---- a two-level tree (the body of build_tlas_fresh for it).  (1) every unique BLAS has its object-space tree (topology),
+//      built once per BLAS and kept on the device; (2) the device build over the instances' bounds, whose leaves come out as transform nodes;
+//      (3) the BLAS trees are copied in behind the top level and refitted in object space; (4) the top level's refit -- the only part an update
+//      repeats.  t's per-instance tables (transforms, inverses, bounds as the top level's "geometry") are in place; `ra` carries them. ----
+static int build_two_level(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, const std::vector<Blas *> &uniq, const std::vector<uint32_t> &slot_of,
+                           const std::vector<uint32_t> &first, float scene_scale, RefitArgs ra, hipStream_t s) {
+    const uint32_t n = (uint32_t)inst.size();
+    const uint32_t nu = (uint32_t)uniq.size();
+    std::vector<uint32_t> node_off(nu + 1, 0u), prim_off(nu + 1, 0u);
+    uint32_t blas_depth = 0;
+    for (uint32_t j = 0; j < nu; ++j) {
+        const int rc = ensure_template(ctx, *uniq[j], s, true);
+        if (rc != HRT_OK) return rc;
+        const Bvh8 &tp = uniq[j]->tmpl;
+        if ((uint64_t)node_off[j] + tp.nodes.size() > 0x7fffffffull || (uint64_t)prim_off[j] + tp.prims.size() > 0x7fffffffull) return fail(ctx, HRT_ERR_INVALID, "two-level tree: more than 2^31 nodes or records");
+        node_off[j + 1] = node_off[j] + (uint32_t)tp.nodes.size(); prim_off[j + 1] = prim_off[j] + (uint32_t)tp.prims.size();
+        blas_depth = std::max(blas_depth, tp.max_depth);
+    }
+    // the top level's primitives: one per visible instance of a non-empty BLAS
+    std::vector<uint32_t> first2(n + 1, 0u), kind2(std::max(n, 1u), kPrimKindInstance);
+    for (uint32_t i = 0; i < n; ++i) {
+        const Blas &b = *t.blas_refs[i];
+        first2[i + 1] = first2[i] + (((inst[i].visibilityMask & 1u) != 0 && b.n_prims != 0u && b.lo[0] <= b.hi[0]) ? 1u : 0u);
+    }
+    const uint32_t n2 = first2[n];
+    HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_first, sizeof(uint32_t) * first2.size()));
+    HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_kind, sizeof(uint32_t) * kind2.size()));
+    HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_root, sizeof(uint32_t) * std::max(n, 1u)));
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_first, first2.data(), sizeof(uint32_t) * first2.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_kind, kind2.data(), sizeof(uint32_t) * kind2.size(), hipMemcpyHostToDevice, s));
+    GpuBuildInput in{};
+    in.n_prims = n2; in.n_inst = n; in.d_inst_first = t.d_inst_first; in.d_inst_kind = t.d_inst_kind; in.d_inst_src = t.d_inst_src;
+    in.d_inst_xf = t.d_inst_xf; in.d_inst_identity = t.d_inst_identity;
+    in.max_leaf_prims = 1; in.instance_leaves = true; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius; in.quant_guard = ctx->quant_guard;
+    in.split.enabled = ctx->build_topdown != 0; in.split.budget_frac = 0.0f; in.split.alpha = ctx->split_alpha; in.split.bias = ctx->split_bias; in.split.cut_bias = ctx->split_cut_bias;
+    in.split.cell_refs = (uint32_t)ctx->split_cell_refs; in.split.pad = ra.pad; in.split.verbose = ctx->build_verbose;
+    // worst case: a transform node per instance and fewer box nodes than instances
+    const size_t max_nodes = 2 * (size_t)n2 + 2;
+    const size_t stage_nodes = ((size_t)t.node_stride * max_nodes + 255u) & ~(size_t)255u, stage_ref = (sizeof(float) * 2 * max_nodes + 255u) & ~(size_t)255u;
+    // (the pack's refit tables and walk order share the block: nu small tables, one entry per BLAS node)
+    const size_t tab_xf = ((sizeof(float) * 12 * nu) + 255u) & ~(size_t)255u, tab_id = ((sizeof(uint32_t) * nu) + 255u) & ~(size_t)255u, tab_src = ((sizeof(void *) * nu) + 255u) & ~(size_t)255u;
+    const size_t tab_order = ((sizeof(uint32_t) * (size_t)node_off[nu]) + 255u) & ~(size_t)255u;
+    const size_t stage_all = stage_nodes + stage_ref + tab_xf + tab_id + tab_src + tab_order, want = gpu_build_scratch_bytes(n2, &in.split) + stage_all;
+    ScratchArena arena = scratch_acquire(ctx, want);
+    if (!arena.p) return fail(ctx, HRT_ERR_OOM, "device build: no working memory (%zu bytes)", want);
+    struct Release { HrtContext *c; ScratchArena a; hipStream_t st; ~Release() { (void)hipStreamSynchronize(st); scratch_release(c, a); } } release{ctx, arena, s};
+    unsigned char *stage = static_cast<unsigned char *>(arena.p);
+    in.out_nodes = stage; in.node_stride = t.node_stride; in.out_node_ref = reinterpret_cast<float *>(stage + stage_nodes);
+    in.out_prims = stage; in.prim_stride = t.prim_stride;        // (no record is written: the leaves are transform nodes)
+    in.scratch = stage + stage_all; in.scratch_bytes = arena.bytes - stage_all;
+    const GpuBuildResult r = gpu_build_bvh8(in, s);      // (synchronises the stream before it returns)
+    if (r.error != hipSuccess) return fail(ctx, r.error == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, "device build of the top level failed: %s (%s)", hipGetErrorString(r.error), r.where);
+    if (r.n_prims == 0u) return kRetryFlattened;                                 // nothing valid to instance: the flattened path emits the empty root
+    // the path kernel keeps one sibling group per level of BOTH trees on its node stack
+    if (r.max_depth + 1u + blas_depth > (uint32_t)ctx->fused_max_depth) return kRetryFlattened;
+    const uint32_t n_top = r.n_nodes, n_all = n_top + node_off[nu], n_rec = prim_off[nu];
+    if ((uint64_t)n_all * t.node_stride >= ctx->fused_max_bytes || (uint64_t)std::max(n_rec, 1u) * t.prim_stride >= ctx->fused_max_bytes) return kRetryFlattened;
+    HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_nodes, (size_t)t.node_stride * n_all + 16));       // (+16: the path kernel reads 80 bytes of the last node whatever its stride)
+    HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_node_box, sizeof(float) * 6 * (size_t)n_all));
+    HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_node_ref, sizeof(float) * 2 * (size_t)n_all));
+    HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_prims, (size_t)t.prim_stride * std::max(n_rec, 1u)));
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, stage, (size_t)t.node_stride * n_top, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_node_ref, in.out_node_ref, sizeof(float) * 2 * (size_t)n_top, hipMemcpyDeviceToDevice, s));
+    // (3) the BLAS trees behind the top level
+    std::vector<uint32_t> roots(std::max(n, 1u), 0u);
+    for (uint32_t i = 0; i < n; ++i) roots[i] = n_top + node_off[slot_of[i]];
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_root, roots.data(), sizeof(uint32_t) * roots.size(), hipMemcpyHostToDevice, s));
+    for (uint32_t j = 0; j < nu; ++j) {
+        PackBlasArgs pa{};
+        pa.src_nodes = uniq[j]->d_tmpl_nodes; pa.src_prims = uniq[j]->d_tmpl_prims; pa.n_nodes = node_off[j + 1] - node_off[j]; pa.n_prims = prim_off[j + 1] - prim_off[j];
+        pa.dst_nodes = reinterpret_cast<unsigned char *>(t.d_nodes); pa.dst_prims = reinterpret_cast<unsigned char *>(t.d_prims); pa.node_stride = t.node_stride; pa.prim_stride = t.prim_stride;
+        pa.node_off = n_top + node_off[j]; pa.prim_off = prim_off[j]; pa.slot = j;
+        launch_pack_blas(pa, s);
+    }
+    // their refit, all BLASes at once: phase k = the k-th level from the bottom of every tree (a template is stored breadth first,
+    // children one level below their parents), walked through an order array; per-BLAS tables with the identity transform
+    std::vector<float> pxf(12 * (size_t)nu, 0.0f); std::vector<uint32_t> pid(nu, 1u); std::vector<const void *> psrc(nu, nullptr);
+    std::vector<uint32_t> order; order.reserve(node_off[nu]);
+    std::vector<std::pair<uint32_t, uint32_t>> pack_phases;
+    float obj_coord = 1.0f;
+    for (uint32_t j = 0; j < nu; ++j) {
+        pxf[12 * (size_t)j] = pxf[12 * (size_t)j + 5] = pxf[12 * (size_t)j + 10] = 1.0f; psrc[j] = uniq[j]->d_verts;
+        for (int a = 0; a < 3; ++a) obj_coord = std::max(obj_coord, std::max(std::fabs(uniq[j]->lo[a]), std::fabs(uniq[j]->hi[a])));
+    }
+    for (uint32_t k = 0; k <= blas_depth; ++k) {
+        const uint32_t begin = (uint32_t)order.size();
+        for (uint32_t j = 0; j < nu; ++j) {
+            const std::vector<uint32_t> &lb = uniq[j]->tmpl.level_begin;
+            const uint32_t levels = lb.empty() ? 0u : (uint32_t)lb.size() - 1u;
+            if (k >= levels) continue;
+            const uint32_t l = levels - 1u - k;
+            for (uint32_t x = lb[l]; x < lb[l + 1]; ++x) order.push_back(n_top + node_off[j] + x);
+        }
+        if (order.size() > begin) pack_phases.emplace_back(begin, (uint32_t)order.size() - begin);
+    }
+    if (order.size() != node_off[nu]) return fail(ctx, HRT_ERR_HIP, "two-level tree: a BLAS template's levels do not cover its nodes");
+    unsigned char *tabs = stage + stage_nodes + stage_ref;
+    float *d_pxf = reinterpret_cast<float *>(tabs); uint32_t *d_pid = reinterpret_cast<uint32_t *>(tabs + tab_xf);
+    const void **d_psrc = reinterpret_cast<const void **>(tabs + tab_xf + tab_id); uint32_t *d_porder = reinterpret_cast<uint32_t *>(tabs + tab_xf + tab_id + tab_src);
+    HIP_TRY(ctx, hipMemcpyAsync(d_pxf, pxf.data(), sizeof(float) * pxf.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_pid, pid.data(), sizeof(uint32_t) * nu, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync((void *)d_psrc, psrc.data(), sizeof(void *) * nu, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipMemcpyAsync(d_porder, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice, s));
+    // The boxes inside a BLAS are padded for the object-space rays that will come: the slab test's error grows with the distance
+    // of the ray's origin, which in object space is the world's extent seen through the instance's inverse (a rigid pose: the
+    // world's own extent, as for the flattened tree).
+    float reach = 1.0f;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (first2[i + 1] == first2[i]) continue;
+        const float *v = &t.h_inv[12 * (size_t)i];
+        float rown = 0.0f;
+        for (int rr = 0; rr < 3; ++rr) rown = std::max(rown, std::fabs(v[4 * rr]) + std::fabs(v[4 * rr + 1]) + std::fabs(v[4 * rr + 2]));
+        if (std::isfinite(rown)) reach = std::max(reach, rown * scene_scale);
+    }
+    t.built_reach = std::max(reach, obj_coord);
+    RefitArgs rp{};
+    rp.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); rp.node_stride = t.node_stride; rp.prims = reinterpret_cast<unsigned char *>(t.d_prims); rp.prim_stride = t.prim_stride;
+    rp.node_box = t.d_node_box; rp.node_ref = t.d_node_ref; rp.inst_xf = d_pxf; rp.inst_identity = d_pid; rp.inst_src = d_psrc; rp.order = d_porder;
+    rp.pad = 4e-6f * t.built_reach; rp.write_reference = 1u;
+    launch_refit_phases(rp, pack_phases, s);
+    HIP_TRY(ctx, hipGetLastError());
+    // (4) the top level
+    ra.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); ra.prims = reinterpret_cast<unsigned char *>(t.d_prims); ra.node_box = t.d_node_box; ra.node_ref = t.d_node_ref;
+    ra.inst_inv = t.d_inst_inv; ra.inst_root = t.d_inst_root;
+    for (size_t l = r.level_begin.size() - 1; l-- > 0;) t.phases.emplace_back(r.level_begin[l], r.level_begin[l + 1] - r.level_begin[l]);
+    launch_refit_phases(ra, t.phases, s);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (ctx->build_verbose)
+        std::fprintf(stderr, "[hrt] two-level build: %u instances over %u BLASes -> %u top nodes (depth %u, %u split levels), %u BLAS nodes (depth <= %u), %u records (flattened: %u)\n",
+                     n2, nu, n_top, r.max_depth, r.split_levels, node_off[nu], blas_depth, n_rec, first[n]);
+    t.bvh = Bvh8();
+    t.two_level = true; t.n_top_nodes = n_top; t.n_unique_blas = nu;
+    t.n_nodes = n_all; t.n_prims = n_rec; t.max_depth = r.max_depth + 1u + blas_depth;
+    t.n_triangles = t.n_spheres = 0;
+    for (uint32_t j = 0; j < nu; ++j) { t.n_triangles += uniq[j]->tmpl.n_triangles; t.n_spheres += uniq[j]->tmpl.n_spheres; }
+    t.alloc_bytes = (uint64_t)t.node_stride * n_all + sizeof(float) * 8 * (uint64_t)n_all + (uint64_t)t.prim_stride * std::max(n_rec, 1u);
+    for (int a = 0; a < 3; ++a) { t.lo[a] = r.lo[a]; t.hi[a] = r.hi[a]; }
+    return HRT_OK;
+}
+
+
 static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &inst, hipStream_t s, bool instanced, bool fast_trace, int two_level_mode) {
     const uint32_t n = (uint32_t)inst.size();
     std::vector<std::shared_ptr<Blas>> refs(n);
@@ -517,220 +746,11 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
     ra.node_box = t.d_node_box; ra.node_ref = t.d_node_ref; ra.inst_xf = t.d_inst_xf; ra.inst_identity = t.d_inst_identity;
     ra.inst_src = t.d_inst_src; ra.pad = 4e-6f * std::max(1.0f, scene_scale); ra.write_reference = 1u;
     if (on_device && two_level) {
-        // ---- a two-level tree.  (1) every unique BLAS has its object-space tree (topology), built once per BLAS and kept on the device;
-        //      (2) the device build over the instances' boxes, whose leaves come out as transform nodes; (3) the BLAS trees are copied in
-        //      behind the top level and refitted in object space; (4) the top level's refit -- the only part an update repeats. ----
-        const uint32_t nu = (uint32_t)uniq.size();
-        std::vector<uint32_t> node_off(nu + 1, 0u), prim_off(nu + 1, 0u);
-        uint32_t blas_depth = 0;
-        for (uint32_t j = 0; j < nu; ++j) {
-            const int rc = ensure_template(ctx, *uniq[j], s, true);
-            if (rc != HRT_OK) return rc;
-            const Bvh8 &tp = uniq[j]->tmpl;
-            if ((uint64_t)node_off[j] + tp.nodes.size() > 0x7fffffffull || (uint64_t)prim_off[j] + tp.prims.size() > 0x7fffffffull) return fail(ctx, HRT_ERR_INVALID, "two-level tree: more than 2^31 nodes or records");
-            node_off[j + 1] = node_off[j] + (uint32_t)tp.nodes.size(); prim_off[j + 1] = prim_off[j] + (uint32_t)tp.prims.size();
-            blas_depth = std::max(blas_depth, tp.max_depth);
-        }
-        // the top level's primitives: one per visible instance of a non-empty BLAS
-        std::vector<uint32_t> first2(n + 1, 0u), kind2(std::max(n, 1u), kPrimKindInstance);
-        for (uint32_t i = 0; i < n; ++i) {
-            const Blas &b = *t.blas_refs[i];
-            first2[i + 1] = first2[i] + (((inst[i].visibilityMask & 1u) != 0 && b.n_prims != 0u && b.lo[0] <= b.hi[0]) ? 1u : 0u);
-        }
-        const uint32_t n2 = first2[n];
-        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_first, sizeof(uint32_t) * first2.size()));
-        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_kind, sizeof(uint32_t) * kind2.size()));
-        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_root, sizeof(uint32_t) * std::max(n, 1u)));
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_first, first2.data(), sizeof(uint32_t) * first2.size(), hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_kind, kind2.data(), sizeof(uint32_t) * kind2.size(), hipMemcpyHostToDevice, s));
-        GpuBuildInput in{};
-        in.n_prims = n2; in.n_inst = n; in.d_inst_first = t.d_inst_first; in.d_inst_kind = t.d_inst_kind; in.d_inst_src = t.d_inst_src;
-        in.d_inst_xf = t.d_inst_xf; in.d_inst_identity = t.d_inst_identity;
-        in.max_leaf_prims = 1; in.instance_leaves = true; in.c_node = ctx->build_c_node; in.c_prim = ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius; in.quant_guard = ctx->quant_guard;
-        in.split.enabled = ctx->build_topdown != 0; in.split.budget_frac = 0.0f; in.split.alpha = ctx->split_alpha; in.split.bias = ctx->split_bias; in.split.cut_bias = ctx->split_cut_bias;
-        in.split.cell_refs = (uint32_t)ctx->split_cell_refs; in.split.pad = ra.pad; in.split.verbose = ctx->build_verbose;
-        // worst case: a transform node per instance and fewer box nodes than instances
-        const size_t max_nodes = 2 * (size_t)n2 + 2;
-        const size_t stage_nodes = ((size_t)t.node_stride * max_nodes + 255u) & ~(size_t)255u, stage_ref = (sizeof(float) * 2 * max_nodes + 255u) & ~(size_t)255u;
-        // (the pack's refit tables and walk order share the block: nu small tables, one entry per BLAS node)
-        const size_t tab_xf = ((sizeof(float) * 12 * nu) + 255u) & ~(size_t)255u, tab_id = ((sizeof(uint32_t) * nu) + 255u) & ~(size_t)255u, tab_src = ((sizeof(void *) * nu) + 255u) & ~(size_t)255u;
-        const size_t tab_order = ((sizeof(uint32_t) * (size_t)node_off[nu]) + 255u) & ~(size_t)255u;
-        const size_t stage_all = stage_nodes + stage_ref + tab_xf + tab_id + tab_src + tab_order, want = gpu_build_scratch_bytes(n2, &in.split) + stage_all;
-        ScratchArena arena = scratch_acquire(ctx, want);
-        if (!arena.p) return fail(ctx, HRT_ERR_OOM, "device build: no working memory (%zu bytes)", want);
-        struct Release { HrtContext *c; ScratchArena a; hipStream_t st; ~Release() { (void)hipStreamSynchronize(st); scratch_release(c, a); } } release{ctx, arena, s};
-        unsigned char *stage = static_cast<unsigned char *>(arena.p);
-        in.out_nodes = stage; in.node_stride = t.node_stride; in.out_node_ref = reinterpret_cast<float *>(stage + stage_nodes);
-        in.out_prims = stage; in.prim_stride = t.prim_stride;        // (no record is written: the leaves are transform nodes)
-        in.scratch = stage + stage_all; in.scratch_bytes = arena.bytes - stage_all;
-        const GpuBuildResult r = gpu_build_bvh8(in, s);      // (synchronises the stream before it returns)
-        if (r.error != hipSuccess) return fail(ctx, r.error == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, "device build of the top level failed: %s (%s)", hipGetErrorString(r.error), r.where);
-        if (r.n_prims == 0u) return kRetryFlattened;                                 // nothing valid to instance: the flattened path emits the empty root
-        // the path kernel keeps one sibling group per level of BOTH trees on its node stack
-        if (r.max_depth + 1u + blas_depth > (uint32_t)ctx->fused_max_depth) return kRetryFlattened;
-        const uint32_t n_top = r.n_nodes, n_all = n_top + node_off[nu], n_rec = prim_off[nu];
-        if ((uint64_t)n_all * t.node_stride >= ctx->fused_max_bytes || (uint64_t)std::max(n_rec, 1u) * t.prim_stride >= ctx->fused_max_bytes) return kRetryFlattened;
-        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_nodes, (size_t)t.node_stride * n_all + 16));       // (+16: the path kernel reads 80 bytes of the last node whatever its stride)
-        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_node_box, sizeof(float) * 6 * (size_t)n_all));
-        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_node_ref, sizeof(float) * 2 * (size_t)n_all));
-        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_prims, (size_t)t.prim_stride * std::max(n_rec, 1u)));
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, stage, (size_t)t.node_stride * n_top, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_node_ref, in.out_node_ref, sizeof(float) * 2 * (size_t)n_top, hipMemcpyDeviceToDevice, s));
-        // (3) the BLAS trees behind the top level
-        std::vector<uint32_t> roots(std::max(n, 1u), 0u);
-        for (uint32_t i = 0; i < n; ++i) roots[i] = n_top + node_off[slot_of[i]];
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_root, roots.data(), sizeof(uint32_t) * roots.size(), hipMemcpyHostToDevice, s));
-        for (uint32_t j = 0; j < nu; ++j) {
-            PackBlasArgs pa{};
-            pa.src_nodes = uniq[j]->d_tmpl_nodes; pa.src_prims = uniq[j]->d_tmpl_prims; pa.n_nodes = node_off[j + 1] - node_off[j]; pa.n_prims = prim_off[j + 1] - prim_off[j];
-            pa.dst_nodes = reinterpret_cast<unsigned char *>(t.d_nodes); pa.dst_prims = reinterpret_cast<unsigned char *>(t.d_prims); pa.node_stride = t.node_stride; pa.prim_stride = t.prim_stride;
-            pa.node_off = n_top + node_off[j]; pa.prim_off = prim_off[j]; pa.slot = j;
-            launch_pack_blas(pa, s);
-        }
-        // their refit, all BLASes at once: phase k = the k-th level from the bottom of every tree (a template is stored breadth first,
-        // children one level below their parents), walked through an order array; per-BLAS tables with the identity transform
-        std::vector<float> pxf(12 * (size_t)nu, 0.0f); std::vector<uint32_t> pid(nu, 1u); std::vector<const void *> psrc(nu, nullptr);
-        std::vector<uint32_t> order; order.reserve(node_off[nu]);
-        std::vector<std::pair<uint32_t, uint32_t>> pack_phases;
-        float obj_coord = 1.0f;
-        for (uint32_t j = 0; j < nu; ++j) {
-            pxf[12 * (size_t)j] = pxf[12 * (size_t)j + 5] = pxf[12 * (size_t)j + 10] = 1.0f; psrc[j] = uniq[j]->d_verts;
-            for (int a = 0; a < 3; ++a) obj_coord = std::max(obj_coord, std::max(std::fabs(uniq[j]->lo[a]), std::fabs(uniq[j]->hi[a])));
-        }
-        for (uint32_t k = 0; k <= blas_depth; ++k) {
-            const uint32_t begin = (uint32_t)order.size();
-            for (uint32_t j = 0; j < nu; ++j) {
-                const std::vector<uint32_t> &lb = uniq[j]->tmpl.level_begin;
-                const uint32_t levels = lb.empty() ? 0u : (uint32_t)lb.size() - 1u;
-                if (k >= levels) continue;
-                const uint32_t l = levels - 1u - k;
-                for (uint32_t x = lb[l]; x < lb[l + 1]; ++x) order.push_back(n_top + node_off[j] + x);
-            }
-            if (order.size() > begin) pack_phases.emplace_back(begin, (uint32_t)order.size() - begin);
-        }
-        if (order.size() != node_off[nu]) return fail(ctx, HRT_ERR_HIP, "two-level tree: a BLAS template's levels do not cover its nodes");
-        unsigned char *tabs = stage + stage_nodes + stage_ref;
-        float *d_pxf = reinterpret_cast<float *>(tabs); uint32_t *d_pid = reinterpret_cast<uint32_t *>(tabs + tab_xf);
-        const void **d_psrc = reinterpret_cast<const void **>(tabs + tab_xf + tab_id); uint32_t *d_porder = reinterpret_cast<uint32_t *>(tabs + tab_xf + tab_id + tab_src);
-        HIP_TRY(ctx, hipMemcpyAsync(d_pxf, pxf.data(), sizeof(float) * pxf.size(), hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipMemcpyAsync(d_pid, pid.data(), sizeof(uint32_t) * nu, hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipMemcpyAsync((void *)d_psrc, psrc.data(), sizeof(void *) * nu, hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipMemcpyAsync(d_porder, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice, s));
-        // The boxes inside a BLAS are padded for the object-space rays that will come: the slab test's error grows with the distance
-        // of the ray's origin, which in object space is the world's extent seen through the instance's inverse (a rigid pose: the
-        // world's own extent, as for the flattened tree).
-        float reach = 1.0f;
-        for (uint32_t i = 0; i < n; ++i) {
-            if (first2[i + 1] == first2[i]) continue;
-            const float *v = &t.h_inv[12 * (size_t)i];
-            float rown = 0.0f;
-            for (int rr = 0; rr < 3; ++rr) rown = std::max(rown, std::fabs(v[4 * rr]) + std::fabs(v[4 * rr + 1]) + std::fabs(v[4 * rr + 2]));
-            if (std::isfinite(rown)) reach = std::max(reach, rown * scene_scale);
-        }
-        t.built_reach = std::max(reach, obj_coord);
-        RefitArgs rp{};
-        rp.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); rp.node_stride = t.node_stride; rp.prims = reinterpret_cast<unsigned char *>(t.d_prims); rp.prim_stride = t.prim_stride;
-        rp.node_box = t.d_node_box; rp.node_ref = t.d_node_ref; rp.inst_xf = d_pxf; rp.inst_identity = d_pid; rp.inst_src = d_psrc; rp.order = d_porder;
-        rp.pad = 4e-6f * t.built_reach; rp.write_reference = 1u;
-        launch_refit_phases(rp, pack_phases, s);
-        HIP_TRY(ctx, hipGetLastError());
-        // (4) the top level
-        ra.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); ra.prims = reinterpret_cast<unsigned char *>(t.d_prims); ra.node_box = t.d_node_box; ra.node_ref = t.d_node_ref;
-        ra.inst_inv = t.d_inst_inv; ra.inst_root = t.d_inst_root;
-        for (size_t l = r.level_begin.size() - 1; l-- > 0;) t.phases.emplace_back(r.level_begin[l], r.level_begin[l + 1] - r.level_begin[l]);
-        launch_refit_phases(ra, t.phases, s);
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipStreamSynchronize(s));
-        if (ctx->build_verbose)
-            std::fprintf(stderr, "[hrt] two-level build: %u instances over %u BLASes -> %u top nodes (depth %u, %u split levels), %u BLAS nodes (depth <= %u), %u records (flattened: %u)\n",
-                         n2, nu, n_top, r.max_depth, r.split_levels, node_off[nu], blas_depth, n_rec, first[n]);
-        t.bvh = Bvh8();
-        t.two_level = true; t.n_top_nodes = n_top; t.n_unique_blas = nu;
-        t.n_nodes = n_all; t.n_prims = n_rec; t.max_depth = r.max_depth + 1u + blas_depth;
-        t.n_triangles = t.n_spheres = 0;
-        for (uint32_t j = 0; j < nu; ++j) { t.n_triangles += uniq[j]->tmpl.n_triangles; t.n_spheres += uniq[j]->tmpl.n_spheres; }
-        t.alloc_bytes = (uint64_t)t.node_stride * n_all + sizeof(float) * 8 * (uint64_t)n_all + (uint64_t)t.prim_stride * std::max(n_rec, 1u);
-        for (int a = 0; a < 3; ++a) { t.lo[a] = r.lo[a]; t.hi[a] = r.hi[a]; }
+        const int rc2 = build_two_level(ctx, t, inst, uniq, slot_of, first, scene_scale, ra, s);
+        if (rc2 != HRT_OK) return rc2;
     } else if (on_device) {
-        // ---- the device build (build.hip): topology and primitive ids; the refit below computes everything else ----
-        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_first, sizeof(uint32_t) * first.size()));
-        HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_inst_kind, sizeof(uint32_t) * std::max(n, 1u)));
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_first, first.data(), sizeof(uint32_t) * first.size(), hipMemcpyHostToDevice, s));
-        HIP_TRY(ctx, hipMemcpyAsync(t.d_inst_kind, t.kind.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
-        GpuBuildInput in{};
-        in.n_prims = first[n]; in.n_inst = n; in.d_inst_first = t.d_inst_first; in.d_inst_kind = t.d_inst_kind; in.d_inst_src = t.d_inst_src;
-        in.d_inst_xf = t.d_inst_xf; in.d_inst_identity = t.d_inst_identity;
-        in.max_leaf_prims = kMaxLeafPrims; in.width = (uint32_t)ctx->build_width; in.c_node = ctx->build_c_node; in.c_prim = scene_of_bodies ? ctx->build_c_prim_bodies : ctx->build_c_prim; in.ploc_radius = ctx->ploc_radius; in.quant_guard = ctx->quant_guard;
-        // the top-down phase always (object splits: what gives the tree its shape above the cells PLOC builds -- on the reference's kind of
-        // scene, separate bodies over a huge ground sphere, PLOC alone costs seven times the node visits); spatial splits under HRT_CTX_FAST_TRACE
-        in.split.enabled = device_split || ctx->build_topdown != 0; in.split.budget_frac = device_split ? ctx->split_budget : 0.0f; in.split.alpha = ctx->split_alpha; in.split.bias = ctx->split_bias; in.split.cut_bias = ctx->split_cut_bias;
-        in.split.cell_refs = (uint32_t)ctx->split_cell_refs; in.split.pad = ra.pad; in.split.verbose = ctx->build_verbose;
-        // worst-case node output (one node and two reference floats per leaf: primitive, or reference of a spatial split) at the front of the
-        // working memory; a split build's records and their clip boxes too (their number is known afterwards)
-        const size_t max_leaves = gpu_build_max_refs(in.n_prims, &in.split);
-        const size_t stage_nodes = ((size_t)t.node_stride * max_leaves + 255u) & ~(size_t)255u, stage_ref = (sizeof(float) * 2 * max_leaves + 255u) & ~(size_t)255u;
-        const size_t stage_prims = device_split ? ((size_t)t.prim_stride * max_leaves + 255u) & ~(size_t)255u : 0u, stage_clip = device_split ? (sizeof(float) * 6 * max_leaves + 255u) & ~(size_t)255u : 0u;
-        const size_t stage_all = stage_nodes + stage_ref + stage_prims + stage_clip, want = gpu_build_scratch_bytes(in.n_prims, &in.split) + stage_all;
-        ScratchArena arena = scratch_acquire(ctx, want);
-        if (!arena.p && in.split.enabled && !device_split) {      // no room for the top-down phase's buffers: PLOC alone
-            in.split.enabled = false;
-            arena = scratch_acquire(ctx, gpu_build_scratch_bytes(in.n_prims, nullptr) + stage_all);
-        }
-        if (!arena.p) return fail(ctx, HRT_ERR_OOM, "device build: no working memory (%zu bytes)", want);
-        struct Release { HrtContext *c; ScratchArena a; hipStream_t st; ~Release() { (void)hipStreamSynchronize(st); scratch_release(c, a); } } release{ctx, arena, s};      // (see ensure_template)
-        unsigned char *stage = static_cast<unsigned char *>(arena.p);
-        in.out_nodes = stage; in.node_stride = t.node_stride; in.out_node_ref = reinterpret_cast<float *>(stage + stage_nodes);
-        in.out_prims = device_split ? stage + stage_nodes + stage_ref : ra.prims; in.prim_stride = t.prim_stride;
-        in.out_clip = device_split ? reinterpret_cast<float *>(stage + stage_nodes + stage_ref + stage_prims) : nullptr;
-        in.scratch = stage + stage_all; in.scratch_bytes = arena.bytes - stage_all;
-        const GpuBuildResult r = gpu_build_bvh8(in, s);      // (synchronises the stream before it returns)
-        if (r.error != hipSuccess) return fail(ctx, r.error == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, "device build failed: %s (%s)", hipGetErrorString(r.error), r.where);
-        {   // the tree's own buffers, as large as the build turned out to need
-            const size_t nn = std::max<size_t>(r.n_prims ? r.n_nodes : 1u, 1u);
-            HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_nodes, (size_t)t.node_stride * nn));
-            HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_node_box, sizeof(float) * 6 * nn));
-            HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_node_ref, sizeof(float) * 2 * nn));
-            size_t rec_bytes = pb;
-            if (device_split) {
-                rec_bytes = (size_t)t.prim_stride * std::max<size_t>(r.n_records, 1);
-                HIP_TRY(ctx, pool_alloc(ctx, (void **)&t.d_prims, rec_bytes));
-                ra.prims = reinterpret_cast<unsigned char *>(t.d_prims);
-                if (r.n_records) HIP_TRY(ctx, hipMemcpyAsync(t.d_prims, in.out_prims, (size_t)t.prim_stride * r.n_records, hipMemcpyDeviceToDevice, s));
-            }
-            if (r.n_prims) {
-                HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, stage, (size_t)t.node_stride * nn, hipMemcpyDeviceToDevice, s));
-                HIP_TRY(ctx, hipMemcpyAsync(t.d_node_ref, in.out_node_ref, sizeof(float) * 2 * nn, hipMemcpyDeviceToDevice, s));
-                HIP_TRY(ctx, hipStreamSynchronize(s));         // the working memory goes back to the context when this scope ends
-            }
-            ra.nodes = reinterpret_cast<unsigned char *>(t.d_nodes); ra.node_box = t.d_node_box; ra.node_ref = t.d_node_ref;
-            t.alloc_bytes = (uint64_t)t.node_stride * nn + sizeof(float) * 8 * nn + rec_bytes;
-        }
-        t.bvh = Bvh8();
-        if (r.n_prims == 0u) {
-            // every primitive had non-finite bounds: the empty root (every ray misses)
-            build_bvh8({}, t.bvh, 1, scene_scale);
-            HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, t.bvh.nodes.data(), sizeof(Bvh8Node), hipMemcpyHostToDevice, s));
-            t.phases.clear();
-            t.n_nodes = 1; t.n_prims = 0; t.n_triangles = t.n_spheres = 0; t.max_depth = 0;
-        } else {
-            if (2 * r.max_depth + 2 > (uint32_t)(8 + 56)) return fail(ctx, HRT_ERR_INVALID, "BVH depth %u exceeds the traversal stack", r.max_depth);
-            for (size_t l = r.level_begin.size() - 1; l-- > 0;) t.phases.emplace_back(r.level_begin[l], r.level_begin[l + 1] - r.level_begin[l]);
-            // (a split build: every record's box is the one its cell is responsible for, not the primitive's -- this once; a later
-            // update would recompute the boxes from whole primitives, so the first update rebuilds instead: has_split_refs)
-            if (device_split && r.split_levels) { ra.clip = in.out_clip; t.has_split_refs = true; }
-            attach_rec_box(ctx, t, ra, r.n_records);
-            launch_refit_phases(ra, t.phases, s);
-            HIP_TRY(ctx, hipGetLastError());
-            if (device_split && r.split_levels) HIP_TRY(ctx, hipStreamSynchronize(s));      // (the clip boxes live in the working memory)
-            ra.clip = nullptr;
-            if (ctx->build_verbose)
-                std::fprintf(stderr, "[hrt] device build: %u primitives -> %u records, %u nodes, depth %u, %u PLOC rounds (radius %d), %u split levels, %u cells\n",
-                             r.n_prims, r.n_records, r.n_nodes, r.max_depth, r.ploc_rounds, ctx->ploc_radius, r.split_levels, r.n_cells);
-            const uint32_t dropped = first[n] - r.n_prims;      // non-finite primitives (counted against the triangles unless there are none)
-            t.n_nodes = r.n_nodes; t.n_prims = r.n_records; t.max_depth = r.max_depth;
-            t.n_triangles = n_tri_in >= dropped ? n_tri_in - dropped : 0u; t.n_spheres = r.n_prims - t.n_triangles;
-            for (int a = 0; a < 3; ++a) { t.lo[a] = r.lo[a]; t.hi[a] = r.hi[a]; }
-        }
+        const int rc2 = build_merged_on_device(ctx, t, first, device_split, scene_of_bodies, n_tri_in, scene_scale, pb, ra, s);
+        if (rc2 != HRT_OK) return rc2;
     } else {
         if (t.node_stride == sizeof(Bvh8Node) && t.prim_stride == sizeof(PrimRecord)) {
             HIP_TRY(ctx, hipMemcpyAsync(t.d_nodes, t.bvh.nodes.data(), nb, hipMemcpyHostToDevice, s));
