@@ -822,6 +822,10 @@ static inline float safe_rcp_dir(float d) {
     return 1.0f / dd;
 }
 
+/* (a what-if of tools/tree_quality.py --line-mates: node visits whose neighbour in the array, index ^ 1, the same ray had visited
+ * before -- what a 64-byte node, two to a 128-byte line, would save in line fetches) */
+static _Thread_local uint64_t tl_line_mates;
+
 /* one ray through a packed BVH8 (one- or two-level): the canonical closest hit (or any hit), and what the walk cost */
 static void bvh8_walk(const uint32_t *nodes, const void *prims_blob, const float *inst_inv, const uint32_t *inst_identity, f3 ow, f3 dw,
                       float tmin, float tmax, int any_hit, hit_rec *out, uint64_t *n_nodes, uint64_t *n_prims, uint64_t *n_empty) {
@@ -836,6 +840,7 @@ static void bvh8_walk(const uint32_t *nodes, const void *prims_blob, const float
     hit_rec best; best.hit = 0; best.t = tmax; best.u = best.v = 0.0f; best.prim = best.inst = 0xffffffffu;
     uint32_t stack_x[64], stack_y[64]; int sp = 0;
     uint32_t cur_x = 0, cur_y = 0x80000000u;
+    uint32_t seen[96]; int n_seen = 0;
     int done = 0;
     while (!done) {
         uint32_t tri_x = 0, tri_y = 0;
@@ -848,6 +853,8 @@ static void bvh8_walk(const uint32_t *nodes, const void *prims_blob, const float
             const uint32_t rel = (uint32_t)__builtin_popcount(hits_imask & ~(0xffffffffu << slot_index));
             const uint32_t *nd = nodes + 20 * (size_t)(cur_x + rel);
             ++tot_nodes;
+            for (int k = 0; k < n_seen; ++k) if (seen[k] == ((cur_x + rel) ^ 1u)) { ++tl_line_mates; break; }
+            if (n_seen < 96) seen[n_seen++] = cur_x + rel;
             const uint32_t e_imask = nd[3];
             if (e_imask == 0u) {
                 /* a transform node (two-level trees, csrc/bvh8.h): word 4 = root of the instance's BLAS, word 5 = instance,
@@ -926,19 +933,20 @@ void oracle_bvh8_trace(const void *nodes_blob, const void *prims_blob,
                        const float *origins, const float *dirs, uint32_t n_rays,
                        float tmin, float tmax, int any_hit,
                        float *t_out, float *u_out, float *v_out, uint32_t *prim_out, uint32_t *inst_out,
-                       uint64_t *out_counters /* [4]: node visits, prim tests, node visits that found nothing to enter or test, 0 */, uint32_t *per_ray_nodes /* or NULL */) {
-    uint64_t tot_nodes = 0, tot_prims = 0, tot_empty = 0;
-    #pragma omp parallel for schedule(dynamic, 256) reduction(+:tot_nodes, tot_prims, tot_empty)
+                       uint64_t *out_counters /* [4]: node visits, prim tests, node visits that found nothing to enter or test, line-mate visits */, uint32_t *per_ray_nodes /* or NULL */) {
+    uint64_t tot_nodes = 0, tot_prims = 0, tot_empty = 0, tot_mates = 0;
+    #pragma omp parallel for schedule(dynamic, 256) reduction(+:tot_nodes, tot_prims, tot_empty, tot_mates)
     for (long ri = 0; ri < (long)n_rays; ++ri) {
         hit_rec best; uint64_t nn = 0, np = 0, ne = 0;
+        tl_line_mates = 0;
         bvh8_walk((const uint32_t *)nodes_blob, prims_blob, inst_inv, inst_identity, mk3(origins[3 * ri], origins[3 * ri + 1], origins[3 * ri + 2]),
                   mk3(dirs[3 * ri], dirs[3 * ri + 1], dirs[3 * ri + 2]), tmin, tmax, any_hit, &best, &nn, &np, &ne);
-        tot_nodes += nn; tot_prims += np; tot_empty += ne;
+        tot_nodes += nn; tot_prims += np; tot_empty += ne; tot_mates += tl_line_mates;
         t_out[ri] = best.hit ? best.t : tmax; u_out[ri] = best.u; v_out[ri] = best.v;
         prim_out[ri] = best.hit ? best.prim : 0xffffffffu; inst_out[ri] = best.hit ? best.inst : 0xffffffffu;
         if (per_ray_nodes) per_ray_nodes[ri] = (uint32_t)nn;
     }
-    if (out_counters) { out_counters[0] = tot_nodes; out_counters[1] = tot_prims; out_counters[2] = tot_empty; out_counters[3] = 0; }
+    if (out_counters) { out_counters[0] = tot_nodes; out_counters[1] = tot_prims; out_counters[2] = tot_empty; out_counters[3] = tot_mates; }
 }
 
 /* ------------------------------------------------------------------------------------------

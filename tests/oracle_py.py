@@ -254,6 +254,7 @@ def bvh8_trace(nodes_ptr, prims_ptr, origins, directions, tmin=1e-6, tmax=1e16, 
     L.oracle_bvh8_trace(nodes_ptr, prims_ptr, _p(inst_inv), _p(inst_identity), _p(o), _p(d), n, tmin, tmax, int(any_hit),
                         _p(t), _p(u), _p(v), _p(prim), _p(inst), _p(cnt), _p(per_ray_nodes))
     bvh8_trace.last_empty_visits = int(cnt[2])       # node visits that found nothing to enter or test (tools/tree_quality.py)
+    bvh8_trace.last_line_mates = int(cnt[3])         # node visits whose array neighbour (index ^ 1) the ray had visited before
     return t, u, v, prim, inst, int(cnt[0]), int(cnt[1])
 
 

@@ -72,6 +72,11 @@ if __name__ == "__main__":
     knobs = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("HRT_"))
     print(f"{knobs or 'default':60s} build {secs:6.2f}s nodes {blob.n_nodes:8d} refs {blob.n_triangles:8d} | rays {len(o)} hits {hits} | "
           f"nodes/ray {nodes / len(o):6.3f} prims/ray {prims / len(o):6.3f} | est instr/ray {213 * nodes / len(o) + 83 * prims / len(o):7.1f}")
+    if "--line-mates" in sys.argv:
+        # what a 64-byte node would save: the L2s fetch 128-byte lines, so two 64-byte nodes share one, and a visit costs no new
+        # line when the same ray has been at the node's neighbour (the ray's own reuse only: an upper bound on the lines of a ray)
+        m = oracle_py.bvh8_trace.last_line_mates
+        print(f"  node visits {nodes / len(o):.2f} per ray, of which {m / len(o):.2f} ({100.0 * m / nodes:.1f} %) at the array neighbour of a node the ray visited before")
     if "--empty" in sys.argv:
         # what the visits are made of: visits that find nothing to enter or test, for miss rays, hit rays, and hit rays culled with
         # their final hit distance from the start (the best any traversal order could do)
