@@ -432,6 +432,30 @@ def main():
                 out["config"]["alt_builders"].append({"bvh_builder": label, "value": round(sa.rays / alt_dt / 1e6, 3), "unit": "Mrays/s", "steps": alt_steps,
                                                       "bvh_nodes": int(sa.bvh_nodes), "bvh_build_s": round(alt_build_s, 3)})
                 alt.close()
+        if world == 1 and not args.no_alt_builder:
+            # the same frame with HRT_CTX_REUSE_PRIMARY (include/hrt.h): a pixel's primary ray is traversed once per launch instead of
+            # once per sample -- the same image bit for bit in less time.  Its rays are the TRAVERSED ones only (a third fewer), so
+            # its Mrays/s is not this line's `value` and is not printed: the gain is the step time.
+            r.set_flags(0)
+            r.set_frame(W, H, hrt.scenes.SEED_SALT, aov=False)          # (the same RNG states for both)
+            r.render(min(spp, 8), tile=tile, sync=True)
+            without = r.color.clone()
+            r.set_flags(hrt.CTX_REUSE_PRIMARY)
+            r.set_frame(W, H, hrt.scenes.SEED_SALT, aov=False)
+            r.render(min(spp, 8), tile=tile, sync=True)
+            same = bool(torch.equal(without.view(torch.int32), r.color.view(torch.int32)))
+            r.reset_stats()
+            reuse_steps = max(1, min(args.steps, 3))
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reuse_steps):
+                r.render(spp, tile=tile, sync=False)
+            torch.cuda.synchronize(dev)
+            reuse_dt = time.perf_counter() - t0
+            sr = r.stats()
+            out["config"]["primary_reuse"] = {"flag": "HRT_CTX_REUSE_PRIMARY (off for `value`)", "steps": reuse_steps, "ms_per_step": round(reuse_dt / reuse_steps * 1e3, 3),
+                                              "ms_per_step_without": out["ms_per_step"], "traversed_rays_per_step": int(sr.rays // reuse_steps),
+                                              "paths_per_step": int(sr.paths // reuse_steps), "image_bit_identical_at_8spp": same}
         if not args.no_cpu_baseline and world == 1:             # the CPU leg is timed at N = 1 only
             r.set_flags(0)                                      # production kernels for the parity render
             out["cpu_baseline"], out["parity"] = cpu_baseline(hrt, scene, args.cpu_seconds, r)

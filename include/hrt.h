@@ -63,6 +63,12 @@ typedef struct HrtContext HrtContext;
                                     oracle's INSTANCED mode (object-space triangle test), those of a flattened tree to its FLATTENED mode: the two
                                     differ in rounding, not in geometry.  Trees too deep for the path kernel's stack, and contexts that count
                                     (HRT_CTX_COUNT) or run another execution mode (HRT_FUSED != 1), flatten. */
+#define HRT_CTX_REUSE_PRIMARY 0x20u /* hrt_render_launch with spp > 1: the reference's raygen has no pixel jitter (shader/Shader.cu:249-261), so a pixel's
+                                    primary ray hits the same thing in every sample.  With this flag (or HRT_REUSE_PRIMARY=1) the path kernel traverses it for
+                                    the first sample a launch takes of the pixel and shades the later samples from that hit record: the same image bit
+                                    for bit, a third fewer rays on the reference's scenes.  HrtStats.rays counts TRAVERSED rays only, so Mrays/s figures
+                                    with and without the flag are not comparable -- compare times.  Off by default (all published figures are without);
+                                    ignored by the other execution modes (HRT_FUSED != 1, HRT_CTX_COUNT). */
 #define HRT_CTX_FAST_TRACE 0x4u  /* hrt_tlas_build prefers trace speed to build speed: the reference's OPTIX_BUILD_FLAG_PREFER_FAST_TRACE
                                     (its GAS builds, RendererImpl.cu:94,118,144).  The tree is then built WITH SPATIAL SPLITS: on the device
                                     (csrc/build_split.hip: top-down SAH splits of references level by level, PLOC within the cells that
@@ -77,7 +83,7 @@ typedef struct HrtContext HrtContext;
 /* replaces createContext / destroyContext, src/Global/RendererImpl.cu:6-27 */
 int  hrt_ctx_create(int device_id, uint32_t flags, HrtContext **out_ctx);
 int  hrt_ctx_destroy(HrtContext *ctx);
-int  hrt_ctx_set_flags(HrtContext *ctx, uint32_t flags);   /* switch HRT_CTX_TIMING / HRT_CTX_COUNT at run time */
+int  hrt_ctx_set_flags(HrtContext *ctx, uint32_t flags);   /* switch HRT_CTX_TIMING / HRT_CTX_COUNT / HRT_CTX_REUSE_PRIMARY at run time */
 const char *hrt_last_error(const HrtContext *ctx);        /* ctx may be NULL: creation errors */
 const char *hrt_version(void);
 

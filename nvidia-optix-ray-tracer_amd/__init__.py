@@ -92,7 +92,7 @@ assert C.sizeof(GlobalParams) == 16 and C.sizeof(RayGenParams) == 80 and C.sizeo
 assert C.sizeof(HitGroupParams) == 32 and C.sizeof(SbtRecord) == 64 and C.sizeof(Instance) == 80
 
 PROGRAM_SPHERE_ROUGH, PROGRAM_SPHERE_METAL, PROGRAM_TRIANGLE_ROUGH, PROGRAM_TRIANGLE_METAL = range(4)
-CTX_TIMING, CTX_COUNT, CTX_FAST_TRACE, CTX_ASYNC_UPDATE, CTX_TWO_LEVEL = 1, 2, 4, 8, 16
+CTX_TIMING, CTX_COUNT, CTX_FAST_TRACE, CTX_ASYNC_UPDATE, CTX_TWO_LEVEL, CTX_REUSE_PRIMARY = 1, 2, 4, 8, 16, 32
 
 # every symbol include/hrt.h declares (checked by the CPU test-suite)
 EXPORTS = [

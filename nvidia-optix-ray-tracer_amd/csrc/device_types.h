@@ -69,6 +69,7 @@ struct PathArgs {
     uint64_t *rays_closest, *rays_any;
     const RayRec *trace_rays;      // fused kernel as hrt_trace_rays: the "pixels" are these rays, traced once; results below (else NULL)
     float4 *trace_tuvp; uint32_t *trace_inst; uint32_t trace_any;
+    float4 *primary_cache;         // k_fused<.., REUSE>: two float4 per lane of the grid, the primary hit of the lane's pixel (else NULL)
 };
 
 struct TraverseArgs {

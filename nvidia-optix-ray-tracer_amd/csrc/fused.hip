@@ -44,7 +44,11 @@ struct NoInstLane { static constexpr uint32_t inst_cur = 0u; };
 // held (`base` = the frame's bottom), so the bookkeeping sequence is the one-level kernel's, unchanged.  When it reports the frame
 // empty the lane takes its world ray back and pops what it had left in world space.  A separate instantiation: the one-level kernels
 // and their register budget are untouched.
-template <bool HAS_SPHERES, bool INSTANCED>
+// REUSE (HRT_CTX_REUSE_PRIMARY): the reference's raygen has no pixel jitter (Shader.cu:249-261), so the primary ray of a pixel -- and its
+// hit -- is the same for every sample.  The first sample a launch takes of a pixel traces it and leaves the hit record in the lane's slot of
+// `primary_cache`; the later ones are shaded from there (same record, same shading, same random numbers: the same bits) and only their
+// bounces are traversed.  Rays that are not traversed are not counted.  A separate instantiation, like INSTANCED.
+template <bool HAS_SPHERES, bool INSTANCED, bool REUSE>
 #ifndef HRT_FUSED_WAVES_PER_SIMD
 #define HRT_FUSED_WAVES_PER_SIMD 4      // 128 VGPRs, a dozen kernel constants spilled; 5 waves (96 VGPRs, 95 spilled around the shading): 2560 against 3122 Mrays/s
 #endif
@@ -100,6 +104,8 @@ __global__ __launch_bounds__(kTraverseBlock, INSTANCED ? HRT_INST_WAVES_PER_SIMD
     uint32_t wbeg = 0, wend = 0, kstart = 0;
     const uint32_t home_shard = blockIdx.x & (kFetchShards - 1);
 
+    [[maybe_unused]] bool force_regen = false;      // (REUSE, wave-uniform)
+    [[maybe_unused]] bool cached = false;           // (REUSE) this lane waits to be shaded with its pixel's cached primary hit
     for (;;) {
         const uint64_t idle = __ballot(!alive);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -107,20 +113,37 @@ __global__ __launch_bounds__(kTraverseBlock, INSTANCED ? HRT_INST_WAVES_PER_SIMD
         // (once the tile is used up the lanes without a pixel stay idle and the render ends with the slowest pixels' sample chains:
         // what counts then is how soon a finished ray's successor starts, against what a regeneration costs the rays still under
         // way -- a dozen waiting rays, or nothing else left to do: 1/8 of the C4 frame 142 ms with 1, 129 ms with 8 to 16)
-        if (idle == ~0ull || (exhausted ? (uint32_t)__popcll(__ballot(waiting)) >= (uint32_t)a.tail_regen : n_idle >= (uint32_t)a.refill_threshold)) {
+        if (force_regen || idle == ~0ull || (exhausted ? (uint32_t)__popcll(__ballot(waiting)) >= (uint32_t)a.tail_regen : n_idle >= (uint32_t)a.refill_threshold)) {
 #ifdef HRT_LANE_STATS
             ++ls_regen;
 #endif
             __builtin_amdgcn_s_setprio(HRT_PRIO_REGEN);
             bool launch = false, want_primary = false;      // launch: this lane starts the ray (ro, rd) below
+            [[maybe_unused]] bool reshade = false;
+            [[maybe_unused]] const bool was_forced = force_regen;
+            force_regen = false;
             V3 ro = mk3(0.0f, 0.0f, 0.0f), rd = mk3(0.0f, 0.0f, 1.0f);
             if (!alive && waiting) {
                 waiting = false;
                 const TravState &s = L.s;
-                const bool miss = s.bprim == kMissPrim;
+                // the finished ray and what it hit
+                V3 o = mk3(s.ox, s.oy, s.oz), d = mk3(s.dx, s.dy, s.dz);
+                float bt = s.bt, bu = s.bu, bv = s.bv; uint32_t bprim = s.bprim, binst = s.binst;
+                if constexpr (REUSE) {
+                    float4 *slot = a.path.primary_cache + 2u * (blockIdx.x * kTraverseBlock + tx);
+                    if (cached) {                   // ... or, for a primary ray that was not traversed again, what the pixel's first sample found
+                        const float4 c0 = slot[0]; const float4 c1 = slot[1];
+                        o = mk3(a.path.center[0], a.path.center[1], a.path.center[2]); d = mk3(px_pdx, px_pdy, px_pdz);
+                        bt = c0.x; bu = c0.y; bv = c0.z; bprim = __float_as_uint(c0.w); binst = __float_as_uint(c1.x);
+                        cached = false;
+                    } else if (!a.path.trace_rays && px_depth == 1u && px_sample == 0u) {      // the primary hit of the pixel's first sample in this launch
+                        slot[0] = make_float4(bt, bu, bv, __uint_as_float(bprim)); slot[1] = make_float4(__uint_as_float(binst), 0.0f, 0.0f, 0.0f);
+                    }
+                }
+                const bool miss = bprim == kMissPrim;
                 if (a.path.trace_rays) {           // hrt_trace_rays on this kernel: the "pixel" is a caller's ray, its hit record the result
-                    a.path.trace_tuvp[px_local] = make_float4(s.bt, s.bu, s.bv, __uint_as_float(s.bprim));
-                    a.path.trace_inst[px_local] = s.binst;
+                    a.path.trace_tuvp[px_local] = make_float4(bt, bu, bv, __uint_as_float(bprim));
+                    a.path.trace_inst[px_local] = binst;
                     have_pixel = false;
                 } else if (miss || px_depth >= kRayTraceDepth) {
                     // the path ends: miss colour or black at the depth limit, folded through the albedo chain (Shader.cu:102-107, :236-238, :276-287)
@@ -128,6 +151,11 @@ __global__ __launch_bounds__(kTraverseBlock, INSTANCED ? HRT_INST_WAVES_PER_SIMD
                     if (px_first) { px_ax = r.x; px_ay = r.y; px_az = r.z; px_first = false; }
                     else { px_ax += r.x; px_ay += r.y; px_az += r.z; }
                     ++px_sample;
+                    if constexpr (REUSE) {
+                        // a primary ray that leaves the scene: every sample of the pixel is the background colour, added one by one
+                        if (miss && px_depth == 1u && !a.path.slice_cost)
+                            for (; px_sample < a.path.spp; ++px_sample) { px_ax += r.x; px_ay += r.y; px_az += r.z; }
+                    }
                     if (a.path.slice_cost)     // probe launch: how long this pixel's sample took, start of its primary ray to here
                         atomicAdd(a.path.slice_cost + px_local / a.fetch_chunk, ((uint32_t)__builtin_amdgcn_s_memtime() - px_t0) >> 4);
                     if (px_sample >= a.path.spp) {
@@ -136,12 +164,11 @@ __global__ __launch_bounds__(kTraverseBlock, INSTANCED ? HRT_INST_WAVES_PER_SIMD
                         have_pixel = false;
                     } else want_primary = true;
                 } else {
-                    const uint32_t inst = s.binst;
+                    const uint32_t inst = binst;
                     const HitGroup hg = a.path.hitgroups[inst];
                     const uint32_t program = a.path.inst_program[inst];
-                    const V3 o = mk3(s.ox, s.oy, s.oz), d = mk3(s.dx, s.dy, s.dz);
                     V3 hp, nd;
-                    scatter_programs<HAS_SPHERES>(program, hg, o, d, s.bt, s.bu, s.bv, s.bprim, px_rng, hp, nd);
+                    scatter_programs<HAS_SPHERES>(program, hg, o, d, bt, bu, bv, bprim, px_rng, hp, nd);
                     px_chain[px_depth - 1u] = inst;
                     ++px_depth;
                     ro = hp; rd = nd; launch = true;
@@ -197,11 +224,16 @@ __global__ __launch_bounds__(kTraverseBlock, INSTANCED ? HRT_INST_WAVES_PER_SIMD
                     const RayRec r = a.path.trace_rays[px_local];
                     px_depth = a.path.trace_any ? kRayTraceDepth : 1u;      // any-hit queries take the depth-limit ray's early exit
                     ro = mk3(r.o.x, r.o.y, r.o.z); rd = mk3(r.d.x, r.d.y, r.d.z);
+                    launch = true;
                 } else {
                     px_depth = 1u;
                     ro = mk3(a.path.center[0], a.path.center[1], a.path.center[2]); rd = mk3(px_pdx, px_pdy, px_pdz);
+                    launch = true;
+                    if constexpr (REUSE) {
+                        // not traversed again: the lane waits for its shading as if the ray had just finished (the hit is in the cache)
+                        if (px_sample > 0u) { launch = false; waiting = true; cached = true; reshade = true; }
+                    }
                 }
-                launch = true;
             }
             if (launch) {
                 any = px_depth >= kRayTraceDepth;      // a hit at the depth limit is black whatever it is (Shader.cu:102-107)
@@ -210,8 +242,13 @@ __global__ __launch_bounds__(kTraverseBlock, INSTANCED ? HRT_INST_WAVES_PER_SIMD
                 if constexpr (INSTANCED) I.inst_cur = kNoWork;      // (an any-hit ray may have ended inside an instance)
                 alive = true;
             }
+            // REUSE: lanes that have just taken their primary hit from the cache are shaded in a second regeneration, at once, so that
+            // their bounces start together with the other lanes' rays (one extra round, not more: the others are waiting)
+            if constexpr (REUSE) { if (!was_forced && __ballot(reshade) != 0ull) { force_regen = true; continue; } }
         }
-        if (__ballot(alive) == 0ull) break;     // the tile is used up and every lane has finished (nothing waits after a full regeneration)
+        // the tile is used up and every lane has finished (nothing waits after a full regeneration -- but, REUSE, a lane with a cached hit to shade:
+        // an empty pass through the loop below brings it back here)
+        if (__ballot(REUSE ? alive || waiting : alive) == 0ull) break;
 
         // ---- traverse until enough lanes have finished to make a regeneration worthwhile ----
         // Two copies of the loop: the second one, with tail splitting and the drained phase's exit rule, runs once the tile is used
@@ -436,14 +473,20 @@ __global__ __launch_bounds__(kTraverseBlock, INSTANCED ? HRT_INST_WAVES_PER_SIMD
 // one launch renders every sample of every pixel of the tile
 void launch_fused(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s) {
     const dim3 g(grid_blocks), b(kTraverseBlock);
-    if (has_spheres) hipLaunchKernelGGL((k_fused<true, false>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_fused<false, false>), g, b, 0, s, a);
+    const bool reuse = a.path.primary_cache != nullptr;
+    if (has_spheres && reuse) hipLaunchKernelGGL((k_fused<true, false, true>), g, b, 0, s, a);
+    else if (has_spheres) hipLaunchKernelGGL((k_fused<true, false, false>), g, b, 0, s, a);
+    else if (reuse) hipLaunchKernelGGL((k_fused<false, false, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_fused<false, false, false>), g, b, 0, s, a);
 }
 // ... through a two-level tree (transform nodes over shared BLASes)
 void launch_fused_instanced(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s) {
     const dim3 g(grid_blocks), b(kTraverseBlock);
-    if (has_spheres) hipLaunchKernelGGL((k_fused<true, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_fused<false, true>), g, b, 0, s, a);
+    const bool reuse = a.path.primary_cache != nullptr;
+    if (has_spheres && reuse) hipLaunchKernelGGL((k_fused<true, true, true>), g, b, 0, s, a);
+    else if (has_spheres) hipLaunchKernelGGL((k_fused<true, true, false>), g, b, 0, s, a);
+    else if (reuse) hipLaunchKernelGGL((k_fused<false, true, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_fused<false, true, false>), g, b, 0, s, a);
 }
 
 }  // namespace hrt

@@ -168,7 +168,7 @@ int hrt_ctx_destroy(HrtContext *ctx) {
         void *sp[] = {st.rays[0], st.rays[1], st.hit_tuvp, st.hit_inst, st.bin_items, st.chain, st.result, st.stages};
         for (void *p : sp) if (p) (void)hipFree(p);
     }
-    void *ptrs[] = {w.accum, w.slice_cost, w.slice_order, w.rows, ctx->d_jump, ctx->d_stats, ctx->d_hitgroups, ctx->d_inst_program};
+    void *ptrs[] = {w.accum, w.slice_cost, w.slice_order, w.primary_cache, w.rows, ctx->d_jump, ctx->d_stats, ctx->d_hitgroups, ctx->d_inst_program};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (const ScratchArena &a : ctx->scratch_free) (void)hipFree(a.p);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -319,6 +319,16 @@ static int render_fused(const LaunchFrame &f) {
     }
     const uint32_t grid = std::min<uint32_t>((uint32_t)ctx->n_cu * blocks_per_cu, (n + 63u) / 64u);
     if (t->two_level) ta.tail_split = 0;        // (the pieces of a split ray would have to carry the instance they are in)
+    // HRT_CTX_REUSE_PRIMARY: the lanes' slots for their pixels' primary hits (k_fused<.., REUSE>, fused.hip)
+    if (lean && spp > 1u && ((ctx->flags & HRT_CTX_REUSE_PRIMARY) != 0u || ctx->reuse_primary)) {
+        if (grid * 64u > w.primary_cache_lanes) {
+            if (w.primary_cache) (void)hipFree(w.primary_cache);
+            w.primary_cache = nullptr; w.primary_cache_lanes = 0;
+            HIP_TRY(ctx, hipMalloc((void **)&w.primary_cache, sizeof(float4) * 2u * grid * 64u));
+            w.primary_cache_lanes = grid * 64u;
+        }
+        pa.primary_cache = w.primary_cache;
+    }
     auto launch = [&]() {
         if (lean && t->two_level) launch_fused_instanced(ta, t->has_spheres, grid, s);
         else if (lean) launch_fused(ta, t->has_spheres, grid, s);

@@ -111,6 +111,7 @@ struct Workspace {
     float4 *accum = nullptr;
     uint32_t *rows = nullptr;
     uint32_t *slice_cost = nullptr, *slice_order = nullptr; uint32_t slice_capacity = 0;   // fused mode: cost-ordered slices
+    float4 *primary_cache = nullptr; uint32_t primary_cache_lanes = 0;                     // HRT_CTX_REUSE_PRIMARY: two float4 per lane of the path kernel's grid
 };
 
 struct TimedSpan { int kind; hipEvent_t a, b; };
@@ -178,6 +179,7 @@ struct HrtContext {
                                                 // (32 M triangles: +3.4 %, 8 M: +1 %, C4: -3 %; profiles/r03_large_scenes_node_stride.txt)
     int fused = 1;                              // 1: fused persistent path kernel k_fused (default), 2: round 1's fused kernel, 0: wavefront kernels, -1: fused only for small tiles
     int fused_max_pixels = 700000;
+    bool reuse_primary = false;                 // HRT_REUSE_PRIMARY: every launch as under HRT_CTX_REUSE_PRIMARY
     int fused_lpt = 2;                          // samples of the probe launch that orders the slices by cost for the rest of the render (0: off)
     int fused_max_spp = 512;                    // samples per fused launch
     int lds_gather = 0;                         // 1: cooperative LDS-DMA gathers, 0: per-lane register loads
