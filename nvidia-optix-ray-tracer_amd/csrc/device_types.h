@@ -200,6 +200,8 @@ void launch_traverse(const TraverseArgs &a, bool count, bool has_spheres, bool d
 void launch_paths_v1(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s);   // round 1's fused kernel k_traverse<.., FUSED> (HRT_FUSED=2)
 constexpr int kFusedBlocksPerCu = 16;  // k_fused is compiled for 4 waves per SIMD (125 VGPRs, nothing spilled): more workgroups per CU would only queue
 constexpr int kFusedInstancedBlocksPerCu = 12;   // k_fused<.., INSTANCED> is compiled for 3 waves per SIMD (fused.hip)
+constexpr uint32_t kFetchShards = 8;         // slice counters (one per XCD-group of blocks)
+constexpr uint32_t kFetchShardStride = 32;   // u32s between counters: one 128-byte line each
 constexpr int kFusedMaxDepth = 12;     // deepest tree (levels below the root) k_fused takes: its per-lane node stack in LDS (trav_lean.h: kNodeStackLds)
 void launch_fused(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s);
 void launch_fused_instanced(const TraverseArgs &a, bool has_spheres, uint32_t grid_blocks, hipStream_t s);      // two-level trees (transform nodes, bvh8.h)

@@ -202,8 +202,6 @@ __device__ __forceinline__ V3 fold_chain(bool miss, const float *bg, const uint3
 constexpr int kLdsStack = 8;          // entries per lane staged in LDS
 constexpr int kSpillStack = 56;       // overflow entries per lane in scratch
 constexpr int kTraverseBlock = 64;         // one wave per workgroup
-constexpr uint32_t kFetchShards = 8;         // slice counters (one per XCD-group of blocks)
-constexpr uint32_t kFetchShardStride = 32;   // u32s between counters: one 128-byte line each
 
 struct TravState {
     float ox, oy, oz, dx, dy, dz;
