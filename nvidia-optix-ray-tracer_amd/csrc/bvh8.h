@@ -15,6 +15,8 @@
 //
 //   Transform node of a TWO-LEVEL tree (same 80 B, in the child block of its parent like any inner child): word 3 == 0 marks it
 //   (a box node's exponents are never 0).  The instance's BLAS -- an object-space BVH8 shared by every instance of it -- hangs below:
+//     word 0-2  centre of the BLAS's bounding sphere, object space     (a ray that misses the sphere does not go in: half of those that
+//     word 7    its radius (negative: none)                             cross the instance's box in the top level do, fused.hip)
 //     word 4    index of the BLAS's root node (in the same node array)
 //     word 5    instance index (= what a hit reports, and the SBT offset's key)
 //     word 6    1 when the transform is the identity (the ray is then copied, not multiplied)

@@ -35,6 +35,9 @@ namespace hrt {
 #define HRT_PRIO_REGEN 2     // shading, next pixel, new ray
 #endif
 
+#ifndef HRT_SPHERE_CULL
+#define HRT_SPHERE_CULL 1     // INSTANCED: a ray that misses an instance's bounding sphere does not enter it (0: enters every instance whose box it crosses)
+#endif
 struct InstLane { uint32_t inst_cur = kNoWork, frame = 0u; };
 struct NoInstLane { static constexpr uint32_t inst_cur = 0u; };
 
@@ -64,6 +67,9 @@ __global__ __launch_bounds__(kTraverseBlock, INSTANCED ? HRT_INST_WAVES_PER_SIMD
     __shared__ float s_mb_t[kTraverseBlock], s_mb_u[kTraverseBlock], s_mb_v[kTraverseBlock];
     __shared__ uint32_t s_mb_prim[kTraverseBlock], s_mb_inst[kTraverseBlock], s_mb_pending[kTraverseBlock];
     __shared__ uint32_t s_pair[kTraverseBlock];
+    // INSTANCED: the rest of a world ray that waits while its lane is inside an instance (reciprocals, octant)
+    __shared__ float s_park_idx[kTraverseBlock], s_park_idy[kTraverseBlock], s_park_idz[kTraverseBlock];
+    __shared__ uint32_t s_park_oct[kTraverseBlock];
 
     const uint32_t n_pixels = a.path.n_tile_pixels;
     const char *__restrict__ node_bytes = reinterpret_cast<const char *>(a.nodes);
@@ -369,27 +375,45 @@ __global__ __launch_bounds__(kTraverseBlock, INSTANCED ? HRT_INST_WAVES_PER_SIMD
                     enter = L.nidx != kNoWork && !hit_any && rn0.w == 0u;          // a transform node: word 3 == 0
                     if (L.nidx != kNoWork && !hit_any && !enter) lean_node(L.s, tmin, rn0, rn1, rn2, rn3, rn4, child, tri);
                     if (__ballot(enter) != 0ull) {
-    #ifdef HRT_LANE_STATS
-                        ls_enter += __popcll(__ballot(enter));
-    #endif
+                        float ox = L.s.ox, oy = L.s.oy, oz = L.s.oz, dx = L.s.dx, dy = L.s.dy, dz = L.s.dz;      // the ray in the instance's object space
                         if (enter) {
-                            TravState &s = L.s;
-                            s_mb_t[tx] = s.ox; s_mb_u[tx] = s.oy; s_mb_v[tx] = s.oz;
-                            s_mb_prim[tx] = __float_as_uint(s.dx); s_mb_inst[tx] = __float_as_uint(s.dy); s_mb_pending[tx] = __float_as_uint(s.dz);
-                            I.inst_cur = rn1.y;
+                            const TravState &s = L.s;
                             if (rn1.z == 0u) {          // not the identity: xf_point / xf_vector of the oracle, operation for operation
                                 const float m0 = __uint_as_float(rn2.x), m1 = __uint_as_float(rn2.y), m2 = __uint_as_float(rn2.z), m3 = __uint_as_float(rn2.w);
                                 const float m4 = __uint_as_float(rn3.x), m5 = __uint_as_float(rn3.y), m6 = __uint_as_float(rn3.z), m7 = __uint_as_float(rn3.w);
                                 const float m8 = __uint_as_float(rn4.x), m9 = __uint_as_float(rn4.y), m10 = __uint_as_float(rn4.z), m11 = __uint_as_float(rn4.w);
-                                const float ox = s.ox, oy = s.oy, oz = s.oz, dx = s.dx, dy = s.dy, dz = s.dz;
-                                s.ox = ((m0 * ox + m1 * oy) + m2 * oz) + m3; s.oy = ((m4 * ox + m5 * oy) + m6 * oz) + m7; s.oz = ((m8 * ox + m9 * oy) + m10 * oz) + m11;
-                                s.dx = (m0 * dx + m1 * dy) + m2 * dz; s.dy = (m4 * dx + m5 * dy) + m6 * dz; s.dz = (m8 * dx + m9 * dy) + m10 * dz;
+                                ox = ((m0 * s.ox + m1 * s.oy) + m2 * s.oz) + m3; oy = ((m4 * s.ox + m5 * s.oy) + m6 * s.oz) + m7; oz = ((m8 * s.ox + m9 * s.oy) + m10 * s.oz) + m11;
+                                dx = (m0 * s.dx + m1 * s.dy) + m2 * s.dz; dy = (m4 * s.dx + m5 * s.dy) + m6 * s.dz; dz = (m8 * s.dx + m9 * s.dy) + m10 * s.dz;
                             }
-                            s.idx = safe_rcp_dir<false>(s.dx); s.idy = safe_rcp_dir<false>(s.dy); s.idz = safe_rcp_dir<false>(s.dz);
-                            const uint32_t oct = (s.dx < 0.0f ? 4u : 0u) | (s.dy < 0.0f ? 2u : 0u) | (s.dz < 0.0f ? 1u : 0u);
+                            // The object-space ray against the BLAS's bounding sphere (words 0-2: centre, word 7: radius, negative: none) -- the
+                            // instance's box in the top level is the box of that sphere under a rotation nobody knows in advance, and half the rays
+                            // that cross such a box miss the sphere.  Culling only, with slack for the rounding of every term: misses the line of
+                            // the ray by more than the radius, or starts outside and points away.
+                            const float R = __uint_as_float(rn1.w);
+                            const float cx = ox - __uint_as_float(rn0.x), cy = oy - __uint_as_float(rn0.y), cz = oz - __uint_as_float(rn0.z);
+                            const float cc = fmaf(cx, cx, fmaf(cy, cy, cz * cz)), aa = fmaf(dx, dx, fmaf(dy, dy, dz * dz)), b = fmaf(cx, dx, fmaf(cy, dy, cz * dz));
+                            const float R2 = R * R * 1.0001f, ca = cc * aa;
+                            // (branch-free on purpose, & and | instead of && and ||: with a branch on R >= 0 inside this block hipcc 7.2 carries child.x and
+                            // I.inst_cur of the block below through the registers it also uses for cc and b here, and the lanes that took the branch
+                            // entered node 0 instead of their BLAS, for ever -- found in the ISA, tools/debug_two_level.py)
+                            const bool beside = fmaf(-b, b, ca) > fmaf(R2, aa, 4e-6f * ca), behind = (b > 0.0f) & (cc > fmaf(4e-6f, cc, R2));
+                            if (HRT_SPHERE_CULL && ((R >= 0.0f) & (beside | behind))) enter = false;
+                        }
+                        if (enter) {
+                            TravState &s = L.s;
+                            s_mb_t[tx] = s.ox; s_mb_u[tx] = s.oy; s_mb_v[tx] = s.oz;
+                            s_mb_prim[tx] = __float_as_uint(s.dx); s_mb_inst[tx] = __float_as_uint(s.dy); s_mb_pending[tx] = __float_as_uint(s.dz);
+                            s_park_idx[tx] = s.idx; s_park_idy[tx] = s.idy; s_park_idz[tx] = s.idz; s_park_oct[tx] = s.oct_inv4;
+                            I.inst_cur = rn1.y;
+                            s.ox = ox; s.oy = oy; s.oz = oz; s.dx = dx; s.dy = dy; s.dz = dz;
+                            s.idx = safe_rcp_dir<false>(dx); s.idy = safe_rcp_dir<false>(dy); s.idz = safe_rcp_dir<false>(dz);
+                            const uint32_t oct = (dx < 0.0f ? 4u : 0u) | (dy < 0.0f ? 2u : 0u) | (dz < 0.0f ? 1u : 0u);
                             s.oct_inv4 = (7u - oct) * 0x01010101u;
                             child = make_uint2(rn1.x, 0x01000000u);      // one child, no inner-mask bits: the pick below is child base + 0 = the BLAS's root
                         }
+    #ifdef HRT_LANE_STATS
+                        ls_enter += __popcll(__ballot(enter));
+    #endif
                     }
                 }
                 // ---- B. bookkeeping (trav_lean.h: one hand-written sequence): file the new groups; the leaf pass (ONE per iteration, one
@@ -421,9 +445,7 @@ __global__ __launch_bounds__(kTraverseBlock, INSTANCED ? HRT_INST_WAVES_PER_SIMD
                             TravState &s = L.s;
                             s.ox = s_mb_t[tx]; s.oy = s_mb_u[tx]; s.oz = s_mb_v[tx];
                             s.dx = __uint_as_float(s_mb_prim[tx]); s.dy = __uint_as_float(s_mb_inst[tx]); s.dz = __uint_as_float(s_mb_pending[tx]);
-                            s.idx = safe_rcp_dir<false>(s.dx); s.idy = safe_rcp_dir<false>(s.dy); s.idz = safe_rcp_dir<false>(s.dz);
-                            const uint32_t oct = (s.dx < 0.0f ? 4u : 0u) | (s.dy < 0.0f ? 2u : 0u) | (s.dz < 0.0f ? 1u : 0u);
-                            s.oct_inv4 = (7u - oct) * 0x01010101u;
+                            s.idx = s_park_idx[tx]; s.idy = s_park_idy[tx]; s.idz = s_park_idz[tx]; s.oct_inv4 = s_park_oct[tx];
                             I.inst_cur = kNoWork;
                             L.base = (int)(I.frame & 0xffu); L.nsp = (int)(I.frame >> 8);
                             if (L.nsp != L.base) { --L.nsp; s.cur = s_nodes[L.nsp][lane]; }      // (only groups with hits are ever pushed)

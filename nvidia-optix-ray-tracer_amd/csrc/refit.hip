@@ -133,6 +133,10 @@ __device__ __forceinline__ void refit_slot(const RefitArgs &a, uint32_t node, ui
         const float *inv = a.inst_inv + 12 * (size_t)inst;
         float *pf = reinterpret_cast<float *>(nd);
         for (int k = 0; k < 12; ++k) pf[8 + k] = inv[k];
+        {   // the BLAS's bounding sphere in object space: what a ray is tested against before it goes in (fused.hip)
+            const float *b10 = reinterpret_cast<const float *>(a.inst_src[inst]);
+            pf[0] = b10[6]; pf[1] = b10[7]; pf[2] = b10[8]; pf[7] = b10[9];
+        }
         if (ok) {
             float2 *ref = reinterpret_cast<float2 *>(a.node_ref) + node;
             const float plo[3] = {nlo[0] - pad, nlo[1] - pad, nlo[2] - pad}, phi[3] = {nhi[0] + pad, nhi[1] + pad, nhi[2] + pad};

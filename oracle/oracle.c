@@ -860,9 +860,19 @@ static void bvh8_walk(const uint32_t *nodes, const void *prims_blob, const float
                 /* a transform node (two-level trees, csrc/bvh8.h): word 4 = root of the instance's BLAS, word 5 = instance,
                  * word 6 = identity flag, words 8..19 = world -> object.  The ray goes into object space; a marker on the stack
                  * brings the world ray back when the BLAS has been walked. */
+                f3 oo = ow, od = dw;
+                if (!nd[6]) { const float *m = (const float *)(nd + 8); oo = xf_point(m, ow); od = xf_vector(m, dw); }
+                {   /* words 0-2, 7: the BLAS's bounding sphere in object space (negative radius: none); a ray that misses it does not go in.
+                     * Culling only -- the same conservative test as the kernel's (csrc/fused.hip), so that the visit counts agree. */
+                    float c[3], R; memcpy(c, nd, 12); memcpy(&R, nd + 7, 4);
+                    const float cx = oo.x - c[0], cy = oo.y - c[1], cz = oo.z - c[2];
+                    const float cc = fmaf(cx, cx, fmaf(cy, cy, cz * cz)), aa = fmaf(od.x, od.x, fmaf(od.y, od.y, od.z * od.z)), b = fmaf(cx, od.x, fmaf(cy, od.y, cz * od.z));
+                    const float R2 = R * R * 1.0001f, ca = cc * aa;
+                    if (R >= 0.0f && (fmaf(-b, b, ca) > fmaf(R2, aa, 4e-6f * ca) || (b > 0.0f && cc > fmaf(4e-6f, cc, R2)))) continue;
+                }
                 stack_x[sp] = 0xffffffffu; stack_y[sp] = 0u; ++sp;
                 cur_inst = nd[5];
-                if (!nd[6]) { const float *m = (const float *)(nd + 8); o = xf_point(m, ow); d = xf_vector(m, dw); }
+                o = oo; d = od;
                 idx = safe_rcp_dir(d.x); idy = safe_rcp_dir(d.y); idz = safe_rcp_dir(d.z);
                 oct = (d.x < 0.0f ? 4u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 1u : 0u); oct_inv = 7u - oct;
                 cur_x = nd[4]; cur_y = 0x01000000u;          /* one child: the root (no inner-mask bits: index = base) */
