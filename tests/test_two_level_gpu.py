@@ -237,3 +237,42 @@ def test_two_level_is_chosen_by_size_and_refused_where_it_cannot_be_traced(hrt, 
     monkeypatch.delenv("HRT_TWO_LEVEL")
     monkeypatch.setenv("HRT_FUSED", "0")
     assert nodes_of(hrt.CTX_TWO_LEVEL) == flat
+
+
+def test_rays_at_the_edge_of_an_instances_bounding_sphere(hrt, oracle, gpu_available):
+    """A ray that misses an instance's bounding sphere does not enter it (transform node words 0-2, 7; fused.hip).  The test is culling
+    only and has to stay so at its edges: rays that graze the sphere or the farthest vertices, rays that start inside it or on it,
+    origins 10^5 radii away (where the terms of the test round coarsely), instances that are scaled unevenly and sheared (the sphere
+    is tested in OBJECT space: any affine map).  Hit records bit-exact against the instanced oracle's brute force."""
+    r = _two_level(hrt, gpu_available)
+    try:
+        scene = hrt.scenes.particle_scene(9, 64, 48, 1, frame=1)
+        rng = np.random.default_rng(17)
+        for k, it in enumerate(scene["instances"][1:]):           # (the ground sphere stays as it is)
+            m = it["transform"].reshape(3, 4).astype(np.float64)
+            lin = m[:, :3] @ np.diag([1.0 + 0.8 * (k % 3), 0.5 + 0.25 * (k % 2), 1.0]) @ np.array([[1, 0.3 * (k % 2), 0], [0, 1, 0], [0.2 * (k % 3 == 0), 0, 1]])
+            it["transform"] = np.concatenate([lin, m[:, 3:]], axis=1).astype(np.float32).reshape(12)
+        r.load_scene(scene)
+        assert r.stats().fused_fallback_launches == 0
+        origins, dirs = [], []
+        for it in scene["instances"][1:]:
+            m = it["transform"].reshape(3, 4).astype(np.float64)
+            v = it["vertices"].reshape(-1, 3).astype(np.float64)
+            c_o = 0.5 * (v.min(0) + v.max(0)); rad = np.linalg.norm(v - c_o, axis=1).max()
+            far = v[np.argsort(-np.linalg.norm(v - c_o, axis=1))[:6]]                    # the vertices that define the sphere
+            n = 400
+            u = rng.normal(size=(n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+            t = np.cross(u, rng.normal(size=(n, 3))); t /= np.linalg.norm(t, axis=1, keepdims=True)
+            scale = rng.choice([0.98, 0.999, 1.0, 1.0001, 1.001, 1.02], size=(n, 1))
+            target = np.where(rng.random((n, 1)) < 0.3, far[rng.integers(0, len(far), n)], c_o + u * rad * scale)   # on / just off the sphere, or a far vertex
+            dist = rng.choice([0.0, 0.5, 1.0, 3.0, 1e2, 1e5], size=(n, 1)) * rad                # start inside, on, near, very far
+            o_obj = target - t * dist
+            d_obj = t * rng.choice([1.0, 1e-3, 37.0], size=(n, 1))                              # (t is shared by both spaces: unnormalised directions)
+            origins.append(o_obj @ m[:, :3].T + m[:, 3]); dirs.append(d_obj @ m[:, :3].T)      # object -> world
+        o = np.concatenate(origins).astype(np.float32); d = np.concatenate(dirs).astype(np.float32)
+        t_, u_, v_, prim, inst = r.trace_rays(o, d)
+        rt, ru, rv, rprim, rinst = oracle.OracleScene(scene, force_brute=True, instanced=True).trace(o, d)
+        assert np.array_equal(prim, rprim) and np.array_equal(inst, rinst) and np.array_equal(t_.view(np.uint32), rt.view(np.uint32))
+        assert (prim != 0xFFFFFFFF).sum() > 500                                                 # (and plenty of them do hit)
+    finally:
+        r.close()
