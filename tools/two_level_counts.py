@@ -25,10 +25,16 @@ for structure in ("flat", "two"):
     inv = np.stack([np.linalg.inv(np.vstack([it["transform"].reshape(3, 4).astype(np.float64), [0, 0, 0, 1]]))[:3].reshape(12) for it in scene["instances"]]).astype(np.float32)
     ident = np.array([int(np.array_equal(it["transform"], hrt.scenes.IDENTITY)) for it in scene["instances"]], dtype=np.uint32)
     res = O.bvh8_trace(nodes.ctypes.data, prims.ctypes.data, o, d, inst_inv=inv, inst_identity=ident)
+    extra = ""
+    if structure == "two":      # the same walk with the bounding-sphere test at the transform nodes switched off (radius < 0: none)
+        w = np.frombuffer(nodes.tobytes(), dtype=np.uint32).reshape(-1, 20).copy()
+        w[w[:, 3] == 0, 7] = np.float32(-1.0).view(np.uint32)
+        off = O.bvh8_trace(w.ctypes.data, prims.ctypes.data, o, d, inst_inv=inv, inst_identity=ident)
+        extra = f" (without the bounding-sphere test at the transform nodes: {off[5] / n:.2f} + {off[6] / n:.2f}; same hits: {bool(np.array_equal(off[3], res[3]))})"
     r.reset_stats()
     got = r.trace_rays(o, d)
     s = r.stats()
-    line = f"{scene['name']} {structure}: canonical {res[5] / n:.2f} node visits + {res[6] / n:.2f} primitive tests per ray; hit fraction {(res[3] != 0xffffffff).mean():.2f}"
+    line = f"{scene['name']} {structure}: canonical {res[5] / n:.2f} node visits + {res[6] / n:.2f} primitive tests per ray{extra}; hit fraction {(res[3] != 0xffffffff).mean():.2f}"
     if "stats" in os.environ.get("HRT_LIB", ""):
         line += f"; executed {s.debug[2] / n:.2f} node steps + {s.debug[3] / n:.2f} primitive tests in {s.debug[0] * 64 / n:.1f} lane iterations per ray, {(s.node_visits - s.node_visits_closest) / n:.2f} instances entered"
     print(line, "; same primitives as the CPU walk:", bool(np.array_equal(got[3], res[3])), flush=True)
