@@ -868,7 +868,8 @@ static void bvh8_walk(const uint32_t *nodes, const void *prims_blob, const float
                     const float cx = oo.x - c[0], cy = oo.y - c[1], cz = oo.z - c[2];
                     const float cc = fmaf(cx, cx, fmaf(cy, cy, cz * cz)), aa = fmaf(od.x, od.x, fmaf(od.y, od.y, od.z * od.z)), b = fmaf(cx, od.x, fmaf(cy, od.y, cz * od.z));
                     const float R2 = R * R * 1.0001f, ca = cc * aa;
-                    if (R >= 0.0f && (fmaf(-b, b, ca) > fmaf(R2, aa, 4e-6f * ca) || (b > 0.0f && cc > fmaf(4e-6f, cc, R2)))) continue;
+                    /* (not entered: the siblings still to visit were pushed above, the copy in hand goes) */
+                    if (R >= 0.0f && (fmaf(-b, b, ca) > fmaf(R2, aa, 4e-6f * ca) || (b > 0.0f && cc > fmaf(4e-6f, cc, R2)))) { cur_y = 0u; continue; }
                 }
                 stack_x[sp] = 0xffffffffu; stack_y[sp] = 0u; ++sp;
                 cur_inst = nd[5];
