@@ -86,6 +86,7 @@ struct TraverseArgs {
     int tail_split;                // split long rays across idle lanes once the queue is drained
     int postpone_pct;              // the leaf pass is skipped while fewer than this % of the alive lanes have leaf work and none needs it
     int leaf_quorum;               // k_fused: ... and fewer than this many lanes have nothing but leaf work (they wait; >= 1)
+    int leaf_hold;                 // k_fused: a lane with this many leaf groups queued takes no new node until some are tested (2 .. 4 = the leaf stack's depth)
     int tail_regen;                // k_fused, tile used up: regenerate once this many finished rays wait (>= 1)
     PathArgs path;                 // FUSED only
 };

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(kTraverseBlock, INSTANCED ? HRT_INST_WAVES_PER_SIMD
     const char *__restrict__ node_bytes = reinterpret_cast<const char *>(a.nodes);
     const char *__restrict__ prim_bytes = reinterpret_cast<const char *>(a.prims);
     const float tmin = a.tmin, tmax_ray = a.tmax;
+    const uint32_t leaf_hold = a.leaf_hold >= 1 && a.leaf_hold <= 4 ? (uint32_t)a.leaf_hold : 4u;      // (a lane that could never take a node would never finish)
     const uint32_t tx = threadIdx.x;
     const uint32_t ldsn = (uint32_t)reinterpret_cast<uintptr_t>(&s_nodes[0][tx]), ldsl = (uint32_t)reinterpret_cast<uintptr_t>(&s_leaves[0][tx]);
 
@@ -426,14 +427,14 @@ __global__ __launch_bounds__(kTraverseBlock, INSTANCED ? HRT_INST_WAVES_PER_SIMD
                 if (hit_any) { L.nidx = kNoWork; L.pidx = kNoWork; done = true; }
                 [[maybe_unused]] uint32_t lane = 0u;
                 if constexpr (!INSTANCED) {
-                    if (alive && !done) done = lean_bookkeeping_asm(L, child, tri, ldsn, ldsl, (uint32_t)a.postpone_pct, (uint32_t)a.leaf_quorum) != 0u;
+                    if (alive && !done) done = lean_bookkeeping_asm(L, child, tri, ldsn, ldsl, (uint32_t)a.postpone_pct, (uint32_t)a.leaf_quorum, leaf_hold) != 0u;
                 } else {
                     // (this instantiation is two registers over its budget and the compiler's choice of what to keep in scratch is the two
                     // stack addresses, reloaded here in every iteration: they are a constant plus eight times the lane number -- two
                     // instructions to make again)
                     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
                     const uint32_t ldsn_i = (uint32_t)reinterpret_cast<uintptr_t>(&s_nodes[0][0]) + 8u * lane, ldsl_i = (uint32_t)reinterpret_cast<uintptr_t>(&s_leaves[0][0]) + 8u * lane;
-                    if (alive && !done) done = lean_bookkeeping_asm(L, child, tri, ldsn_i, ldsl_i, (uint32_t)a.postpone_pct, (uint32_t)a.leaf_quorum) != 0u;
+                    if (alive && !done) done = lean_bookkeeping_asm(L, child, tri, ldsn_i, ldsl_i, (uint32_t)a.postpone_pct, (uint32_t)a.leaf_quorum, leaf_hold) != 0u;
                 }
                 if constexpr (INSTANCED) {
                     // in: the frame starts above what the lane holds (siblings still in hand have just been pushed, step 2 of the sequence)

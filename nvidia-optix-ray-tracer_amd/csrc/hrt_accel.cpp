@@ -571,6 +571,7 @@ static int build_tlas_fresh(HrtContext *ctx, Tlas &t, const std::vector<HrtInsta
     uint32_t n_vis = 0;
     for (uint32_t i = 0; i < n; ++i) n_vis += first[i + 1] > first[i] ? 1u : 0u;
     const bool scene_of_bodies = n_vis >= 4u && (uint64_t)first[n] < 20000ull * n_vis;
+    t.scene_of_bodies = scene_of_bodies;      // (the launch picks the path kernel's leaf-hold by it, hrt_api.cpp)
     // ---- two levels or one?  Flattening costs memory, build and refit time in proportion to instances x primitives; a two-level tree
     //      (transform nodes over one shared tree per BLAS) in proportion to instances + unique primitives, at the price of a ray
     //      transform per instance entered.  Asked for (two_level_mode > 0), or chosen when the flattened tree would leave the caches

@@ -78,6 +78,7 @@ struct Tlas {
     // one transform node per visible instance, what an update refits --, behind them one object-space tree per UNIQUE BLAS; d_prims holds those
     // trees' records only.  Memory and update cost: instances + unique primitives.
     bool two_level = false; uint32_t n_top_nodes = 0, n_unique_blas = 0;
+    bool scene_of_bodies = false;        // at least 4 visible instances of fewer than 20 000 primitives each on average (the reference's kind of scene)
     uint32_t *d_inst_root = nullptr;                     // per instance: node index of its BLAS's root
     float *d_blas_bound = nullptr;                       // per instance, 10 floats: its BLAS's object-space box and bounding sphere (the top level's "geometry")
     float built_reach = 1.0f;                            // the largest object-space |coordinate| a ray origin was assumed to have when the BLAS trees were padded
@@ -171,6 +172,7 @@ struct HrtContext {
                                                 // are not what limits the mode (traversal is 85 % of its GPU time), profiles/r03_wavefront.txt
     uint64_t graph_replays = 0;
     int fused_tail_regen = 12;                  // k_fused, tile used up: finished rays that wait before a regeneration (HRT_TAIL_REGEN; 1/8 of C4: 142 ms with 1, 129 with 8..16)
+    int leaf_hold = 0;                          // HRT_LEAF_HOLD: leaf groups a lane may queue before its node work waits for primitive tests; 0 = by scene (render_fused)
     int leaf_quorum = 1;                        // k_fused: lanes with nothing but leaf work wait until this many of them have gathered (HRT_LEAF_QUORUM)
     int tail_split = 1;
     int node_stride = 80, prim_stride = 64;     // bytes between records in HBM (80/48 packed; 128/64 = one cache line each)

@@ -145,7 +145,7 @@ __device__ __forceinline__ void issue_node_loads_off(uint64_t mask, const void *
 //   pct, quorum: leaf passes are skipped while fewer than pct % of the active lanes have leaf work and fewer than `quorum`
 //   lanes have nothing else to do (those wait)
 // Returns 1 in the lanes whose ray has nothing left to do.
-__device__ __forceinline__ uint32_t lean_bookkeeping_asm(LeanLane &L, uint2 child, uint2 tri, uint32_t ldsn, uint32_t ldsl, uint32_t pct, uint32_t quorum) {
+__device__ __forceinline__ uint32_t lean_bookkeeping_asm(LeanLane &L, uint2 child, uint2 tri, uint32_t ldsn, uint32_t ldsl, uint32_t pct, uint32_t quorum, uint32_t hold = 4u) {
     static_assert(kLeafStackLds == 4 && kTraverseBlock == 64 && sizeof(uint2) == 8,
                   "the sequence below has the leaf stack's depth (4, 'about to fill' = 3) and the stacks' row pitch (64 lanes x 8 bytes = 1 << 9) as literals");
     uint32_t fin, t0, t1, t2, c0, c1;
@@ -199,7 +199,7 @@ __device__ __forceinline__ uint32_t lean_bookkeeping_asm(LeanLane &L, uint2 chil
         "s_cmp_ge_u32 %[c0], %[quorum]\n\t"
         "s_cselect_b64 %[sv2], -1, 0\n\t"
         "s_or_b64 %[sv2], %[sv2], vcc\n\t"
-        "v_cmp_lt_u32_e32 vcc, 2, %[lsp]\n\t"
+        "v_cmp_lt_u32_e32 vcc, %[fill], %[lsp]\n\t"
         "s_and_b64 vcc, vcc, %[sv1]\n\t"                   // a leaf stack about to fill
         "s_cmp_lg_u64 vcc, 0\n\t"
         "s_cselect_b64 vcc, -1, 0\n\t"
@@ -235,7 +235,7 @@ __device__ __forceinline__ uint32_t lean_bookkeeping_asm(LeanLane &L, uint2 chil
         // (7) the next node: the nearest child (highest hit bit, octant order) of the group in hand -- unless the leaf stack is full
         "v_mov_b32_e32 %[nidx], -1\n\t"
         "v_cmp_lt_u32_e32 vcc, %[k24], %[cy]\n\t"
-        "v_cmp_gt_u32_e64 %[sv1], 4, %[lsp]\n\t"
+        "v_cmp_gt_u32_e64 %[sv1], %[hold], %[lsp]\n\t"
         "s_and_b64 exec, vcc, %[sv1]\n\t"
         "v_ffbh_u32_e32 %[t0], %[cy]\n\t"
         "v_sub_u32_e32 %[t0], 31, %[t0]\n\t"
@@ -262,7 +262,7 @@ __device__ __forceinline__ uint32_t lean_bookkeeping_asm(LeanLane &L, uint2 chil
           [nidx] "+v"(L.nidx), [pidx] "+v"(L.pidx), [fin] "=&v"(fin), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
           [sv0] "=&s"(sv0), [sv1] "=&s"(sv1), [sv2] "=&s"(sv2), [c2] "=&s"(c2), [c0] "=&s"(c0), [c1] "=&s"(c1)
         : [chx] "v"(child.x), [chy] "v"(child.y), [tx] "v"(tri.x), [ty] "v"(tri.y), [oct] "v"(L.s.oct_inv4), [base] "v"(L.base), [ldsn] "v"(ldsn), [ldsl] "v"(ldsl),
-          [k24] "s"(k24), [pct] "s"(pct), [quorum] "s"(quorum)
+          [k24] "s"(k24), [pct] "s"(pct), [quorum] "s"(quorum), [hold] "s"(hold), [fill] "s"(hold >= 2u ? hold - 2u : 0u)
         : "vcc", "scc", "memory");
     return fin;
 }
