@@ -172,6 +172,7 @@ struct HrtContext {
                                                 // are not what limits the mode (traversal is 85 % of its GPU time), profiles/r03_wavefront.txt
     uint64_t graph_replays = 0;
     int fused_tail_regen = 12;                  // k_fused, tile used up: finished rays that wait before a regeneration (HRT_TAIL_REGEN; 1/8 of C4: 142 ms with 1, 129 with 8..16)
+    bool refill_auto = true;                    // HRT_REFILL_THRESHOLD not set: two-level launches regenerate at 12 waiting lanes (profiles/r04_leaf_hold.txt)
     int leaf_hold = 0;                          // HRT_LEAF_HOLD: leaf groups a lane may queue before its node work waits for primitive tests; 0 = by scene (render_fused)
     int leaf_quorum = 1;                        // k_fused: lanes with nothing but leaf work wait until this many of them have gathered (HRT_LEAF_QUORUM)
     int tail_split = 1;
