@@ -199,7 +199,8 @@ __device__ __forceinline__ uint32_t lean_bookkeeping_asm(LeanLane &L, uint2 chil
         "s_cmp_ge_u32 %[c0], %[quorum]\n\t"
         "s_cselect_b64 %[sv2], -1, 0\n\t"
         "s_or_b64 %[sv2], %[sv2], vcc\n\t"
-        "v_cmp_lt_u32_e32 vcc, %[fill], %[lsp]\n\t"
+        "s_lshr_b32 %[c0], %[hold], 1\n\t"                 // "about to fill": one group below the hold (4 -> more than 2 queued, as ever; 1 -> any)
+        "v_cmp_lt_u32_e32 vcc, %[c0], %[lsp]\n\t"
         "s_and_b64 vcc, vcc, %[sv1]\n\t"                   // a leaf stack about to fill
         "s_cmp_lg_u64 vcc, 0\n\t"
         "s_cselect_b64 vcc, -1, 0\n\t"
@@ -262,7 +263,7 @@ __device__ __forceinline__ uint32_t lean_bookkeeping_asm(LeanLane &L, uint2 chil
           [nidx] "+v"(L.nidx), [pidx] "+v"(L.pidx), [fin] "=&v"(fin), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
           [sv0] "=&s"(sv0), [sv1] "=&s"(sv1), [sv2] "=&s"(sv2), [c2] "=&s"(c2), [c0] "=&s"(c0), [c1] "=&s"(c1)
         : [chx] "v"(child.x), [chy] "v"(child.y), [tx] "v"(tri.x), [ty] "v"(tri.y), [oct] "v"(L.s.oct_inv4), [base] "v"(L.base), [ldsn] "v"(ldsn), [ldsl] "v"(ldsl),
-          [k24] "s"(k24), [pct] "s"(pct), [quorum] "s"(quorum), [hold] "s"(hold), [fill] "s"(hold >= 2u ? hold - 2u : 0u)
+          [k24] "s"(k24), [pct] "s"(pct), [quorum] "s"(quorum), [hold] "s"(hold)
         : "vcc", "scc", "memory");
     return fin;
 }

@@ -294,6 +294,13 @@ def test_path_kernel_hot_loop_keeps_its_instruction_budget():
     # 4 waves per SIMD (<= 128 VGPRs) for the one-level kernels; the INSTANCED instantiations are compiled for 3 (<= 168)
     counts = sorted(int(v) for v in re.findall(r"\.vgpr_count:\s+(\d+)", text))
     assert len(counts) == 8 and counts[3] <= 128 and counts[7] <= 168, counts
+    # ... and what they keep in scratch stays what it is (kernel constants, reloaded around the shading): a 12th register spilled by the C4
+    # kernel was a reload in every regeneration (round 4: a second SGPR operand of the bookkeeping sequence had done that)
+    spills = {m.group(1): int(m.group(2)) for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)}
+    by_kind = {k: v for k, v in spills.items() if "k_fused" in k}
+    assert len(by_kind) == 8, sorted(spills)
+    assert max(v for k, v in by_kind.items() if "ILb0ELb0ELb0E" in k) <= 11 and max(v for k, v in by_kind.items() if "ILb1ELb0ELb0E" in k) <= 14, by_kind
+    assert all(v == 0 for k, v in by_kind.items() if "ELb1ELb" in k.split("k_fusedILb")[1][:9]), by_kind      # INSTANCED: nothing spilled at 3 waves per SIMD
     # the REUSE instantiations (HRT_CTX_REUSE_PRIMARY) keep the same loop: nothing of theirs is inside it
     for k, (cs_k, ops_k) in found.items():
         if "ILb0ELb0ELb1E" in k:

@@ -276,3 +276,31 @@ def test_rays_at_the_edge_of_an_instances_bounding_sphere(hrt, oracle, gpu_avail
         assert (prim != 0xFFFFFFFF).sum() > 500                                                 # (and plenty of them do hit)
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("flags_name", ["flattened", "two_level"])
+def test_every_leaf_hold_gives_the_same_bits(hrt, oracle, gpu_available, monkeypatch, flags_name):
+    """HRT_LEAF_HOLD (how many leaf groups a lane may queue before its node work waits; by scene when unset: 4 / 2 / 1) and the
+    regeneration threshold change WHEN primitives are tested, never what is hit: frames and ray counts are the oracle's at every value."""
+    if not gpu_available:
+        pytest.skip("no GPU in this container")
+    w, h, spp = 128, 96, 4
+    scene = hrt.scenes.particle_cloud(400, w, h, spp)
+    flags = hrt.CTX_TWO_LEVEL if flags_name == "two_level" else 0
+    ref = oracle.OracleScene(scene, instanced=flags != 0).render(w, h, oracle.rng_init(w, h, 5), spp)
+    for env in ({}, {"HRT_LEAF_HOLD": "1"}, {"HRT_LEAF_HOLD": "2"}, {"HRT_LEAF_HOLD": "3"}, {"HRT_LEAF_HOLD": "4"},
+                {"HRT_LEAF_HOLD": "1", "HRT_REFILL_THRESHOLD": "1"}, {"HRT_LEAF_HOLD": "1", "HRT_REFILL_THRESHOLD": "64", "HRT_POSTPONE_PCT": "100"}):
+        for k in ("HRT_LEAF_HOLD", "HRT_REFILL_THRESHOLD", "HRT_POSTPONE_PCT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = hrt.Renderer(0, flags)
+        try:
+            r.load_scene(scene)
+            r.set_frame(w, h, 5, linear=True)
+            r.reset_stats()
+            r.render(spp)
+            assert np.array_equal(r.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32)), env
+            assert int(r.stats().rays) == ref["rays"] and r.stats().fused_fallback_launches == 0
+        finally:
+            r.close()
