@@ -305,3 +305,16 @@ def test_path_kernel_hot_loop_keeps_its_instruction_budget():
     for k, (cs_k, ops_k) in found.items():
         if "ILb0ELb0ELb1E" in k:
             assert sum(cs_k.values()) <= 480 and not any(op.startswith("scratch_") for op in ops_k), (k, dict(cs_k))
+
+
+def test_context_flags_of_the_binding_are_the_headers(hrt):
+    """The ctypes binding restates the context flags of include/hrt.h as Python constants: every HRT_CTX_* of the header has its
+    CTX_* twin with the same value, no two flags share a bit."""
+    import re
+    from pathlib import Path
+    text = (Path(__file__).resolve().parent.parent / "include" / "hrt.h").read_text()
+    flags = {m.group(1): int(m.group(2), 16) for m in re.finditer(r"#define\s+HRT_CTX_(\w+)\s+0x([0-9a-fA-F]+)u", text)}
+    assert len(flags) >= 6 and len(set(flags.values())) == len(flags), flags
+    for name, value in flags.items():
+        assert getattr(hrt, "CTX_" + name) == value, name
+        assert value & (value - 1) == 0, name
