@@ -221,7 +221,11 @@ struct TravState {
 template <bool EXACT>
 __device__ __forceinline__ float safe_rcp_dir(float d) {
     const float lim = 1e-20f;
-    const float dd = fabsf(d) < lim ? copysignf(lim, d) : d;
+    // (the sign is the one the slab test's near / far choice and the octant use, `d < 0`: a component of -0.0 -- a ray mirrored by an axis-aligned
+    // wall -- counts as positive there, and with copysignf here its reciprocal was negative: near and far swapped, every box culled, the ray left
+    // a closed room.  Found in round 4 by tools/stress_modes.py: one pixel of a Cornell box; tests/test_gpu_parity.py has the rays.)
+    // (d + 0.0f: -0.0 becomes +0.0, everything else stays -- one instruction, no new constant in a kernel that has no register to spare)
+    const float dd = fabsf(d) < lim ? copysignf(lim, d + 0.0f) : d;
     return EXACT ? 1.0f / dd : __builtin_amdgcn_rcpf(dd);
 }
 

@@ -719,6 +719,10 @@ static void closesthit_impl(launch_ctx *lc, const hit_rec *hit, f3 rayOrigin, f3
     *payload = result;                                              /* setPayload(result, albedo, normal) :241 */
 }
 
+/* (debugging aid, oracle_debug_pixel_path: the rays of one path as the oracle traced them -- 10 floats each: origin, direction, any-hit flag, t,
+ * primitive and instance as float bits) */
+static _Thread_local float *tl_ray_log; static _Thread_local uint32_t tl_ray_log_n, tl_ray_log_cap;
+
 /* rayTrace + optixTrace dispatch, Shader.cu:46-92 */
 static void ray_trace(launch_ctx *lc, f3 origin, f3 direction, float tMin, float tMax,
                       f4 *payload, f4 *albedo, f4 *normal) {
@@ -727,6 +731,11 @@ static void ray_trace(launch_ctx *lc, f3 origin, f3 direction, float tMin, float
      * oracle may stop at the first accepted intersection there; the result is identical */
     const int any_hit = payload->w >= (float)RAY_TRACE_DEPTH;
     closest_hit(lc->sc, origin, direction, tMin, tMax, any_hit, &hit, &lc->cnt);
+    if (tl_ray_log && tl_ray_log_n < tl_ray_log_cap) {
+        float *q = tl_ray_log + 10 * (size_t)tl_ray_log_n++;
+        q[0] = origin.x; q[1] = origin.y; q[2] = origin.z; q[3] = direction.x; q[4] = direction.y; q[5] = direction.z;
+        q[6] = (float)any_hit; q[7] = hit.hit ? hit.t : -1.0f; memcpy(q + 8, &hit.prim, 4); memcpy(q + 9, &hit.inst, 4);
+    }
     if (hit.hit) closesthit_impl(lc, &hit, origin, direction, payload, albedo, normal);
     else miss_program(lc, payload, albedo, normal);
 }
@@ -786,6 +795,21 @@ void oracle_render(const oracle_scene *sc, const float *cam12, uint32_t width, u
     if (out_counters) { out_counters[0] = tot_rays; out_counters[1] = tot_nodes; out_counters[2] = tot_prims; }
 }
 
+/* One sample of one pixel, its rays logged (10 floats per ray, see tl_ray_log); the pixel's RNG state advances as in a render.  Returns the
+ * number of rays; result3 = the sample's linear radiance. */
+uint32_t oracle_debug_pixel_path(const oracle_scene *sc, const float *cam12, uint32_t width, uint32_t height, void *states, const float *bg3,
+                                 uint32_t x, uint32_t y, float *log10, uint32_t cap, float *result3) {
+    oracle_init();
+    launch_ctx lc; memset(&lc, 0, sizeof lc);
+    lc.sc = sc; lc.stateArray = (rng_state *)states; lc.backgroundColor = mk3(bg3[0], bg3[1], bg3[2]);
+    f4 a, n;
+    tl_ray_log = log10; tl_ray_log_n = 0; tl_ray_log_cap = cap;
+    const f4 r = raygen_program(&lc, x, y, width, height, cam12, &a, &n);
+    tl_ray_log = NULL;
+    if (result3) { result3[0] = r.x; result3[1] = r.y; result3[2] = r.z; }
+    return tl_ray_log_n;
+}
+
 /* convertFloat4ToUchar4Kernel, src/Global/RendererImpl.cu:672-678 */
 void oracle_to_rgba8(const float *src4, unsigned char *dst4, uint32_t width, uint32_t height) {
     const long n = (long)width * height;
@@ -818,7 +842,7 @@ typedef struct { float a[3]; uint32_t prim; float b[3]; uint32_t inst; float c[3
 
 static inline float safe_rcp_dir(float d) {
     const float lim = 1e-20f;
-    const float dd = fabsf(d) < lim ? copysignf(lim, d) : d;
+    const float dd = fabsf(d) < lim ? (d < 0.0f ? -lim : lim) : d;      /* the sign that `d < 0` sees: -0.0 is positive (csrc/trav_common.h safe_rcp_dir) */
     return 1.0f / dd;
 }
 

@@ -148,6 +148,17 @@ class OracleScene:
         return {"color": color, "albedo": albedo, "normal": normal, "linear": linear,
                 "rays": int(cnt[0]), "node_visits": int(cnt[1]), "prim_tests": int(cnt[2])}
 
+    def pixel_path(self, width, height, states, x, y, cap=16):
+        """One sample of one pixel with its rays logged (a debugging aid): returns (rays (n, 10): origin, direction, any-hit flag, t or -1,
+        primitive and instance as uint32 bits; linear radiance (3,)).  The pixel's RNG state in `states` advances as in a render."""
+        L = lib()
+        L.oracle_debug_pixel_path.restype = C.c_uint32
+        L.oracle_debug_pixel_path.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        cam = self.camera12(); bg = np.ascontiguousarray(self.scene["background"], dtype=np.float32)
+        log = np.zeros((cap, 10), np.float32); res = np.zeros(3, np.float32)
+        n = L.oracle_debug_pixel_path(self.handle, _p(cam), width, height, _p(states), _p(bg), x, y, _p(log), cap, _p(res))
+        return log[:n], res
+
     def trace(self, origins, directions, tmin=1e-6, tmax=1e16, any_hit=False):
         L = lib()
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
@@ -256,6 +267,23 @@ def bvh8_trace(nodes_ptr, prims_ptr, origins, directions, tmin=1e-6, tmax=1e16, 
     bvh8_trace.last_empty_visits = int(cnt[2])       # node visits that found nothing to enter or test (tools/tree_quality.py)
     bvh8_trace.last_line_mates = int(cnt[3])         # node visits whose array neighbour (index ^ 1) the ray had visited before
     return t, u, v, prim, inst, int(cnt[0]), int(cnt[1])
+
+
+def axis_parallel_rays(n, seed, lo=(0.05, 0.05, -0.95), hi=(0.95, 0.95, 0.95)):
+    """Rays along the coordinate axes from points inside a box, their other two direction components every combination of +0.0 and -0.0
+    (what a mirror reflection off an axis-aligned wall produces), and rays in the coordinate planes (one component +-0.0).  A reciprocal
+    whose sign disagrees with `d < 0` for -0.0 swaps near and far in a slab test: such a ray then leaves a closed room."""
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    d = np.zeros((n, 3), np.float32)
+    axis = rng.integers(0, 3, n); sign = rng.choice(np.float32([-1.0, 1.0]), n)
+    zeros = rng.choice(np.float32([0.0, -0.0]), (n, 3))
+    d[:] = zeros
+    planar = rng.random(n) < 0.4                       # two components free, one a signed zero
+    d[planar] = rng.normal(size=(int(planar.sum()), 3)).astype(np.float32)
+    d[planar, axis[planar]] = zeros[planar, axis[planar]]
+    d[~planar, axis[~planar]] = sign[~planar] * rng.choice(np.float32([1.0, 0.25, 7.0]), int((~planar).sum()))
+    return o, d
 
 
 def random_rays(n, seed, scale=1.6):

@@ -83,6 +83,26 @@ def test_traverse_matches_bruteforce_triangles(hrt, oracle, renderer, any_hit):
     assert (rprim != 0xFFFFFFFF).mean() > 0.3
 
 
+def test_rays_with_signed_zero_direction_components(hrt, oracle, renderer):
+    """A direction component of -0.0 -- a ray mirrored by an axis-aligned wall -- counts as positive in the slab test (`d < 0`); its guarded
+    reciprocal was negative (copysignf), near and far swapped, every box was culled and the ray left the room: one pixel of a Cornell box
+    at 64x94, found in round 4 by tools/stress_modes.py.  Axis-parallel and in-plane rays with every combination of +0.0 / -0.0, closest
+    and any-hit, against brute force; and that frame against the oracle."""
+    scene = hrt.scenes.cornell_box(64, 94, 3)
+    renderer.load_scene(scene)
+    o, d = oracle.axis_parallel_rays(60000, 7)
+    brute = oracle.OracleScene(scene, force_brute=True)
+    t, u, v, prim, inst = renderer.trace_rays(o, d)
+    rt, ru, rv, rprim, rinst = brute.trace(o, d)
+    assert np.array_equal(prim, rprim) and np.array_equal(inst, rinst) and np.array_equal(t.view(np.uint32), rt.view(np.uint32))
+    a = renderer.trace_rays(o, d, any_hit=True)
+    assert np.array_equal(a[3] != 0xFFFFFFFF, rprim != 0xFFFFFFFF)
+    renderer.set_frame(64, 94, 525075280, linear=True)
+    renderer.render(3)
+    ref = oracle.OracleScene(scene).render(64, 94, oracle.rng_init(64, 94, 525075280), 3)
+    assert np.array_equal(renderer.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32))
+
+
 def test_traverse_mixed_scene_with_transforms(hrt, oracle, renderer):
     scene = hrt.scenes.mixed_test_scene(3000, 60, 9)
     renderer.load_scene(scene)

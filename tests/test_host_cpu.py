@@ -114,6 +114,23 @@ def test_host_bvh8_build_and_cpu_walk(hrt, oracle, n):
     assert not blob.nodes
 
 
+def test_cpu_walk_of_rays_with_signed_zero_direction_components(hrt, oracle):
+    """A direction component of -0.0 (a ray mirrored by an axis-aligned wall) counts as positive in the slab test's near / far choice
+    (`d < 0`), so its guarded reciprocal has to be positive too: with copysignf it was negative, every box was culled, and one pixel of
+    a Cornell box leaked light (round 4, tools/stress_modes.py).  The CPU walker of the product's tree shares that arithmetic."""
+    scene = hrt.scenes.cornell_box(64, 64, 1)
+    verts = np.concatenate([it["vertices"].reshape(-1, 3, 3) for it in scene["instances"]])
+    lib, blob = _build(hrt, verts)
+    o, d = oracle.axis_parallel_rays(20000, 3)
+    assert (np.signbit(d) & (d == 0)).any() and ((d == 0) & ~np.signbit(d)).any()
+    one = dict(scene); one["instances"] = [dict(scene["instances"][0], vertices=verts, normals=np.zeros((len(verts), 3, 3), np.float32))]
+    want = oracle.OracleScene(one, force_brute=True).trace(o, d)
+    got = oracle.bvh8_trace(blob.nodes, blob.triangles, o, d)
+    assert np.array_equal(got[3], want[3]) and np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+    assert (want[3] != 0xFFFFFFFF).mean() > 0.4             # (the room is open towards the camera)
+    lib.hrt_host_free(C.byref(blob))
+
+
 def test_oracle_renders_the_same_image_through_the_products_bvh8(hrt, oracle):
     """bench.py's cpu_baseline walks the product's BVH8 bytes ("same BVH bytes as the GPU run"): an oracle scene
     with the product's tree attached renders the very image it renders through its own BVH2, rays counted alike -- the closest hit is

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Random small scenes through every combination of tree structure (flattened / two-level), primary-hit reuse and leaf-hold value, frames
+compared bit for bit with the oracle (its FLATTENED / INSTANCED mode).  A one-off stress run, not part of the suites.
+    tools/stress_modes.py [n_scenes=24] [seed=1]"""
+import importlib, itertools, os, sys, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import torch
+hrt = importlib.import_module("nvidia-optix-ray-tracer_amd")
+import oracle_py as oracle
+
+n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for k in range(n_scenes):
+    kind = rng.integers(0, 4)
+    w, h, spp = int(rng.integers(40, 160)), int(rng.integers(30, 120)), int(rng.integers(1, 7))
+    if kind == 0: scene = hrt.scenes.mixed_test_scene(int(rng.integers(10, 4000)), int(rng.integers(1, 60)), int(rng.integers(1, 1000)), w, h, spp)
+    elif kind == 1: scene = hrt.scenes.particle_cloud(int(rng.integers(4, 900)), w, h, spp, subdiv=int(rng.integers(0, 3)), seed=int(rng.integers(1, 100)))
+    elif kind == 2: scene = hrt.scenes.particle_scene(int(rng.integers(1, 300)), w, h, spp, frame=int(rng.integers(0, 5)))
+    else: scene = hrt.scenes.cornell_box(w, h, spp)
+    salt = int(rng.integers(1, 1 << 30))
+    refs = {}
+    for two, reuse, hold in itertools.product((0, 1), (0, 1), ("", "1", "3")):
+        if hold: os.environ["HRT_LEAF_HOLD"] = hold
+        else: os.environ.pop("HRT_LEAF_HOLD", None)
+        os.environ["HRT_REFILL_THRESHOLD"] = str(int(rng.integers(1, 64)))
+        r = hrt.Renderer(0, (hrt.CTX_TWO_LEVEL if two else 0) | (hrt.CTX_REUSE_PRIMARY if reuse else 0))
+        try:
+            r.load_scene(scene); r.set_frame(w, h, salt, linear=True); r.render(spp)
+            got = r.linear.cpu().numpy().view(np.uint32).copy()
+        finally:
+            r.close()
+        if two not in refs:
+            refs[two] = oracle.OracleScene(scene, instanced=bool(two)).render(w, h, oracle.rng_init(w, h, salt), spp)["linear"].view(np.uint32)
+        ok = np.array_equal(got, refs[two])
+        if not ok:
+            bad += 1
+            print("MISMATCH", scene["name"], (w, h, spp), "two" if two else "flat", "reuse" if reuse else "", "hold", hold or "auto", int((got != refs[two]).sum()), "words", flush=True)
+    print(time.strftime("%H:%M:%S"), k, scene["name"], (w, h, spp), "ok" if not bad else f"{bad} mismatches so far", flush=True)
+print("stress:", "all frames bit-exact" if not bad else f"{bad} MISMATCHES")
+sys.exit(1 if bad else 0)
