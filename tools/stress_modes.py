@@ -15,12 +15,23 @@ n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 for k in range(n_scenes):
-    kind = rng.integers(0, 4)
+    kind = rng.integers(0, 8)
     w, h, spp = int(rng.integers(40, 160)), int(rng.integers(30, 120)), int(rng.integers(1, 7))
     if kind == 0: scene = hrt.scenes.mixed_test_scene(int(rng.integers(10, 4000)), int(rng.integers(1, 60)), int(rng.integers(1, 1000)), w, h, spp)
     elif kind == 1: scene = hrt.scenes.particle_cloud(int(rng.integers(4, 900)), w, h, spp, subdiv=int(rng.integers(0, 3)), seed=int(rng.integers(1, 100)))
     elif kind == 2: scene = hrt.scenes.particle_scene(int(rng.integers(1, 300)), w, h, spp, frame=int(rng.integers(0, 5)))
-    else: scene = hrt.scenes.cornell_box(w, h, spp)
+    elif kind == 3: scene = hrt.scenes.cornell_box(w, h, spp)
+    elif kind == 4: scene = hrt.scenes.random_soup(int(rng.integers(1, 30000)), float(rng.uniform(0.01, 0.3)), int(rng.integers(1, 1000)), w, h, spp)
+    elif kind == 5: scene = hrt.scenes.sphere_in_box(w, h, spp)
+    elif kind == 6:
+        n_chain = int(rng.integers(3, 400))
+        scene = hrt.scenes.growing_chain(n_chain, float(min(rng.uniform(1.01, 1.3), 1e12 ** (1.0 / n_chain))), w, h, spp)      # (sizes stay finite floats)
+    else:
+        # a room of mirrors: axis-aligned metal walls without fuzz send rays along the axes, into edges and corners, with components of +-0.0
+        scene = hrt.scenes.cornell_box(w, h, spp) if rng.random() < 0.5 else hrt.scenes.sphere_in_box(w, h, spp)
+        scene["name"] += "-mirrors"
+        for it in scene["instances"]:
+            if rng.random() < 0.7: it["material"], it["fuzz"] = "metal", float(rng.choice([0.0, 0.0, 0.05]))
     salt = int(rng.integers(1, 1 << 30))
     refs = {}
     for two, reuse, hold in itertools.product((0, 1), (0, 1), ("", "1", "3")):
@@ -31,6 +42,10 @@ for k in range(n_scenes):
         try:
             r.load_scene(scene); r.set_frame(w, h, salt, linear=True); r.render(spp)
             got = r.linear.cpu().numpy().view(np.uint32).copy()
+        except hrt.HrtError as e:
+            bad += 1
+            print("ERROR", scene["name"], (w, h, spp), "two" if two else "flat", str(e)[:160], flush=True)
+            continue
         finally:
             r.close()
         if two not in refs:
