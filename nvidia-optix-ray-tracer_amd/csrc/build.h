@@ -28,6 +28,8 @@ struct GpuBuildArgs {
     uint32_t max_leaf_prims; float c_node, c_prim; int ploc_radius;
     float quant_guard;                // emission: a node whose children's stored (8-bit) boxes would have more than this times their true area keeps its two BVH2 children (0: off)
     uint32_t width;                   // children per node at most (8; HRT_BVH_WIDTH: fewer, to measure what a narrower node would cost in visits)
+    uint32_t balanced;                // 1: PLOC pairs every cluster with its neighbour in Morton order (position ^ 1) whatever the areas: a tree of log2(n) levels
+                                      // for scenes whose nearest-neighbour tree is deeper than the traversal stacks (GpuBuildInput::balanced)
     uint32_t instance_leaves;         // 1: the top level of a two-level tree -- every primitive is an instance (kPrimKindInstance) and is emitted as a
                                       // TRANSFORM NODE in its parent's child block (bvh8.h), not as a record
     BuildCounters *counters;
@@ -89,6 +91,8 @@ struct GpuBuildInput {
     float quant_guard = 1.25f;
     uint32_t width = 8;                                  // children per node at most
     bool instance_leaves = false;                        // the top level of a two-level tree (GpuBuildArgs); max_leaf_prims must be 1
+    bool balanced = false;                               // no top-down phase, PLOC by position: the fallback for a tree too deep to traverse (a chain of
+                                                         // primitives over many orders of magnitude: SAH peels one off the rest at every level)
     unsigned char *out_nodes; uint32_t node_stride;      // room for n_prims nodes (worst case; instance_leaves: 2 * n_prims + 1)
     unsigned char *out_prims; uint32_t prim_stride;      // room for n_prims records
     float *out_node_ref;                                 // 2 floats per node

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256) void k_ploc_nn(GpuBuildArgs a, const uint32_t 
         // tree a chain (6000 copies of a triangle: depth 860); with the pairing rule they halve every round.  NaN areas still pick something
         if (ar < best || bj == kNone || (ar == best && (uint32_t)j == (i ^ 1u))) { best = ar; bj = (uint32_t)j; }
     }
+    if (a.balanced) bj = (i ^ 1u) < m ? (i ^ 1u) : kNone;      // by position: the clusters halve every round
     a.nn[i] = bj;
 }
 
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(1024) void k_ploc_small(GpuBuildArgs a, uint32_t *c
                 const float ar = merged_half_area(mlo, mhi, a.node_lo[o], a.node_hi[o]);
                 if (ar < best || bj == kNone || (ar == best && (uint32_t)j == (i ^ 1u))) { best = ar; bj = (uint32_t)j; }      // (k_ploc_nn's rule)
             }
+            if (a.balanced) bj = (i ^ 1u) < m ? (i ^ 1u) : kNone;
             a.nn[i] = bj;
         }
         __syncthreads();
@@ -770,6 +772,7 @@ GpuBuildResult gpu_build_bvh8(const GpuBuildInput &in, hipStream_t s) {
     a.inst_xf = in.d_inst_xf; a.inst_identity = in.d_inst_identity;
     a.max_leaf_prims = in.max_leaf_prims; a.c_node = in.c_node; a.c_prim = in.c_prim; a.quant_guard = in.quant_guard;
     a.instance_leaves = in.instance_leaves ? 1u : 0u;
+    a.balanced = in.balanced ? 1u : 0u;
     a.width = in.width >= 2u && in.width <= 8u ? in.width : 8u;
     a.ploc_radius = in.ploc_radius < 1 ? 1 : (in.ploc_radius > kPlocMaxRadius ? kPlocMaxRadius : in.ploc_radius);
     a.out_nodes = in.out_nodes; a.node_stride = in.node_stride; a.out_prims = in.out_prims; a.prim_stride = in.prim_stride; a.out_node_ref = in.out_node_ref;

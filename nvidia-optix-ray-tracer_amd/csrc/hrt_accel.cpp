@@ -338,7 +338,14 @@ static int build_merged_on_device(HrtContext *ctx, Tlas &t, const std::vector<ui
     in.out_prims = device_split ? stage + stage_nodes + stage_ref : ra.prims; in.prim_stride = t.prim_stride;
     in.out_clip = device_split ? reinterpret_cast<float *>(stage + stage_nodes + stage_ref + stage_prims) : nullptr;
     in.scratch = stage + stage_all; in.scratch_bytes = arena.bytes - stage_all;
-    const GpuBuildResult r = gpu_build_bvh8(in, s);      // (synchronises the stream before it returns)
+    GpuBuildResult r = gpu_build_bvh8(in, s);      // (synchronises the stream before it returns)
+    // A tree deeper than any kernel's stack (a chain of primitives over many orders of magnitude: nearest-neighbour clustering, like SAH, takes
+    // one off the rest at every level): built again by position -- every cluster with its Morton neighbour, log2(n) levels, whatever the areas
+    if (r.error == hipSuccess && r.n_prims != 0u && 2 * r.max_depth + 2 > (uint32_t)(8 + 56) && !device_split) {
+        if (ctx->build_verbose) std::fprintf(stderr, "[hrt] the tree is %u levels deep: built again by position\n", r.max_depth);
+        in.balanced = true; in.split.enabled = false;
+        r = gpu_build_bvh8(in, s);
+    }
     if (r.error != hipSuccess) return fail(ctx, r.error == hipErrorOutOfMemory ? HRT_ERR_OOM : HRT_ERR_HIP, "device build failed: %s (%s)", hipGetErrorString(r.error), r.where);
     {   // the tree's own buffers, as large as the build turned out to need
         const size_t nn = std::max<size_t>(r.n_prims ? r.n_nodes : 1u, 1u);

@@ -1492,6 +1492,31 @@ def test_deep_trees_at_and_beyond_the_path_kernels_node_stack(hrt, oracle, gpu_a
         assert depths == [12, 13], depths          # = kFusedMaxDepth and one more: both kernels ran
 
 
+def test_a_tree_too_deep_to_traverse_is_built_again_by_position(hrt, oracle, gpu_available):
+    """393 triangles whose size grows by 7 % each, over twelve orders of magnitude: nearest-neighbour clustering (like SAH) takes one
+    triangle off the rest at every level and the tree is deeper than any kernel's stack holds -- `hrt_tlas_build` used to say so and
+    give up (found by tools/stress_modes.py).  The device build now notices and builds again by position (every cluster with its Morton
+    neighbour: log2(n) levels); the image is the oracle's either way."""
+    if not gpu_available:
+        pytest.skip("no GPU")
+    r = hrt.Renderer(0, 0)
+    try:
+        for n, growth in ((393, 1.0728), (369, 1.0777)):
+            scene = hrt.scenes.growing_chain(n, growth, 96, 64, 2)
+            r.load_scene(scene)
+            r.set_frame(96, 64, 11, linear=True)
+            r.render(2)
+            st = r.stats()
+            assert st.bvh_depth <= 12 and st.bvh_triangles == n, (int(st.bvh_depth), int(st.bvh_triangles))
+            ref = oracle.OracleScene(scene).render(96, 64, oracle.rng_init(96, 64, 11), 2)
+            assert np.array_equal(r.linear.cpu().numpy().view(np.uint32), ref["linear"].view(np.uint32)), n
+            o, d = oracle.random_rays(20000, 3, 40.0)
+            got = r.trace_rays(o, d); want = oracle.OracleScene(scene, force_brute=True).trace(o, d)
+            assert np.array_equal(got[3], want[3]) and np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+    finally:
+        r.close()
+
+
 def test_record_arrays_beyond_32_bit_offsets_take_round_ones_kernel(hrt, oracle, gpu_available, monkeypatch):
     """k_fused addresses nodes and records by 32-bit byte offsets; arrays of 4 GiB and more take round 1's path kernel, which
     uses 64-bit addresses (csrc/hrt_api.cpp: fits_fused_kernel).  HRT_FUSED_MAX_BYTES lowers the limit so that a small scene
