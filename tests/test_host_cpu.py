@@ -335,3 +335,11 @@ def test_context_flags_of_the_binding_are_the_headers(hrt):
     for name, value in flags.items():
         assert getattr(hrt, "CTX_" + name) == value, name
         assert value & (value - 1) == 0, name
+
+
+def test_tools_compile():
+    """The measurement and stress scripts under tools/ are run by hand on the GPU box: at least they parse."""
+    import py_compile
+    from pathlib import Path
+    for path in sorted((Path(__file__).resolve().parent.parent / "tools").glob("*.py")):
+        py_compile.compile(str(path), doraise=True, cfile=f"/tmp/hrt_pyc_{path.stem}.pyc")
