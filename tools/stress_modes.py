@@ -17,6 +17,7 @@ bad = 0
 for k in range(n_scenes):
     kind = rng.integers(0, 8)
     w, h, spp = int(rng.integers(40, 160)), int(rng.integers(30, 120)), int(rng.integers(1, 7))
+    if os.environ.get("STRESS_BIG"): w, h, spp = int(rng.integers(300, 800)), int(rng.integers(200, 500)), int(rng.integers(1, 4))      # (fewer, larger frames)
     if kind == 0: scene = hrt.scenes.mixed_test_scene(int(rng.integers(10, 4000)), int(rng.integers(1, 60)), int(rng.integers(1, 1000)), w, h, spp)
     elif kind == 1: scene = hrt.scenes.particle_cloud(int(rng.integers(4, 900)), w, h, spp, subdiv=int(rng.integers(0, 3)), seed=int(rng.integers(1, 100)))
     elif kind == 2: scene = hrt.scenes.particle_scene(int(rng.integers(1, 300)), w, h, spp, frame=int(rng.integers(0, 5)))
