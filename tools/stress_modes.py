@@ -35,11 +35,18 @@ for k in range(n_scenes):
             if rng.random() < 0.7: it["material"], it["fuzz"] = "metal", float(rng.choice([0.0, 0.0, 0.05]))
     salt = int(rng.integers(1, 1 << 30))
     refs = {}
-    for two, reuse, hold in itertools.product((0, 1), (0, 1), ("", "1", "3")):
+    combos = list(itertools.product((0, 1), (0, 1), ("", "1", "3")))
+    if os.environ.get("STRESS_OTHER_MODES"):      # the other execution modes (flattened trees): wavefront pipeline, round 1's path kernel, the counting build
+        combos = [(0, 0, "fused0"), (0, 0, "fused2"), (0, 0, "count"), (0, 0, "fused-1")]
+    for two, reuse, hold in combos:
+        ctx_flags = 0
+        os.environ.pop("HRT_FUSED", None)
+        if hold.startswith("fused"): os.environ["HRT_FUSED"] = hold[5:]; hold = ""
+        elif hold == "count": ctx_flags = hrt.CTX_COUNT; hold = ""
         if hold: os.environ["HRT_LEAF_HOLD"] = hold
         else: os.environ.pop("HRT_LEAF_HOLD", None)
         os.environ["HRT_REFILL_THRESHOLD"] = str(int(rng.integers(1, 64)))
-        r = hrt.Renderer(0, (hrt.CTX_TWO_LEVEL if two else 0) | (hrt.CTX_REUSE_PRIMARY if reuse else 0))
+        r = hrt.Renderer(0, (hrt.CTX_TWO_LEVEL if two else 0) | (hrt.CTX_REUSE_PRIMARY if reuse else 0) | ctx_flags)
         try:
             r.load_scene(scene); r.set_frame(w, h, salt, linear=True); r.render(spp)
             got = r.linear.cpu().numpy().view(np.uint32).copy()
