@@ -1,6 +1,7 @@
 // hrt_accel.cpp -- acceleration structures behind the C ABI: BLAS objects, the merged world-space build, trees over
 // instances, the per-frame device refit (updateIAS), the Time-mode pose kernel's entry point, and the download /
 // host-build helpers the tests use.  Entry points and the reference call sites they replace: include/hrt.h.
+#include <thread>
 #include "hrt_internal.hpp"
 #include "build.h"
 
@@ -168,23 +169,35 @@ float instance_tables(const std::vector<HrtInstance> &inst, const std::vector<st
                       std::vector<float> &xf, std::vector<float> &inv, std::vector<uint32_t> &ident) {
     const size_t n = inst.size();
     xf.assign(12 * std::max<size_t>(n, 1), 0.0f); inv.assign(12 * std::max<size_t>(n, 1), 0.0f); ident.assign(std::max<size_t>(n, 1), 1u);
-    float smax = 1.0f;
-    for (size_t i = 0; i < n; ++i) {
-        const float *m = inst[i].transform;
-        std::memcpy(&xf[12 * i], m, 12 * sizeof(float));
-        const bool id = is_identity(m);
-        ident[i] = id ? 1u : 0u;
-        invert_affine(m, &inv[12 * i]);
-        const Blas &b = *blas[i];
-        if ((inst[i].visibilityMask & 1u) == 0 || !(b.lo[0] <= b.hi[0])) continue;
-        for (int c = 0; c < 8; ++c) {
-            const float q[3] = {(c & 1) ? b.hi[0] : b.lo[0], (c & 2) ? b.hi[1] : b.lo[1], (c & 4) ? b.hi[2] : b.lo[2]};
-            float w[3];
-            if (id) { w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; } else xf_point(m, q, w);
-            for (int a = 0; a < 3; ++a) if (std::isfinite(w[a])) smax = std::max(smax, std::fabs(w[a]));
+    const auto range = [&](size_t i0, size_t i1) {
+        float smax = 1.0f;
+        for (size_t i = i0; i < i1; ++i) {
+            const float *m = inst[i].transform;
+            std::memcpy(&xf[12 * i], m, 12 * sizeof(float));
+            const bool id = is_identity(m);
+            ident[i] = id ? 1u : 0u;
+            invert_affine(m, &inv[12 * i]);
+            const Blas &b = *blas[i];
+            if ((inst[i].visibilityMask & 1u) == 0 || !(b.lo[0] <= b.hi[0])) continue;
+            for (int c = 0; c < 8; ++c) {
+                const float q[3] = {(c & 1) ? b.hi[0] : b.lo[0], (c & 2) ? b.hi[1] : b.lo[1], (c & 4) ? b.hi[2] : b.lo[2]};
+                float w[3];
+                if (id) { w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; } else xf_point(m, q, w);
+                for (int a = 0; a < 3; ++a) if (std::isfinite(w[a])) smax = std::max(smax, std::fabs(w[a]));
+            }
         }
-    }
-    return smax;
+        return smax;
+    };
+    // (a DEM time step has 10^5 instances and a synchronous hrt_tlas_update derives these on the host in every frame: a few threads then --
+    // every instance writes its own entries, the largest coordinate is a maximum: the result does not depend on the split)
+    const unsigned hw = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (n < 32768u || hw < 2u) return range(0, n);
+    std::vector<float> part(hw, 1.0f);
+    std::vector<std::thread> pool;
+    for (unsigned k = 1; k < hw; ++k) pool.emplace_back([&, k] { part[k] = range(n * k / hw, n * (k + 1) / hw); });
+    part[0] = range(0, n / hw);
+    for (std::thread &th : pool) th.join();
+    return *std::max_element(part.begin(), part.end());
 }
 
 void launch_refit_phases(RefitArgs ra, const std::vector<std::pair<uint32_t, uint32_t>> &phases, hipStream_t s);
@@ -825,9 +838,27 @@ int build_tlas_into(HrtContext *ctx, Tlas &t, const std::vector<HrtInstance> &in
 }
 
 int download_instances(HrtContext *ctx, const HrtInstance *d_instances, uint32_t n, hipStream_t s, std::vector<HrtInstance> &inst) {
+    const size_t bytes = sizeof(HrtInstance) * (size_t)n;
+    if (n >= 16384u) {
+        // many instances (a DEM time step: 8 MB), every frame of a synchronous update loop: through pinned memory the context keeps
+        std::lock_guard<std::mutex> lk(ctx->pin_mu);
+        if (ctx->pin_bytes < bytes) {
+            if (ctx->pin_stage) (void)hipHostFree(ctx->pin_stage);
+            ctx->pin_stage = nullptr; ctx->pin_bytes = 0;
+            if (hipHostMalloc(&ctx->pin_stage, bytes, hipHostMallocDefault) == hipSuccess) ctx->pin_bytes = bytes;
+            else { (void)hipGetLastError(); ctx->pin_stage = nullptr; }
+        }
+        if (ctx->pin_stage) {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_stage, d_instances, bytes, hipMemcpyDeviceToHost, s));
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            const HrtInstance *p = static_cast<const HrtInstance *>(ctx->pin_stage);
+            inst.assign(p, p + n);
+            return HRT_OK;
+        }
+    }
     inst.resize(n);
     if (n) {
-        HIP_TRY(ctx, hipMemcpyAsync(inst.data(), d_instances, sizeof(HrtInstance) * (size_t)n, hipMemcpyDeviceToHost, s));
+        HIP_TRY(ctx, hipMemcpyAsync(inst.data(), d_instances, bytes, hipMemcpyDeviceToHost, s));
         HIP_TRY(ctx, hipStreamSynchronize(s));
     }
     return HRT_OK;

@@ -168,6 +168,7 @@ int hrt_ctx_destroy(HrtContext *ctx) {
         void *sp[] = {st.rays[0], st.rays[1], st.hit_tuvp, st.hit_inst, st.bin_items, st.chain, st.result, st.stages};
         for (void *p : sp) if (p) (void)hipFree(p);
     }
+    if (ctx->pin_stage) (void)hipHostFree(ctx->pin_stage);
     void *ptrs[] = {w.accum, w.slice_cost, w.slice_order, w.primary_cache, w.rows, ctx->d_jump, ctx->d_stats, ctx->d_hitgroups, ctx->d_inst_program};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (const ScratchArena &a : ctx->scratch_free) (void)hipFree(a.p);

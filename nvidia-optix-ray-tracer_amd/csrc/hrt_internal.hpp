@@ -133,6 +133,7 @@ struct HrtContext {
     std::unordered_map<uint64_t, std::shared_ptr<hrt::Blas>> blas;
     std::unordered_map<uint64_t, std::unique_ptr<hrt::Tlas>> tlas;
     uint64_t next_handle = 0x1000;
+    std::mutex pin_mu; void *pin_stage = nullptr; size_t pin_bytes = 0;      // pinned staging for the instance array of large synchronous updates (hrt_accel.cpp download_instances)
     std::mutex scratch_mu; std::vector<hrt::ScratchArena> scratch_free;      // scratch_acquire / scratch_release (hrt_accel.cpp)
     std::mutex pool_mu; std::vector<hrt::ScratchArena> pool_free; std::unordered_map<void *, size_t> pool_live; size_t pool_bytes = 0;   // pool_alloc / pool_release: the trees' device memory
     // materials
