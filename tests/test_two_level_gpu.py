@@ -207,6 +207,14 @@ def test_two_level_hundred_thousand_particles(hrt, oracle, gpu_available):
         r._torch.cuda.synchronize()
         print("10^5 particles: load_scene %.2f s, tree %d bytes, %d nodes, depth %d" % (t_load, s.bvh_alloc_bytes, s.bvh_nodes, s.bvh_depth))
         assert s.fused_fallback_launches == 0 and s0.tlas_rebuilds == 1
+        # a synchronous update at this size: the instance array comes back through pinned memory and the host derives the tables on a few
+        # threads (hrt_accel.cpp download_instances / instance_tables) -- the same tables, the same frame as the oracle's of the moved scene
+        for it in scene["instances"][1:]:
+            m = it["transform"].copy(); m[3] += np.float32(0.004); m[11] -= np.float32(0.006); it["transform"] = m
+        r.update_instances([it["transform"] for it in scene["instances"]])
+        after = r.stats()
+        assert after.tlas_refits == s.tlas_refits + 1 and after.tlas_rebuilds == s.tlas_rebuilds
+        _frame_matches(oracle, r, scene, 192, 128, 10)
     finally:
         r.close()
 
