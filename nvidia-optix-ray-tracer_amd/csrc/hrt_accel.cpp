@@ -163,6 +163,8 @@ void free_tlas_host(Tlas &t) {
     t.h_area = nullptr; t.area_ready = nullptr;
 }
 
+int g_instance_table_threads = 8;      // HRT_TABLE_THREADS
+
 // Per-instance tables of a set of instances: object->world, world->object, identity flags, and the
 // largest |coordinate| of the transformed BLAS boxes (what the padding of the tree is derived from).
 float instance_tables(const std::vector<HrtInstance> &inst, const std::vector<std::shared_ptr<Blas>> &blas,
@@ -190,7 +192,7 @@ float instance_tables(const std::vector<HrtInstance> &inst, const std::vector<st
     };
     // (a DEM time step has 10^5 instances and a synchronous hrt_tlas_update derives these on the host in every frame: a few threads then --
     // every instance writes its own entries, the largest coordinate is a maximum: the result does not depend on the split)
-    const unsigned hw = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    const unsigned hw = std::min((unsigned)std::max(g_instance_table_threads, 1), std::max(1u, std::thread::hardware_concurrency()));
     if (n < 32768u || hw < 2u) return range(0, n);
     std::vector<float> part(hw, 1.0f);
     std::vector<std::thread> pool;

@@ -122,6 +122,7 @@ struct ScratchArena { void *p = nullptr; size_t bytes = 0; };
 
 }  // namespace hrt
 
+namespace hrt { extern int g_instance_table_threads; }      // host threads that derive the per-instance tables of 32768 instances and more (HRT_TABLE_THREADS)
 using namespace hrt;
 
 struct HrtContext {
